@@ -1,0 +1,43 @@
+"""Shared builders for the parity tests: the synthetic checkpoints the golden fixtures were made on."""
+import os
+
+import numpy as np
+import torch
+
+from ladiffcodec_amd import synth
+from ladiffcodec_amd.spec import CodecConfig, UnetConfig
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+COND_CFG = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0)
+COND_SEED = 11
+
+CASES = {
+    # tag: (main codec cfg, unet cfg, weight seed)   -- must match tools/gen_golden.py
+    "r84": (CodecConfig(enc_ratios=(8, 4), quantization=False),
+            UnetConfig(dim=32, upsampling_ratios=(5, 2), unet_scale_cond=True), 21),
+    "r8": (CodecConfig(enc_ratios=(8,), quantization=False),
+           UnetConfig(dim=32, upsampling_ratios=(5, 4, 2), unet_scale_cond=False), 22),
+}
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def cond_sd_np():
+    return synth.codec_state_dict(COND_CFG, COND_SEED)
+
+
+def main_sd_np(tag):
+    mc, u, seed = CASES[tag]
+    return synth.ladiff_state_dict(mc, u, seed)
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

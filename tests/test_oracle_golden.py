@@ -1,0 +1,103 @@
+"""Pin the CPU oracle (oracle/ldc_oracle.py) to outputs of the reference itself (tests/golden/,
+made by tools/gen_golden.py).  CPU-only; this is what lets the GPU parity tests trust the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from ladiffcodec_amd import synth
+from oracle import ldc_oracle as O
+from helpers import CASES, COND_CFG, T, cond_sd_np, load_golden, main_sd_np, rel_err
+
+TOL = 2e-5   # fp32 CPU vs fp32 CPU, different op order only
+
+
+def test_schedule_tables_match_reference():
+    gold = load_golden("schedule")
+    mine = synth.cosine_schedule_buffers(1000)
+    assert set(mine) == set(gold)
+    for k in mine:
+        np.testing.assert_allclose(mine[k], gold[k], rtol=2e-6, atol=1e-12, err_msg=k)
+
+
+def test_sconv1d_padding_rules():
+    g = load_golden("primitives")
+    names = sorted({k.split(".")[0] for k in g if k.startswith("c_")})
+    assert len(names) == 7
+    for n in names:
+        k, s, d, causal = (int(v) for v in g[n + ".cfg"])
+        w = O.fold_weight_norm(T(g[n + ".g"]), T(g[n + ".v"]))
+        y = O.sconv1d(T(g[n + ".x"]), w, T(g[n + ".b"]), stride=s, dilation=d, causal=bool(causal))
+        assert y.shape == g[n + ".y"].shape, n
+        assert rel_err(y.numpy(), g[n + ".y"]) < TOL, n
+
+
+def test_sconvtranspose1d_trim_rules():
+    g = load_golden("primitives")
+    names = sorted({k.split(".")[0] for k in g if k.startswith("t_")})
+    assert len(names) == 5
+    for n in names:
+        k, s, d, causal = (int(v) for v in g[n + ".cfg"])
+        w = O.fold_weight_norm(T(g[n + ".g"]), T(g[n + ".v"])) if (n + ".g") in g else T(g[n + ".w"])
+        y = O.sconvtr1d(T(g[n + ".x"]), w, T(g[n + ".b"]), s, causal=bool(causal))
+        assert y.shape == g[n + ".y"].shape, n
+        assert rel_err(y.numpy(), g[n + ".y"]) < TOL, n
+
+
+def test_lstm_skip():
+    g = load_golden("primitives")
+    sd = {"p." + k[len("lstm.sd."):]: T(v) for k, v in g.items() if k.startswith("lstm.sd.")}
+    y = O.lstm_skip(T(g["lstm.x"]), sd, "p", 2)
+    assert rel_err(y.numpy(), g["lstm.y"]) < TOL
+
+
+def test_codec_encode_rvq_decode():
+    g = load_golden("codec_c1")
+    sd = synth.to_torch(cond_sd_np())
+    wav = T(g["wav"])
+    q, codes, margins, z = O.get_cond(sd, COND_CFG, wav)
+    assert rel_err(z.numpy(), g["z"]) < TOL
+    assert codes.shape == g["codes"].shape and codes.dtype == torch.int64
+    safe = margins.numpy() > 1e-3
+    assert safe.mean() > 0.95
+    assert np.array_equal(codes.numpy()[safe], g["codes"][safe])
+    if np.array_equal(codes.numpy(), g["codes"]):
+        assert rel_err(q.numpy(), g["quantized"]) < TOL
+    q15, codes15, _, _ = O.get_cond(sd, COND_CFG, wav, bandwidth=1.5)
+    assert codes15.shape[0] == 3 and np.array_equal(codes15.numpy(), g["codes_1p5"])
+    dec = O.seanet_decode(sd, COND_CFG, T(g["quantized"]))
+    assert rel_err(dec.numpy(), g["decoded"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["r84", "r8"])
+def test_unet_step_and_chain(tag):
+    g = load_golden("ladiff_" + tag)
+    mc, u, _ = CASES[tag]
+    sd = synth.to_torch(main_sd_np(tag))
+    cond, x = T(g["cond"]), T(g["x"])
+    assert rel_err(O.process_cond(sd, u, cond).numpy(), g["cond_proc"]) < TOL
+    for t in (0, 37):
+        eps = O.unet_forward(sd, u, x, torch.full((2,), t, dtype=torch.long), cond)
+        assert rel_err(eps.numpy(), g[f"eps_t{t}"]) < 5e-5, t
+    assert rel_err(O.cond_upsample(sd, u, cond).numpy(), g["img_up"]) < TOL
+    img0 = O.start_image(sd, u, cond)
+    assert rel_err(img0.numpy(), g["img0"]) < TOL
+    n = int(g["meta"][2])
+    noises = T(g["noises"])
+    one = O.p_sample(sd, u, x, 5, cond, noises[n - 1])
+    assert rel_err(one.numpy(), g["p_sample_t5"]) < 5e-5
+    lat = O.halfway_sampling(sd, u, img0, cond, n, noises)
+    assert rel_err(lat.numpy(), g["latents"]) < 2e-4
+    wav_raw = O.seanet_decode(sd, mc, T(g["latents"]))
+    assert rel_err(wav_raw.numpy(), g["wav_raw"]) < TOL
+    assert rel_err(O.output_normalise(T(g["wav_raw"])).numpy(), g["wav_out"]) < TOL
+
+
+def test_end_to_end_stage_tensors():
+    g = load_golden("ladiff_r84")
+    mc, u, _ = CASES["r84"]
+    out = O.decode_utterances(synth.to_torch(cond_sd_np()), COND_CFG, synth.to_torch(main_sd_np("r84")), mc, u,
+                              T(g["wav"]), int(g["meta"][2]), T(g["noises"]))
+    assert rel_err(out["cond"].numpy(), g["cond"]) < TOL
+    assert rel_err(out["img0"].numpy(), g["img0"]) < TOL
+    assert rel_err(out["latents"].numpy(), g["latents"]) < 2e-4
+    assert rel_err(out["wav"].numpy(), g["wav_out"]) < 1e-3

@@ -1,0 +1,200 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (/root/reference, imported read-only with
+placeholder modules for its absent deps) on seeded synthetic checkpoints and inputs.
+
+Run in the build container only:   python tools/gen_golden.py
+The fixtures hold inputs and expected outputs (data); the weights are regenerated from
+(config, seed) by ladiffcodec_amd.synth at test time, so no checkpoint is committed.
+
+Loading the synthetic state dicts into the reference modules with strict=True doubles as the check
+that ladiffcodec_amd/spec.py enumerates exactly the reference's key set and shapes.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+from ref_import import import_reference  # noqa: E402
+from ladiffcodec_amd import synth  # noqa: E402
+from ladiffcodec_amd.spec import CodecConfig, UnetConfig  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def build_cond_model(ref, cc: CodecConfig, seed: int):
+    # exactly as reference srcs/sample.py:63 (the `ratios=` kwarg is swallowed: quirk Q1)
+    m = ref.DiffAudioRep(rep_dims=cc.rep_dims, emb_dims=128, n_residual_layers=cc.n_residual_layers,
+                         n_filters=cc.n_filters, lstm=cc.lstm, quantization=True, bandwidth=cc.bandwidth,
+                         ratios=[8, 5, 4, 2], final_activation=None)
+    sd = synth.to_torch(synth.codec_state_dict(cc, seed))
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def build_main_model(ref, mc: CodecConfig, u: UnetConfig, seed: int):
+    # as reference srcs/sample.py:56 with the README flags (--run_diff --scaling_global --unet_scale_cond)
+    m = ref.DiffAudioRep(other_cond=True, rep_dims=mc.rep_dims, emb_dims=128, diff_dims=u.dim, n_filters=mc.n_filters,
+                         lstm=mc.lstm, n_residual_layers=mc.n_residual_layers, enc_ratios=list(mc.enc_ratios),
+                         upsampling_ratios=list(u.upsampling_ratios), run_diff=True, model_type="unet",
+                         scaling_global=True, unet_scale_cond=u.unet_scale_cond, unet_scale_x=u.unet_scale_x,
+                         sampling_timesteps=1000, quantization=False, bandwidth=3.0, cond_global=3.0, seq_length=16000)
+    sd = synth.to_torch(synth.ladiff_state_dict(mc, u, seed))
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+class NoiseTape:
+    """Replaces torch.randn_like inside the reference's ddpm_loss so the noise draws are known."""
+
+    def __init__(self, noises):
+        self.noises = noises
+        self.i = 0
+
+    def __call__(self, x):
+        n = self.noises[self.i]
+        self.i += 1
+        assert n.shape == x.shape
+        return n
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    import srcs.losses.ddpm_loss as ref_ddpm
+    from srcs.modules.conv import SConv1d, SConvTranspose1d
+    from srcs.modules.lstm import SLSTM
+
+    # ---------------------------------------------------------------- schedule tables (a9)
+    diff = ref_ddpm.GaussianDiffusion1D(type("M", (torch.nn.Module,), {"channels": 128, "self_condition": False})(),
+                                        seq_length=16, sampling_timesteps=1000)
+    np.savez_compressed(os.path.join(OUT, "schedule.npz"), **{k: np32(v) for k, v in diff.state_dict().items()})
+
+    # ---------------------------------------------------------------- primitive KATs (L1)
+    g = torch.Generator().manual_seed(7)
+    kat = {}
+    cases = [  # name, cin, cout, k, stride, dilation, causal, length
+        ("c_k7", 8, 16, 7, 1, 1, True, 37), ("c_k4s2", 8, 16, 4, 2, 1, True, 37), ("c_k10s5", 8, 8, 10, 5, 1, True, 43),
+        ("c_k16s8", 4, 8, 16, 8, 1, True, 100), ("c_k3d2", 8, 8, 3, 1, 2, True, 21), ("c_k3_nc", 8, 8, 3, 1, 1, False, 21),
+        ("c_k7_short", 4, 4, 7, 1, 1, True, 5),
+    ]
+    for name, cin, cout, k, s, d, causal, length in cases:
+        m = SConv1d(cin, cout, k, stride=s, dilation=d, causal=causal, norm="weight_norm")
+        with torch.no_grad():
+            m.conv.conv.weight_g.mul_(torch.rand(cout, 1, 1, generator=g) + 0.5)
+        x = torch.randn(2, cin, length, generator=g)
+        with torch.no_grad():
+            y = m(x)
+        kat[name + ".x"] = np32(x); kat[name + ".y"] = np32(y)
+        kat[name + ".g"] = np32(m.conv.conv.weight_g); kat[name + ".v"] = np32(m.conv.conv.weight_v)
+        kat[name + ".b"] = np32(m.conv.conv.bias)
+        kat[name + ".cfg"] = np.array([k, s, d, int(causal)], np.int64)
+    tcases = [("t_k16s8_c", 8, 4, 16, 8, True, 9, "weight_norm"), ("t_k4s2_c", 8, 8, 4, 2, True, 13, "weight_norm"),
+              ("t_k10s5_nc", 8, 8, 10, 5, False, 11, "none"), ("t_k4s2_nc", 8, 8, 4, 2, False, 11, "none"),
+              ("t_k8s4_nc", 8, 8, 8, 4, False, 7, "none")]
+    for name, cin, cout, k, s, causal, length, norm in tcases:
+        m = SConvTranspose1d(cin, cout, k, stride=s, causal=causal, norm=norm, trim_right_ratio=1.0)
+        x = torch.randn(2, cin, length, generator=g)
+        with torch.no_grad():
+            y = m(x)
+        kat[name + ".x"] = np32(x); kat[name + ".y"] = np32(y)
+        if norm == "weight_norm":
+            kat[name + ".g"] = np32(m.convtr.convtr.weight_g); kat[name + ".v"] = np32(m.convtr.convtr.weight_v)
+        else:
+            kat[name + ".w"] = np32(m.convtr.convtr.weight)
+        kat[name + ".b"] = np32(m.convtr.convtr.bias)
+        kat[name + ".cfg"] = np.array([k, s, 1, int(causal)], np.int64)
+    lstm = SLSTM(16, num_layers=2)
+    x = torch.randn(3, 16, 11, generator=g)
+    with torch.no_grad():
+        y = lstm(x)
+    kat["lstm.x"] = np32(x); kat["lstm.y"] = np32(y)
+    for k_, v_ in lstm.state_dict().items():
+        kat["lstm.sd." + k_] = np32(v_)
+    np.savez_compressed(os.path.join(OUT, "primitives.npz"), **kat)
+
+    # ---------------------------------------------------------------- codec round trip (config C1 shape; a3-a5, a16)
+    cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0)
+    cond_model = build_cond_model(ref, cc, seed=11)
+    wav = torch.from_numpy(synth.synthetic_wav(2, 6400, seed=1234)) * 0.5
+    with torch.no_grad():
+        z = cond_model.encoder(wav)
+        q = cond_model.quantizer(z, sample_rate=cond_model.frame_rate, bandwidth=cond_model.bandwidth)
+        q15 = cond_model.quantizer(z, sample_rate=cond_model.frame_rate, bandwidth=1.5)
+        cond = cond_model.get_cond(wav)
+        dec = cond_model.decoder(q.quantized)
+    assert torch.equal(cond, q.quantized)
+    np.savez_compressed(os.path.join(OUT, "codec_c1.npz"), wav=np32(wav), z=np32(z), quantized=np32(q.quantized),
+                        codes=q.codes.numpy().astype(np.int64), quantized_1p5=np32(q15.quantized),
+                        codes_1p5=q15.codes.numpy().astype(np.int64), decoded=np32(dec),
+                        meta=np.array([11, 6400], np.int64))
+    print("codec_c1: z", tuple(z.shape), "codes", tuple(q.codes.shape), "decoded", tuple(dec.shape))
+
+    # ---------------------------------------------------------------- UNet single step + chain + e2e, [8,4] layout (C2 shape)
+    def ladiff_case(tag, mc, u, T, n_chain, seed_w, seed_in):
+        main = build_main_model(ref, mc, u, seed=seed_w)
+        gg = torch.Generator().manual_seed(seed_in)
+        wav = torch.from_numpy(synth.synthetic_wav(2, T, seed=seed_in)) * 0.5
+        L = T // mc.hop_length
+        out = {"wav": np32(wav), "meta": np.array([seed_w, T, n_chain], np.int64)}
+        with torch.no_grad():
+            cond = cond_model.get_cond(wav)
+            out["cond"] = np32(cond)
+            # single UNet call at two timesteps, random x (a10-a15)
+            x = torch.randn(2, 128, L, generator=gg) * 0.7
+            for t in (0, 37):
+                tt = torch.full((2,), t, dtype=torch.long)
+                out[f"eps_t{t}"] = np32(main.diff_model(x, tt, cond))
+            out["x"] = np32(x)
+            out["cond_proc"] = np32(main.diff_model.process_cond(cond))
+            # start image (a6): sample.py:125-129
+            img = cond
+            for layer in main.diff_model.upsampling_layers:
+                img = layer(img)
+            out["img_up"] = np32(img)
+            img = img / (torch.max(torch.abs(img.flatten())) + 1e-8)
+            out["img0"] = np32(img)
+            # chain (a7, a8) with recorded noise
+            noises = torch.randn(n_chain, 2, 128, L, generator=gg)
+            tape = NoiseTape(list(noises))
+            ref_ddpm.torch.randn_like, saved = tape, ref_ddpm.torch.randn_like
+            try:
+                # NB: ddpm_loss uses `torch.randn_like`; patching the attribute on the module object `torch`
+                # is global, so restore it right after.
+                lat = main.diffusion.halfway_sampling(img=img.clone(), condition=cond, t=n_chain)
+                one, _ = (main.diffusion.p_sample(x.clone(), 5, cond))
+            finally:
+                ref_ddpm.torch.randn_like = saved
+            assert tape.i == n_chain  # n_chain-1 draws in the chain (t>0) + 1 in the single p_sample
+            out["noises"] = np32(noises)
+            out["latents"] = np32(lat)
+            out["p_sample_t5"] = np32(one)       # used noises[n_chain-1]
+            dec = main.decoder(lat)
+            out["wav_raw"] = np32(dec)
+            y = dec / (torch.std(dec.flatten()) + 1e-8)
+            y = y / (torch.max(torch.abs(y.flatten())) + 1e-8)
+            out["wav_out"] = np32(y)
+        np.savez_compressed(os.path.join(OUT, f"ladiff_{tag}.npz"), **out)
+        print(f"ladiff_{tag}: L={L} eps", out["eps_t0"].shape, "latents absmax", float(np.abs(out["latents"]).max()))
+
+    mc84 = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    u84 = UnetConfig(dim=32, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    ladiff_case("r84", mc84, u84, T=5120, n_chain=4, seed_w=21, seed_in=4321)
+    mc8 = CodecConfig(enc_ratios=(8,), quantization=False)
+    u8 = UnetConfig(dim=32, upsampling_ratios=(5, 4, 2), unet_scale_cond=False)
+    ladiff_case("r8", mc8, u8, T=2560, n_chain=3, seed_w=22, seed_in=999)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""Import the read-only reference (/root/reference) in THIS container only.
+
+Generator-side helper for tools/gen_golden.py.  The reference cannot be imported as
+shipped (missing in-repo modules + absent third-party deps), so the
+absent modules are registered as inert placeholders before `srcs.model` is imported.
+Nothing here is shipped to, or usable on, the GPU box.
+"""
+import sys
+import types
+
+import torch
+from torch import nn
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def _placeholder(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Inert(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+class _ZeroSDR(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+    def forward(self, est, tgt):
+        return torch.zeros(est.shape[0])
+
+
+def import_reference():
+    """Returns the reference's `srcs.model` module (DiffAudioRep lives there)."""
+    if "srcs.model" in sys.modules:
+        return sys.modules["srcs.model"]
+    ta = _placeholder("torchaudio")
+    ta.transforms = _placeholder("torchaudio.transforms", MelSpectrogram=_Inert, Spectrogram=_Inert)
+    ta.functional = _placeholder("torchaudio.functional")
+    _placeholder("asteroid")
+    _placeholder("asteroid.losses")
+    _placeholder("asteroid.losses.sdr", MultiSrcNegSDR=_ZeroSDR)
+    _placeholder("labml_helpers")
+    _placeholder("labml_helpers.module", Module=nn.Module)
+    _placeholder("labml_nn")
+    _placeholder("labml_nn.diffusion")
+    _placeholder("labml_nn.diffusion.ddpm")
+    _placeholder("labml_nn.diffusion.ddpm.utils",
+                 gather=lambda c, t: c.gather(-1, t).reshape(-1, 1, 1, 1))
+    _placeholder("pesq", pesq=None)
+    _placeholder("librosa")
+    _placeholder("srcs.modules.transformer_discrete", Transformer=object)
+    _placeholder("srcs.losses.discrete_diff", AbsorbingDiffusion=object)
+    sys.path.insert(0, REFERENCE_ROOT)
+    import srcs.model as ref_model  # noqa: E402
+    return ref_model
