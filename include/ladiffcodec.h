@@ -1,0 +1,161 @@
+/*
+ * ladiffcodec.h  --  C ABI of the MI355X-native LaDiffCodec decode path (libladiffcodec.so).
+ *
+ * The reference (haiciyang/LaDiffCodec) is pure Python/PyTorch and exposes no plugin / FFI layer;
+ * its hot path is `nn.Module` calls made by `synthesis()` (srcs/sample.py:50-136).  Each entry point
+ * below replaces one of those calls; the reference call site it stands in for is cited next to it.
+ * The Python host in `ladiffcodec_amd/` binds these with ctypes and mirrors the reference's module
+ * attributes (`get_cond`, `diff_model.upsampling_layers`, `diffusion.halfway_sampling`, `decoder`).
+ *
+ * Conventions
+ *   - Every function returns 0 on success or a negative LDC_E_* code; `ldc_last_error()` returns a
+ *     thread-local human-readable message for the last failure.  No C++ exception crosses the ABI.
+ *   - Tensor arguments are DEVICE pointers owned by the caller, contiguous, in the reference's own
+ *     layouts: activations [B, C, L] float32, RVQ codes [n_q, B, F] int64.  The caller keeps them
+ *     alive until `stream` has been synchronised.  `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  All work is asynchronous on that stream; the library never
+ *     calls hipDeviceSynchronize in a stage call.
+ *   - Weights are handed over on the HOST (float32, the `.amlt` state-dict tensors,
+ *     srcs/utils.py:98-108), one call per state-dict key, then folded / packed / uploaded by
+ *     `ldc_finalize_weights`.
+ *   - A context is bound to one device and is not thread-safe (one context per rank / stream).
+ *   - Internally activations are channels-last [B, L, C] in the context's compute dtype
+ *     (LDC_F32: exact-fp32 MFMA path for parity; LDC_BF16: bf16 storage + bf16 MFMA, fp32
+ *     accumulation, fp32 diffusion state).
+ */
+#ifndef LADIFFCODEC_H_
+#define LADIFFCODEC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDC_OK 0
+#define LDC_E_INVALID -1   /* bad argument / unsupported configuration          */
+#define LDC_E_STATE -2     /* call out of order (e.g. stage before finalize)    */
+#define LDC_E_MISSING -3   /* strict load: missing / unexpected / mis-shaped key */
+#define LDC_E_HIP -4       /* a HIP runtime call failed                          */
+#define LDC_E_NOMEM -5
+
+#define LDC_F32 0
+#define LDC_BF16 1
+
+/* which of the two DiffAudioRep instances a call addresses (srcs/sample.py:56 and :63) */
+#define LDC_MODEL_MAIN 0   /* --model_path      : autoencoder [enc_ratios] + Unet1D + diffusion */
+#define LDC_MODEL_COND 1   /* --model_for_cond  : EnCodec-style codec, always ratios [8,5,4,2] (quirk Q1) */
+
+#define LDC_MAX_RATIOS 8
+
+typedef struct ldc_ctx ldc_ctx;
+
+/* Mirrors the argparse flags of srcs/sample.py:141-201 that shape the two models. */
+typedef struct ldc_config {
+  int32_t compute_dtype;                 /* LDC_F32 | LDC_BF16 */
+  /* shared SEANet hyper-parameters (model.py:52-55) */
+  int32_t rep_dims;                      /* --rep_dims            (128) */
+  int32_t n_filters;                     /* --n_filters           (32)  */
+  int32_t n_residual_layers;             /* --n_residual_layers   (1)   */
+  int32_t lstm;                          /* --lstm                (2)   */
+  /* main model */
+  int32_t n_enc_ratios;                  /* --enc_ratios          ([8]) */
+  int32_t enc_ratios[LDC_MAX_RATIOS];
+  int32_t diff_dims;                     /* --diff_dims           (256) */
+  int32_t n_upsampling_ratios;           /* --upsampling_ratios   ([5,4,2]); 0 = None */
+  int32_t upsampling_ratios[LDC_MAX_RATIOS];
+  int32_t unet_scale_cond;               /* --unet_scale_cond */
+  int32_t unet_scale_x;                  /* --unet_scale_x    */
+  /* cond model */
+  int32_t has_cond_model;                /* --model_for_cond given */
+  float cond_bandwidth;                  /* --cond_bandwidth      (3.0): builds floor(1000*bw / (50*10)) codebooks */
+  /* capacity hints (workspaces are sized lazily; these only pre-size) */
+  int32_t max_batch;
+  int32_t max_latent_len;
+  uint64_t noise_seed;                   /* device Philox stream used when noise == NULL */
+} ldc_config;
+
+const char* ldc_last_error(void);
+const char* ldc_version(void);
+
+/* lifecycle ---------------------------------------------------------------------------------- */
+int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out);
+int ldc_destroy(ldc_ctx* ctx);
+
+/* load_model(model, path, strict) -- srcs/utils.py:98-108.  One call per state-dict entry (after
+ * the caller stripped any `module.` prefix).  `data` is a host float32 buffer of prod(shape)
+ * elements.  Keys under `diffusion.model.*` alias `diff_model.*` and may be passed or skipped. */
+int ldc_set_weight(ldc_ctx* ctx, int which, const char* key, const float* data, const int64_t* shape, int ndim);
+/* strict != 0 reproduces load_state_dict(strict=True): every expected key present with the expected
+ * shape, no unexpected key.  Folds weight-norm (conv.py:27-30) and weight-standardisation
+ * (unet.py:73-78, eps 1e-5, fp32) once, packs for MFMA, builds the timestep scale/shift table. */
+int ldc_finalize_weights(ldc_ctx* ctx, int strict);
+
+/* stages ---------------------------------------------------------------------------------------- */
+/* model.encoder(wav)  (seanet.py:153)            wav [B,1,T] -> z [B,rep_dims,T/hop]            */
+int ldc_seanet_encode(ldc_ctx* ctx, int which, const float* wav, int B, int T, float* z_out, void* stream);
+/* model.decoder(z)    (seanet.py:246; sample.py:131)   z [B,rep_dims,L] -> wav [B,1,L*hop]      */
+int ldc_seanet_decode(ldc_ctx* ctx, int which, const float* z, int B, int L, float* wav_out, void* stream);
+/* model.quantizer(z, frame_rate, bandwidth) in eval (vq.py:69-84, core_vq.py:324-342).
+ * n_q = number of codebooks used.  codes_out [n_q,B,F] int64 (may be NULL), quantized_out [B,D,F]. */
+int ldc_rvq_encode(ldc_ctx* ctx, const float* z, int B, int F, int n_q, int64_t* codes_out, float* quantized_out,
+                   void* stream);
+/* quantizer.decode(codes) (core_vq.py:356-362) */
+int ldc_rvq_decode(ldc_ctx* ctx, const int64_t* codes, int B, int F, int n_q, float* quantized_out, void* stream);
+/* model_for_cond.get_cond(wav) (model.py:223-231) = encode + rvq, fused on one stream.
+ * codes_out may be NULL.  bandwidth <= 0 means the configured cond_bandwidth. */
+int ldc_get_cond(ldc_ctx* ctx, const float* wav, int B, int T, float bandwidth, float* cond_out, int64_t* codes_out,
+                 void* stream);
+/* for layer in diff_model.upsampling_layers: img = layer(img)   (sample.py:125-128, unet.py:372-377)
+ * normalise: 0 = raw; 1 = img /= max|img|+1e-8 over the whole tensor (sample.py:129);
+ *            2 = the same per batch item (a batch of independent utterances). cond [B,C,F] -> [B,C,L] */
+int ldc_cond_upsample(ldc_ctx* ctx, const float* cond, int B, int F, int normalise, float* img_out, void* stream);
+/* diff_model(x, t, cond)  (Unet1D.forward, unet.py:422-469).  cond is the RAW condition [B,C,F]
+ * (process_cond runs inside, as in the reference).  t is one timestep for the whole batch: the sampler
+ * only ever calls the model with torch.full((b,), t) (ddpm_loss.py:247); per-item t is not supported. */
+int ldc_unet_forward(ldc_ctx* ctx, const float* x, int t, const float* cond, int B, int L, int F, float* eps_out,
+                     void* stream);
+/* diffusion.p_sample(x, t, cond) (ddpm_loss.py:244-251).  noise [B,C,L] or NULL (NULL: Philox draw;
+ * ignored when t == 0). x is updated in place. */
+int ldc_p_sample(ldc_ctx* ctx, float* x_inout, int t, const float* cond, const float* noise, int B, int L, int F,
+                 void* stream);
+/* diffusion.halfway_sampling(img, t=n_steps, condition=cond) (ddpm_loss.py:370-385): t = n_steps-1..0.
+ * noise [n_steps,B,C,L] (entry j is consumed at iteration j; the last is unused) or NULL.
+ * One denoise step is captured in a hipGraph keyed by (B, L, F) and replayed n_steps times. */
+int ldc_denoise(ldc_ctx* ctx, float* img_inout, const float* cond, const float* noise, int n_steps, int B, int L,
+                int F, void* stream);
+/* sample.py:133-134: x /= std(x)+1e-8 ; x /= max|x|+1e-8.  per_item: 0 whole tensor, 1 per item. */
+int ldc_output_normalise(ldc_ctx* ctx, float* wav_inout, int B, int T, int per_item, void* stream);
+/* The whole per-batch body of synthesis() (sample.py:94-134) on resident buffers:
+ * wav [B,1,T] -> wav_out [B,1,T]; optional stage outputs may be NULL. per_item as above. */
+int ldc_decode(ldc_ctx* ctx, const float* wav, int B, int T, int n_steps, const float* noise, int per_item,
+               float* wav_out, float* latents_out, float* cond_out, int64_t* codes_out, void* stream);
+
+/* L1 primitives (reference srcs/modules/conv.py, lstm.py), exposed for the parity tests ---------- */
+/* SConv1d.forward (conv.py:217-232), reflect padding.  w [Cout,Cin,k] (already weight-norm folded),
+ * all HOST float32; x/y DEVICE [B,Cin,L] / [B,Cout,Lout].  pre_elu applies ELU to the input. */
+int ldc_sconv1d(ldc_ctx* ctx, const float* x, int B, int Cin, int L, const float* w_host, const float* b_host,
+                int Cout, int k, int stride, int dilation, int causal, int pre_elu, float* y, void* stream);
+/* SConvTranspose1d.forward (conv.py:252-274), w [Cin,Cout,k] host. */
+int ldc_sconvtr1d(ldc_ctx* ctx, const float* x, int B, int Cin, int L, const float* w_host, const float* b_host,
+                  int Cout, int k, int stride, int causal, float* y, void* stream);
+/* SLSTM.forward (lstm.py:22-28): weights host, PyTorch layout [4H,H] / [4H] per layer, order
+ * w_ih, w_hh, b_ih, b_hh for layer 0 then layer 1 ... */
+int ldc_slstm(ldc_ctx* ctx, const float* x, int B, int H, int T, const float* const* weights_host, int layers,
+              float* y, void* stream);
+
+/* introspection ------------------------------------------------------------------------------- */
+/* Copy a named intermediate of the last ldc_unet_forward (channels-last -> [B,C,L] fp32).
+ * Names: "cond_proc", "init", "down0".."downN", "mid", "up0".."upN".  For tests. */
+int ldc_unet_debug_tap(ldc_ctx* ctx, const char* name, float* out, int64_t capacity_elems, void* stream);
+/* Algorithmic work of one UNet step for (B, L): flops and bytes (activations + weights, compute dtype). */
+int ldc_unet_step_cost(ldc_ctx* ctx, int B, int L, double* flops, double* bytes);
+/* Timing of the dominant kernel class, measured with hipEvents on the launch stream when enabled.
+ * ldc_profile_enable(ctx, 1) makes ldc_denoise bracket every conv-GEMM launch (eager, no graph). */
+int ldc_profile_enable(ldc_ctx* ctx, int on);
+int ldc_profile_read(ldc_ctx* ctx, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LADIFFCODEC_H_ */

@@ -1,0 +1,259 @@
+// attention.hip -- LinearAttention core and bottleneck softmax Attention core (4 heads x 32).
+//
+// LinearAttention.forward (reference srcs/modules/unet.py:208-222), between to_qkv and to_out:
+//   q = softmax_d(q) * 32^-1/2 ; k = softmax_n(k) ; context[d,e] = sum_n k[d,n] v[e,n] ;
+//   out[e,n] = sum_d context[d,e] q[d,n]
+// Attention.forward (:234-246): out = softmax_j((q*scale)^T k) v.
+// The 1x1 convs either side run on the conv-GEMM kernel.  These cores are HBM/L2-bound streaming
+// passes over the qkv rows ([rows][384], channels-last): linattn reads qkv twice (k statistics,
+// then k,v) plus q once and writes [rows][128]; algorithmic bytes ~ rows * (384*2 + 128) * sizeof(dtype).
+#include "ldc_kernels.h"
+
+namespace ldc {
+
+__device__ __forceinline__ float abf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short af2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+template <typename T>
+__device__ __forceinline__ float ld1(const void* p, size_t i);
+template <>
+__device__ __forceinline__ float ld1<float>(const void* p, size_t i) { return reinterpret_cast<const float*>(p)[i]; }
+template <>
+__device__ __forceinline__ float ld1<__bf16>(const void* p, size_t i) {
+  return abf2f(reinterpret_cast<const unsigned short*>(p)[i]);
+}
+template <typename T>
+__device__ __forceinline__ void st1(void* p, size_t i, float v);
+template <>
+__device__ __forceinline__ void st1<float>(void* p, size_t i, float v) { reinterpret_cast<float*>(p)[i] = v; }
+template <>
+__device__ __forceinline__ void st1<__bf16>(void* p, size_t i, float v) {
+  reinterpret_cast<unsigned short*>(p)[i] = af2bf(v);
+}
+
+// order-preserving float <-> uint key so that atomicMax(unsigned) implements a float max from a zeroed buffer
+__device__ __forceinline__ unsigned fkey(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+  const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(b);
+}
+
+// ws layout per item b (floats): kmax_key[HD] | ksum[HD] | ctx[H][D][D]
+__host__ __device__ inline size_t linattn_ws_per_item(int H, int D) { return (size_t)2 * H * D + (size_t)H * D * D; }
+
+// ---- pass 1: column max of k over positions ----
+template <typename T>
+__global__ __launch_bounds__(256) void linattn_kmax_kernel(const void* qkv, float* ws, int L, int HD, int rows_per_block,
+                                                           size_t ws_stride) {
+  __shared__ float red[256];
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(L, r0 + rows_per_block);
+  const int col = threadIdx.x % HD, ph = threadIdx.x / HD, nph = 256 / HD;
+  float m = -INFINITY;
+  for (int r = r0 + ph; r < r1; r += nph) m = fmaxf(m, ld1<T>(qkv, ((size_t)(b * L + r)) * (3 * HD) + HD + col));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  if (ph == 0) {
+    for (int p = 1; p < nph; ++p) m = fmaxf(m, red[p * HD + col]);
+    atomicMax(reinterpret_cast<unsigned*>(ws + (size_t)b * ws_stride) + col, fkey(m));
+  }
+}
+
+// ---- pass 2: unnormalised context and column sums over a chunk of rows, atomically merged ----
+template <typename T, int D>
+__global__ __launch_bounds__(256) void linattn_ctx_kernel(const void* qkv, float* ws, int L, int H, int rows_per_block,
+                                                          size_t ws_stride) {
+  constexpr int TR = 64;
+  __shared__ float sp[TR][D + 1];
+  __shared__ float sv[TR][D];
+  __shared__ float skmax[D];
+  const int HD = H * D;
+  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  float* wsb = ws + (size_t)b * ws_stride;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(L, r0 + rows_per_block);
+  const int tid = threadIdx.x;
+  if (tid < D) skmax[tid] = fkey_inv(reinterpret_cast<const unsigned*>(wsb)[h * D + tid]);
+  __syncthreads();
+  const int d = tid / 8, e0 = (tid % 8) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float ssum = 0.f;
+  for (int t0 = r0; t0 < r1; t0 += TR) {
+    const int nr = min(TR, r1 - t0);
+    for (int idx = tid; idx < TR * D; idx += 256) {
+      const int r = idx / D, c = idx % D;
+      float p = 0.f, v = 0.f;
+      if (r < nr) {
+        const size_t base = ((size_t)(b * L + t0 + r)) * (3 * HD);
+        p = __expf(ld1<T>(qkv, base + HD + h * D + c) - skmax[c]);
+        v = ld1<T>(qkv, base + 2 * HD + h * D + c);
+      }
+      sp[r][c] = p;
+      sv[r][c] = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < TR; ++r) {
+      const float p = sp[r][d];
+      const float4 v4 = *reinterpret_cast<const float4*>(&sv[r][e0]);
+      acc[0] += p * v4.x; acc[1] += p * v4.y; acc[2] += p * v4.z; acc[3] += p * v4.w;
+      ssum += p;
+    }
+    __syncthreads();
+  }
+  float* ctx = wsb + 2 * HD + (size_t)h * D * D;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) atomicAdd(&ctx[d * D + e0 + j], acc[j]);
+  if ((tid % 8) == 0) atomicAdd(&wsb[HD + h * D + d], ssum);
+}
+
+// ---- pass 3: out[n, h*D+e] = sum_d (ctx[d][e]/ksum[d]) * softmax_d(q[n,h,:])[d] * scale ----
+template <typename T, int D>
+__global__ __launch_bounds__(256) void linattn_out_kernel(const void* qkv, void* out, const float* ws, int L, int H,
+                                                          size_t ws_stride, float scale) {
+  constexpr int HS = D * D + 8;   // padded head stride: the 4 heads of a wave hit different banks
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sctx = reinterpret_cast<float*>(smem_raw);   // [H][HS]
+  const int HD = H * D;
+  const int rows_per_block = 256 / H;
+  const int b = blockIdx.y;
+  const float* wsb = ws + (size_t)b * ws_stride;
+  for (int idx = threadIdx.x; idx < H * D * D; idx += 256) {
+    const int h = idx / (D * D), rem = idx % (D * D), d = rem / D;
+    sctx[h * HS + rem] = wsb[2 * HD + idx] / wsb[HD + h * D + d];
+  }
+  __syncthreads();
+  const int h = threadIdx.x % H;
+  const int r = blockIdx.x * rows_per_block + threadIdx.x / H;
+  if (r >= L) return;
+  const size_t base = ((size_t)(b * L + r)) * (3 * HD) + h * D;
+  float q[D];
+  float m = -INFINITY;
+#pragma unroll
+  for (int d = 0; d < D; ++d) { q[d] = ld1<T>(qkv, base + d); m = fmaxf(m, q[d]); }
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) { q[d] = __expf(q[d] - m); s += q[d]; }
+  const float inv = scale / s;
+#pragma unroll
+  for (int d = 0; d < D; ++d) q[d] *= inv;
+  const float* c = sctx + h * HS;
+  const size_t obase = ((size_t)(b * L + r)) * HD + h * D;
+#pragma unroll
+  for (int e0 = 0; e0 < D; e0 += 4) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float4 cv = *reinterpret_cast<const float4*>(&c[d * D + e0]);
+      o.x += cv.x * q[d]; o.y += cv.y * q[d]; o.z += cv.z * q[d]; o.w += cv.w * q[d];
+    }
+    st1<T>(out, obase + e0 + 0, o.x); st1<T>(out, obase + e0 + 1, o.y);
+    st1<T>(out, obase + e0 + 2, o.z); st1<T>(out, obase + e0 + 3, o.w);
+  }
+}
+
+hipError_t launch_linattn(int dt, const void* qkv, void* out, float* ws, int B, int L, int heads, int dim_head,
+                          hipStream_t s) {
+  if (dim_head != 32 || heads * dim_head > 256 || 256 % (heads * dim_head) || 256 % heads) return hipErrorInvalidValue;
+  const int HD = heads * dim_head;
+  const size_t wss = linattn_ws_per_item(heads, dim_head);
+  hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * wss * sizeof(float), s);
+  if (e != hipSuccess) return e;
+  const int rpb = 128;
+  const int chunks = (L + rpb - 1) / rpb;
+  const float scale = 1.0f / sqrtf((float)dim_head);
+  const size_t lds_out = (size_t)heads * (dim_head * dim_head + 8) * sizeof(float);
+  const int rows_out = 256 / heads;
+  if (dt == DT_F32) {
+    hipLaunchKernelGGL(linattn_kmax_kernel<float>, dim3(chunks, B), dim3(256), 0, s, qkv, ws, L, HD, rpb, wss);
+    hipLaunchKernelGGL((linattn_ctx_kernel<float, 32>), dim3(chunks, B * heads), dim3(256), 0, s, qkv, ws, L, heads, rpb, wss);
+    hipLaunchKernelGGL((linattn_out_kernel<float, 32>), dim3((L + rows_out - 1) / rows_out, B), dim3(256), lds_out, s, qkv,
+                       out, ws, L, heads, wss, scale);
+  } else {
+    hipLaunchKernelGGL(linattn_kmax_kernel<__bf16>, dim3(chunks, B), dim3(256), 0, s, qkv, ws, L, HD, rpb, wss);
+    hipLaunchKernelGGL((linattn_ctx_kernel<__bf16, 32>), dim3(chunks, B * heads), dim3(256), 0, s, qkv, ws, L, heads, rpb, wss);
+    hipLaunchKernelGGL((linattn_out_kernel<__bf16, 32>), dim3((L + rows_out - 1) / rows_out, B), dim3(256), lds_out, s,
+                       qkv, out, ws, L, heads, wss, scale);
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full softmax attention at the bottleneck: one workgroup per (item, head); K and V of the head live in
+// LDS as fp32 (n <= 512), each thread owns query rows and runs an online softmax over the keys.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_full_kernel(const void* qkv, void* out, int L, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sk = reinterpret_cast<float*>(smem_raw);   // [L][D]
+  float* sv = sk + (size_t)L * D;                   // [L][D]
+  const int HD = H * D;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  for (int idx = threadIdx.x; idx < L * D; idx += 256) {
+    const int r = idx / D, c = idx % D;
+    const size_t base = ((size_t)(b * L + r)) * (3 * HD) + h * D + c;
+    sk[idx] = ld1<T>(qkv, base + HD);
+    sv[idx] = ld1<T>(qkv, base + 2 * HD);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += 256) {
+    float q[D], acc[D];
+    const size_t qb = ((size_t)(b * L + i)) * (3 * HD) + h * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { q[d] = ld1<T>(qkv, qb + d) * scale; acc[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float4* kj = reinterpret_cast<const float4*>(sk + (size_t)j * D);
+      float sdot = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 kv = kj[d4];
+        sdot += q[4 * d4] * kv.x + q[4 * d4 + 1] * kv.y + q[4 * d4 + 2] * kv.z + q[4 * d4 + 3] * kv.w;
+      }
+      const float mn = fmaxf(m, sdot);
+      const float corr = __expf(m - mn);
+      const float p = __expf(sdot - mn);
+      l = l * corr + p;
+      const float4* vj = reinterpret_cast<const float4*>(sv + (size_t)j * D);
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 vv = vj[d4];
+        acc[4 * d4] = acc[4 * d4] * corr + p * vv.x;
+        acc[4 * d4 + 1] = acc[4 * d4 + 1] * corr + p * vv.y;
+        acc[4 * d4 + 2] = acc[4 * d4 + 2] * corr + p * vv.z;
+        acc[4 * d4 + 3] = acc[4 * d4 + 3] * corr + p * vv.w;
+      }
+      m = mn;
+    }
+    const float inv = 1.0f / l;
+    const size_t ob = ((size_t)(b * L + i)) * HD + h * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) st1<T>(out, ob + d, acc[d] * inv);
+  }
+}
+
+hipError_t launch_attn_full(int dt, const void* qkv, void* out, int B, int L, int heads, int dim_head, hipStream_t s) {
+  if (dim_head != 32) return hipErrorInvalidValue;
+  const size_t lds = (size_t)2 * L * dim_head * sizeof(float);
+  if (lds > 150 * 1024) return hipErrorInvalidValue;
+  const float scale = 1.0f / sqrtf((float)dim_head);
+  static bool opt_in = false;
+  if (!opt_in) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<float, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<__bf16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    opt_in = true;
+  }
+  if (dt == DT_F32)
+    hipLaunchKernelGGL((attn_full_kernel<float, 32>), dim3(B * heads), dim3(256), lds, s, qkv, out, L, heads, scale);
+  else
+    hipLaunchKernelGGL((attn_full_kernel<__bf16, 32>), dim3(B * heads), dim3(256), lds, s, qkv, out, L, heads, scale);
+  return hipGetLastError();
+}
+
+}  // namespace ldc

@@ -1,0 +1,321 @@
+// diffusion.hip -- layout changes at the ABI boundary, max-abs scaling, the fused p_sample update,
+// the device-resident step counter, Philox noise and the output normalisation.
+//
+//   p_sample arithmetic  : reference srcs/losses/ddpm_loss.py:175-179 (x0 from eps), :237-238 (clamp),
+//                          :199-206 (posterior mean), :249-250 (noise unless t == 0)
+//   max-abs scaling      : unet.py:401-403 (per item, +1e-20) and sample.py:129 (whole tensor, +1e-8)
+//   output normalisation : sample.py:133-134
+// All kernels here are HBM-bound: p_sample_update moves 4 fp32 reads/writes + 2 dtype accesses per
+// element of [B,128,L].
+#include "ldc_kernels.h"
+
+namespace ldc {
+
+__device__ __forceinline__ float dbf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short df2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+template <typename T>
+__device__ __forceinline__ float dld(const void* p, size_t i);
+template <>
+__device__ __forceinline__ float dld<float>(const void* p, size_t i) { return reinterpret_cast<const float*>(p)[i]; }
+template <>
+__device__ __forceinline__ float dld<__bf16>(const void* p, size_t i) {
+  return dbf2f(reinterpret_cast<const unsigned short*>(p)[i]);
+}
+template <typename T>
+__device__ __forceinline__ void dst(void* p, size_t i, float v);
+template <>
+__device__ __forceinline__ void dst<float>(void* p, size_t i, float v) { reinterpret_cast<float*>(p)[i] = v; }
+template <>
+__device__ __forceinline__ void dst<__bf16>(void* p, size_t i, float v) {
+  reinterpret_cast<unsigned short*>(p)[i] = df2bf(v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// [B][C][L] f32  <->  [B][L][C] dt through a 32x32 LDS tile (both sides coalesced)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void to_cl_kernel(const float* x, void* y, int C, int L, const float* maxabs,
+                                                    int per_item, float eps) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float den = 1.0f;
+  if (maxabs) den = maxabs[per_item ? b : 0] + eps;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, l = l0 + tx;
+    tile[i][tx] = (c < C && l < L) ? x[((size_t)b * C + c) * L + l] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int l = l0 + i, c = c0 + tx;
+    if (l < L && c < C) {
+      float v = tile[tx][i];
+      if (maxabs) v = v / den;
+      dst<T>(y, ((size_t)b * L + l) * C + c, v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void from_cl_kernel(const void* x, float* y, int C, int L, const float* maxabs,
+                                                      int per_item, float eps) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float den = 1.0f;
+  if (maxabs) den = maxabs[per_item ? b : 0] + eps;
+  for (int i = ty; i < 32; i += 8) {
+    const int l = l0 + i, c = c0 + tx;
+    tile[i][tx] = (c < C && l < L) ? dld<T>(x, ((size_t)b * L + l) * C + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, l = l0 + tx;
+    if (l < L && c < C) {
+      float v = tile[tx][i];
+      if (maxabs) v = v / den;
+      y[((size_t)b * C + c) * L + l] = v;
+    }
+  }
+}
+
+hipError_t launch_to_cl(int dt, const float* x, void* y, int B, int C, int L, const float* maxabs, int per_item,
+                        float eps, hipStream_t s) {
+  dim3 grid((L + 31) / 32, (C + 31) / 32, B);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(to_cl_kernel<float>, grid, dim3(256), 0, s, x, y, C, L, maxabs, per_item, eps);
+  else
+    hipLaunchKernelGGL(to_cl_kernel<__bf16>, grid, dim3(256), 0, s, x, y, C, L, maxabs, per_item, eps);
+  return hipGetLastError();
+}
+
+hipError_t launch_from_cl(int dt, const void* x, float* y, int B, int C, int L, const float* maxabs, int per_item,
+                          float eps, hipStream_t s) {
+  dim3 grid((L + 31) / 32, (C + 31) / 32, B);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(from_cl_kernel<float>, grid, dim3(256), 0, s, x, y, C, L, maxabs, per_item, eps);
+  else
+    hipLaunchKernelGGL(from_cl_kernel<__bf16>, grid, dim3(256), 0, s, x, y, C, L, maxabs, per_item, eps);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// max |x| per item (or global).  |x| >= 0, so the raw float bits order like unsigned ints.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxabs_kernel(const void* x, int64_t n_per_item, int per_item, float* maxabs) {
+  const int b = blockIdx.y;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(dld<T>(x, (size_t)b * n_per_item + i)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(reinterpret_cast<unsigned*>(maxabs) + (per_item ? b : 0), __float_as_uint(m));
+  }
+}
+
+hipError_t launch_maxabs(int dt, const void* x, int B, int64_t n_per_item, int per_item, float* maxabs, hipStream_t s) {
+  int bx = (int)std::min<int64_t>((n_per_item + 255) / 256, 64);
+  if (bx < 1) bx = 1;
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(maxabs_kernel<float>, dim3(bx, B), dim3(256), 0, s, x, n_per_item, per_item, maxabs);
+  else
+    hipLaunchKernelGGL(maxabs_kernel<__bf16>, dim3(bx, B), dim3(256), 0, s, x, n_per_item, per_item, maxabs);
+  return hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_by_maxabs_kernel(void* x, int64_t n_per_item, const float* maxabs,
+                                                              int per_item, float eps) {
+  const int b = blockIdx.y;
+  const float den = maxabs[per_item ? b : 0] + eps;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256) {
+    const size_t idx = (size_t)b * n_per_item + i;
+    dst<T>(x, idx, dld<T>(x, idx) / den);
+  }
+}
+
+hipError_t launch_scale_by_maxabs(int dt, void* x, int B, int64_t n_per_item, const float* maxabs, int per_item,
+                                  float eps, hipStream_t s) {
+  int bx = (int)std::min<int64_t>((n_per_item + 255) / 256, 256);
+  if (bx < 1) bx = 1;
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(scale_by_maxabs_kernel<float>, dim3(bx, B), dim3(256), 0, s, x, n_per_item, maxabs, per_item, eps);
+  else
+    hipLaunchKernelGGL(scale_by_maxabs_kernel<__bf16>, dim3(bx, B), dim3(256), 0, s, x, n_per_item, maxabs, per_item, eps);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller: one normal per (seed, step, element)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned (&k)[2]) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+  const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+  const unsigned c0 = (unsigned)(p1 >> 32) ^ c[1] ^ k[0];
+  const unsigned c2 = (unsigned)(p0 >> 32) ^ c[3] ^ k[1];
+  c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = c0; c[2] = c2;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__device__ __forceinline__ float philox_normal(uint64_t seed, unsigned step, uint64_t elem) {
+  unsigned c[4] = {(unsigned)elem, (unsigned)(elem >> 32), step, 0x4c444321u};
+  unsigned k[2] = {(unsigned)seed, (unsigned)(seed >> 32)};
+#pragma unroll
+  for (int i = 0; i < 10; ++i) philox_round(c, k);
+  const float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+  const float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);            // [0,1)
+  return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// p_sample update on [B][C][L] fp32 state, eps arriving channels-last; also emits the channels-last
+// copy of the new state for the next UNet call.  Tile: 32 positions x 32 channels.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const void* eps_cl, const float* noise,
+                                                              int64_t noise_step_stride, void* x_cl, int C, int L,
+                                                              StepTables tb, const int* st, uint64_t seed) {
+  __shared__ float tile[32][33];
+  const int t = st[0], j = st[1];
+  const float recip = tb.sqrt_recip_alphas_cumprod[t], recipm1 = tb.sqrt_recipm1_alphas_cumprod[t];
+  const float c1 = tb.posterior_mean_coef1[t], c2 = tb.posterior_mean_coef2[t];
+  const float sigma = expf(0.5f * tb.posterior_log_variance_clipped[t]);
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  // eps tile: read channels-last (coalesced over c), hand over transposed
+  for (int i = ty; i < 32; i += 8) {
+    const int l = l0 + i, c = c0 + tx;
+    tile[i][tx] = (l < L && c < C) ? dld<T>(eps_cl, ((size_t)b * L + l) * C + c) : 0.f;
+  }
+  __syncthreads();
+  float newv[4];
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int i = ty + ii * 8;
+    const int c = c0 + i, l = l0 + tx;
+    newv[ii] = 0.f;
+    if (c < C && l < L) {
+      const size_t idx = ((size_t)b * C + c) * L + l;
+      const float xv = x[idx];
+      const float e = tile[tx][i];
+      float x0 = recip * xv - recipm1 * e;
+      x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      float v = c1 * x0 + c2 * xv;
+      if (t > 0) {
+        const float z = noise ? noise[(size_t)j * noise_step_stride + idx] : philox_normal(seed, (unsigned)j, idx);
+        v += sigma * z;
+      }
+      x[idx] = v;
+      newv[ii] = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) tile[ty + ii * 8][tx] = newv[ii];   // tile[c][l]
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int l = l0 + i, c = c0 + tx;
+    if (l < L && c < C) dst<T>(x_cl, ((size_t)b * L + l) * C + c, tile[tx][i]);
+  }
+}
+
+hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const float* noise, int64_t noise_step_stride,
+                                  void* x_cl, int B, int C, int L, StepTables tb, const int* st, uint64_t seed,
+                                  hipStream_t s) {
+  dim3 grid((L + 31) / 32, (C + 31) / 32, B);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(p_sample_update_kernel<float>, grid, dim3(256), 0, s, x, eps_cl, noise, noise_step_stride, x_cl, C, L,
+                       tb, st, seed);
+  else
+    hipLaunchKernelGGL(p_sample_update_kernel<__bf16>, grid, dim3(256), 0, s, x, eps_cl, noise, noise_step_stride, x_cl, C,
+                       L, tb, st, seed);
+  return hipGetLastError();
+}
+
+__global__ void step_advance_kernel(int* st) {
+  st[0] -= 1;
+  st[1] += 1;
+}
+__global__ void step_set_kernel(int* st, int t, int j) {
+  st[0] = t;
+  st[1] = j;
+}
+hipError_t launch_step_advance(int* st, hipStream_t s) {
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, st);
+  return hipGetLastError();
+}
+hipError_t launch_step_set(int* st, int t, int j, hipStream_t s) {
+  hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(1), 0, s, st, t, j);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// output normalisation: x /= std(x)+1e-8 (unbiased) ; x /= max|x|+1e-8     (sample.py:133-134)
+// ws per slot: double sum, double sumsq, then float maxabs array after the doubles
+// ---------------------------------------------------------------------------------------------
+size_t output_normalise_ws_bytes(int B) { return (size_t)B * (2 * sizeof(double) + sizeof(float)) + 16; }
+
+__global__ __launch_bounds__(256) void outnorm_reduce_kernel(const float* x, int64_t n_per_item, int per_item,
+                                                             double* sums, float* maxabs) {
+  const int b = blockIdx.y;
+  double s = 0.0, ss = 0.0;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256) {
+    const float v = x[(size_t)b * n_per_item + i];
+    s += v; ss += (double)v * v; m = fmaxf(m, fabsf(v));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); m = fmaxf(m, __shfl_xor(m, o));
+  }
+  __shared__ double rs[4], rss[4];
+  __shared__ float rm[4];
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rss[threadIdx.x >> 6] = ss; rm[threadIdx.x >> 6] = m; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int slot = per_item ? b : 0;
+    atomicAdd(&sums[2 * slot], rs[0] + rs[1] + rs[2] + rs[3]);
+    atomicAdd(&sums[2 * slot + 1], rss[0] + rss[1] + rss[2] + rss[3]);
+    atomicMax(reinterpret_cast<unsigned*>(maxabs) + slot, __float_as_uint(fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]))));
+  }
+}
+
+__global__ __launch_bounds__(256) void outnorm_apply_kernel(float* x, int64_t n_per_item, int per_item, int B,
+                                                            const double* sums, const float* maxabs) {
+  const int b = blockIdx.y;
+  const int slot = per_item ? b : 0;
+  const double n = per_item ? (double)n_per_item : (double)n_per_item * B;
+  const double mean = sums[2 * slot] / n;
+  double var = (sums[2 * slot + 1] - n * mean * mean) / (n - 1.0);
+  if (var < 0.0) var = 0.0;
+  const float sd = (float)sqrt(var) + 1e-8f;
+  const float mx = maxabs[slot] / sd + 1e-8f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256) {
+    const size_t idx = (size_t)b * n_per_item + i;
+    x[idx] = (x[idx] / sd) / mx;
+  }
+}
+
+hipError_t launch_output_normalise(float* x, int B, int64_t n_per_item, int per_item, void* ws, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(ws, 0, output_normalise_ws_bytes(B), s);
+  if (e != hipSuccess) return e;
+  double* sums = reinterpret_cast<double*>(ws);
+  float* maxabs = reinterpret_cast<float*>(sums + 2 * B);
+  int bx = (int)std::min<int64_t>((n_per_item + 255) / 256, 64);
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(outnorm_reduce_kernel, dim3(bx, B), dim3(256), 0, s, x, n_per_item, per_item, sums, maxabs);
+  hipLaunchKernelGGL(outnorm_apply_kernel, dim3(bx, B), dim3(256), 0, s, x, n_per_item, per_item, B, sums, maxabs);
+  return hipGetLastError();
+}
+
+}  // namespace ldc

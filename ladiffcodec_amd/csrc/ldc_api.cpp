@@ -1,0 +1,1801 @@
+// ldc_api.cpp -- context, weight folding/packing, execution plans, hipGraph capture and the C ABI
+// declared in include/ladiffcodec.h.  Host-side C++ only; every kernel lives in the .hip files.
+//
+// Mapping to the reference (haiciyang/LaDiffCodec):
+//   Ctx::codec[*]    <- DiffAudioRep.encoder / .decoder / .quantizer      (srcs/model.py:52-66)
+//   Ctx::unet        <- DiffAudioRep.diff_model = Unet1D                  (srcs/model.py:74, modules/unet.py:250-469)
+//   Ctx::sched       <- GaussianDiffusion1D registered buffers            (srcs/losses/ddpm_loss.py:138-168)
+//   ldc_denoise      <- GaussianDiffusion1D.halfway_sampling              (srcs/losses/ddpm_loss.py:370-385)
+#include "../../include/ladiffcodec.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "ldc_kernels.h"
+
+using namespace ldc;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) return fail(LDC_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define LDCCHK(expr)          \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != LDC_OK) return _r; \
+  } while (0)
+
+extern "C" const char* ldc_last_error(void) { return g_err; }
+extern "C" const char* ldc_version(void) { return "ladiffcodec-amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// small utilities
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool used = false;
+  size_t numel() const {
+    size_t n = 1;
+    for (auto s : shape) n *= (size_t)s;
+    return n;
+  }
+};
+
+struct Arena {   // bump allocator over one device buffer; base == nullptr measures only
+  char* base = nullptr;
+  size_t cap = 0, off = 0;
+  void* alloc(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+struct DevMem {
+  std::vector<void*> ptrs;
+  ~DevMem() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  int alloc(void** out, size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(LDC_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    ptrs.push_back(p);
+    *out = p;
+    return LDC_OK;
+  }
+  template <typename T>
+  int upload(T** out, const std::vector<T>& v) {
+    void* p = nullptr;
+    LDCCHK(alloc(&p, v.size() * sizeof(T)));
+    if (!v.empty()) {
+      hipError_t e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return fail(LDC_E_HIP, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
+    }
+    *out = reinterpret_cast<T*>(p);
+    return LDC_OK;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// model descriptions
+// ------------------------------------------------------------------------------------------------
+struct LstmLayer {
+  ConvLayer in_proj;          // k1 GEMM H -> 4H with bias b_ih + b_hh
+  float* w_hh = nullptr;      // layout depends on H (see launch_lstm_layer)
+};
+
+struct SeaOp {
+  enum Kind { CONV_CIN1, CONV, CONVTR, RES, LSTM } kind = CONV;
+  ConvLayer conv;             // CONV / CONVTR / RES first conv (k3, pre-ELU)
+  ConvLayer conv2;            // RES second conv (k1, pre-ELU, + shortcut residual)
+  ConvLayer shortcut;         // RES shortcut (k1)
+  std::vector<LstmLayer> lstm;
+  float* w1 = nullptr;        // CONV_CIN1 [Cout][k]
+  float* b1 = nullptr;
+  int cin = 0, cout = 0, k = 1, stride = 1, hidden = 0;
+};
+
+struct Codec {
+  std::vector<int> ratios;
+  int hop = 1;
+  std::vector<SeaOp> enc, dec;
+  // RVQ
+  int n_q_layers = 0, bins = 1024;
+  float* codebooks = nullptr;   // [n_q][bins][D]
+  float* cb_sqnorm = nullptr;   // [n_q][bins]
+  bool present = false;
+};
+
+struct ResnetW {
+  ConvLayer c1, c2, res;
+  bool has_res = false;
+  float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+  int cin1 = 0, cin2 = 0, cout = 0;
+  int ss_off = 0;               // offset of this block's (scale|shift) in a table row
+};
+struct LinAttnW {
+  float* norm_g = nullptr;
+  ConvLayer qkv, out;
+  float* out_g = nullptr;       // null for the bottleneck Attention
+  int dim = 0;
+};
+struct LevelW {
+  ResnetW b1, b2;
+  LinAttnW attn;
+  ConvLayer resample;
+  int kind = 0;                 // 0 down (k4 s2 p1), 1 up (nearest x2 + k3 p1), 2 same (k3 p1)
+  int cin = 0, cout = 0;
+};
+struct UnetW {
+  int dim = 0, time_dim = 0, groups = 8, heads = 4, dim_head = 32, channels = 128, cond_channels = 128;
+  std::vector<int> dims;
+  ConvLayer init, final_conv;
+  std::vector<LevelW> downs, ups;
+  ResnetW mid1, mid2, fin;
+  LinAttnW mid_attn;
+  std::vector<ConvLayer> upsamplers;
+  std::vector<int> up_ratios;
+  float* ss_table = nullptr;    // [T][ss_stride] fp32
+  int ss_stride = 0;
+  int timesteps = 1000;
+  double weight_elems = 0;
+};
+
+struct Plan {   // one UNet step for fixed (B, L, F)
+  int B = 0, L = 0, F = 0;
+  void* arena_base = nullptr;
+  size_t arena_bytes = 0;
+  void* x_cl = nullptr;         // [B*L][channels]
+  void* cond_in_cl = nullptr;   // [B*F][cond_channels]   (raw cond, channels-last)
+  void* cond_cl = nullptr;      // [B*L][cond_channels]   (processed)
+  void* eps_cl = nullptr;       // [B*L][channels]
+  float* maxabs = nullptr;      // [B]
+  std::vector<std::function<hipError_t(hipStream_t)>> cond_ops;   // process_cond (once per denoise)
+  std::vector<std::function<hipError_t(hipStream_t)>> step_ops;   // Unet1D.forward after process_cond
+  std::vector<int> step_is_conv;                                   // 1 where step_ops[i] is a conv-GEMM launch
+  std::vector<double> step_flops;
+  struct Tap { void* p; int C; int L; };
+  std::map<std::string, Tap> taps;
+  double flops = 0, act_bytes = 0;
+  // hipGraph of {unet step, p_sample_update, step_advance}
+  hipGraphExec_t graph = nullptr;
+  const float* graph_noise = nullptr;
+  float* graph_x = nullptr;
+  hipStream_t graph_stream = nullptr;
+};
+
+struct ldc_ctx {
+  ldc_config cfg;
+  int device = 0;
+  int dt = DT_F32;              // UNet compute dtype; the codec (SEANet/LSTM/RVQ/upsampler) is always fp32
+  bool finalized = false;
+  std::map<std::string, HostTensor> raw[2];
+  DevMem wmem;                  // weights, tables
+  Codec codec[2];
+  UnetW unet;
+  StepTables sched{};
+  int* step_state = nullptr;    // device int[2]: t, j
+  std::vector<std::unique_ptr<Plan>> plans;
+  std::vector<void*> plan_mem;
+  // scratch arena for codec stages and boundary buffers
+  char* scratch = nullptr;
+  size_t scratch_cap = 0;
+  void* outnorm_ws = nullptr;
+  size_t outnorm_ws_bytes = 0;
+  hipStream_t own_stream = nullptr;
+  // profiling
+  bool profile = false;
+  double prof_ms = 0, prof_flops = 0;
+  int64_t prof_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  std::vector<double> prof_event_flops;
+};
+
+static hipStream_t pick_stream(ldc_ctx* c, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : c->own_stream; }
+static int finish_stream(ldc_ctx* c, void* s) {
+  if (!s) HIPCHK(hipStreamSynchronize(c->own_stream));   // NULL stream => synchronous call on the context's stream
+  return LDC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight access + folding
+// ------------------------------------------------------------------------------------------------
+struct WeightReader {
+  ldc_ctx* c;
+  int which;
+  std::string missing;
+  HostTensor* get(const std::string& key, std::initializer_list<int64_t> shape) {
+    auto& m = c->raw[which];
+    auto it = m.find(key);
+    if (it == m.end() && key.rfind("diff_model.", 0) == 0) it = m.find("diffusion.model." + key.substr(11));
+    if (it == m.end()) {
+      if (missing.size() < 600) missing += key + " ";
+      return nullptr;
+    }
+    HostTensor& t = it->second;
+    if (t.shape != std::vector<int64_t>(shape)) {
+      if (missing.size() < 600) missing += key + "(shape) ";
+      return nullptr;
+    }
+    t.used = true;
+    return &t;
+  }
+};
+
+// w = g * v / ||v||  per dim-0 slice  (torch weight_norm, dim=0; reference conv.py:27-30)
+static std::vector<float> fold_weight_norm(const HostTensor& g, const HostTensor& v) {
+  const size_t n0 = (size_t)v.shape[0], inner = v.numel() / n0;
+  std::vector<float> w(v.numel());
+  for (size_t i = 0; i < n0; ++i) {
+    double s = 0;
+    for (size_t j = 0; j < inner; ++j) s += (double)v.data[i * inner + j] * v.data[i * inner + j];
+    const float nrm = (float)sqrt(s);
+    const float sc = g.data[i] / nrm;
+    for (size_t j = 0; j < inner; ++j) w[i * inner + j] = v.data[i * inner + j] * sc;
+  }
+  return w;
+}
+
+// weight standardisation, fp32 branch: (w - mean) * rsqrt(var + 1e-5), biased var per out channel (unet.py:73-78)
+static std::vector<float> fold_weight_std(const HostTensor& wt) {
+  const size_t n0 = (size_t)wt.shape[0], inner = wt.numel() / n0;
+  std::vector<float> w(wt.numel());
+  for (size_t i = 0; i < n0; ++i) {
+    double s = 0;
+    for (size_t j = 0; j < inner; ++j) s += wt.data[i * inner + j];
+    const double mean = s / (double)inner;
+    double v = 0;
+    for (size_t j = 0; j < inner; ++j) {
+      const double d = wt.data[i * inner + j] - mean;
+      v += d * d;
+    }
+    const float fmean = (float)mean;
+    const float rs = 1.0f / sqrtf((float)(v / (double)inner) + 1e-5f);
+    for (size_t j = 0; j < inner; ++j) w[i * inner + j] = (wt.data[i * inner + j] - fmean) * rs;
+  }
+  return w;
+}
+
+struct ConvSpec {
+  int dt = DT_F32;
+  int cin1 = 0, cin2 = 0, cout = 0, k = 1, stride = 1, dil = 1, pad_left = 0, ups = 0, pad_mode = PAD_ZERO;
+  int pre_act = ACT_NONE, post_act = ACT_NONE;
+};
+
+static int make_conv(ldc_ctx* c, const ConvSpec& sp, const float* w_oik, const float* bias, ConvLayer* out) {
+  ConvLayer ly;
+  ly.dt = sp.dt;
+  ly.cin1 = sp.cin1; ly.cin2 = sp.cin2;
+  const int bke = 64 / (int)dt_size(sp.dt);
+  if (sp.cin1 % bke || sp.cin2 % bke)
+    return fail(LDC_E_INVALID, "conv input channels (%d,%d) must be multiples of %d for this dtype", sp.cin1, sp.cin2, bke);
+  ly.n = sp.cout;
+  ly.bn = conv_pick_bn(sp.cout);
+  ly.n_pad = (sp.cout + ly.bn - 1) / ly.bn * ly.bn;
+  ly.taps = sp.k; ly.stride = sp.stride; ly.dil = sp.dil; ly.pad_left = sp.pad_left; ly.ups = sp.ups;
+  ly.pad_mode = sp.pad_mode; ly.pre_act = sp.pre_act; ly.post_act = sp.post_act;
+  ly.flops_per_row = 2.0 * (sp.cin1 + sp.cin2) * sp.k * sp.cout;
+  std::vector<char> packed(conv_packed_weight_bytes(ly));
+  pack_conv_weights(ly, w_oik, packed.data());
+  void* dw = nullptr;
+  LDCCHK(c->wmem.alloc(&dw, packed.size()));
+  HIPCHK(hipMemcpy(dw, packed.data(), packed.size(), hipMemcpyHostToDevice));
+  ly.w = dw;
+  if (bias) {
+    std::vector<float> b(bias, bias + sp.cout);
+    LDCCHK(c->wmem.upload(&ly.bias, b));
+  }
+  *out = ly;
+  return LDC_OK;
+}
+
+// ConvTranspose1d(k = 2*stride) as a 2-tap conv over q with N = stride*Cout (see conv_gemm.hip)
+static int make_convtr(ldc_ctx* c, int dt, int cin, int cout, int stride, int trim_left, int pre_act, const float* w_iok,
+                       const float* bias, ConvLayer* out) {
+  ConvLayer ly;
+  ly.dt = dt;
+  ly.cin1 = cin; ly.cin2 = 0;
+  const int bke = 64 / (int)dt_size(dt);
+  if (cin % bke) return fail(LDC_E_INVALID, "convtr input channels %d must be a multiple of %d", cin, bke);
+  ly.n = stride * cout;
+  ly.bn = conv_pick_bn(ly.n);
+  ly.n_pad = (ly.n + ly.bn - 1) / ly.bn * ly.bn;
+  ly.taps = 2; ly.stride = 1; ly.dil = 1; ly.pad_left = 1; ly.ups = 0; ly.pad_mode = PAD_ZERO;
+  ly.pre_act = pre_act; ly.post_act = ACT_NONE;
+  ly.tr_stride = stride; ly.tr_cout = cout; ly.tr_trim_left = trim_left;
+  ly.flops_per_row = 2.0 * cin * 2 * ly.n;
+  std::vector<char> packed(conv_packed_weight_bytes(ly));
+  pack_convtr_weights(ly, w_iok, cin, cout, stride, packed.data());
+  void* dw = nullptr;
+  LDCCHK(c->wmem.alloc(&dw, packed.size()));
+  HIPCHK(hipMemcpy(dw, packed.data(), packed.size(), hipMemcpyHostToDevice));
+  ly.w = dw;
+  std::vector<float> b((size_t)ly.n, 0.f);
+  if (bias)
+    for (int p = 0; p < stride; ++p)
+      for (int co = 0; co < cout; ++co) b[(size_t)p * cout + co] = bias[co];
+  LDCCHK(c->wmem.upload(&ly.bias, b));
+  *out = ly;
+  return LDC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SEANet construction (reference srcs/modules/seanet.py:108-151, 200-244)
+// ------------------------------------------------------------------------------------------------
+static int build_wn_conv(ldc_ctx* c, WeightReader& wr, const std::string& p, int cin, int cout, int k, int stride, int dil,
+                         int pre_act, ConvLayer* out) {
+  HostTensor* b = wr.get(p + ".bias", {cout});
+  HostTensor* g = wr.get(p + ".weight_g", {cout, 1, 1});
+  HostTensor* v = wr.get(p + ".weight_v", {cout, cin, k});
+  if (!b || !g || !v) return LDC_OK;   // reported later through wr.missing
+  std::vector<float> w = fold_weight_norm(*g, *v);
+  ConvSpec sp;
+  sp.dt = DT_F32; sp.cin1 = cin; sp.cout = cout; sp.k = k; sp.stride = stride; sp.dil = dil;
+  sp.pad_left = (k - 1) * dil - (stride - 1);   // causal: all padding on the left (conv.py:222-226)
+  sp.pad_mode = PAD_REFLECT; sp.pre_act = pre_act;
+  return make_conv(c, sp, w.data(), b->data.data(), out);
+}
+
+static int build_lstm(ldc_ctx* c, WeightReader& wr, const std::string& p, int H, int layers, std::vector<LstmLayer>* out) {
+  for (int n = 0; n < layers; ++n) {
+    const std::string s = std::to_string(n);
+    HostTensor* wih = wr.get(p + ".lstm.weight_ih_l" + s, {4 * H, H});
+    HostTensor* whh = wr.get(p + ".lstm.weight_hh_l" + s, {4 * H, H});
+    HostTensor* bih = wr.get(p + ".lstm.bias_ih_l" + s, {4 * H});
+    HostTensor* bhh = wr.get(p + ".lstm.bias_hh_l" + s, {4 * H});
+    if (!wih || !whh || !bih || !bhh) continue;
+    LstmLayer L;
+    std::vector<float> bias(4 * H);
+    for (int i = 0; i < 4 * H; ++i) bias[i] = bih->data[i] + bhh->data[i];
+    ConvSpec sp;
+    sp.dt = DT_F32; sp.cin1 = H; sp.cout = 4 * H; sp.k = 1;
+    LDCCHK(make_conv(c, sp, wih->data.data(), bias.data(), &L.in_proj));
+    if (H == 64 || H == 128) {
+      LDCCHK(c->wmem.upload(&L.w_hh, whh->data));
+    } else {
+      // k-major [H/4][4H][4] for the streaming kernel
+      std::vector<float> km((size_t)4 * H * H);
+      for (int row = 0; row < 4 * H; ++row)
+        for (int k = 0; k < H; ++k) km[((size_t)(k / 4) * 4 * H + row) * 4 + (k % 4)] = whh->data[(size_t)row * H + k];
+      LDCCHK(c->wmem.upload(&L.w_hh, km));
+    }
+    out->push_back(L);
+  }
+  return LDC_OK;
+}
+
+static int build_res(ldc_ctx* c, WeightReader& wr, const std::string& p, int dim, int dil, SeaOp* op) {
+  op->kind = SeaOp::RES;
+  op->cin = op->cout = dim;
+  op->hidden = dim / 2;
+  LDCCHK(build_wn_conv(c, wr, p + ".block.1.conv.conv", dim, dim / 2, 3, 1, dil, ACT_ELU, &op->conv));
+  LDCCHK(build_wn_conv(c, wr, p + ".block.3.conv.conv", dim / 2, dim, 1, 1, 1, ACT_ELU, &op->conv2));
+  LDCCHK(build_wn_conv(c, wr, p + ".shortcut.conv.conv", dim, dim, 1, 1, 1, ACT_NONE, &op->shortcut));
+  return LDC_OK;
+}
+
+static int build_codec(ldc_ctx* c, int which, const std::vector<int>& ratios, int n_q_layers, std::string* missing) {
+  Codec& cd = c->codec[which];
+  cd = Codec();
+  cd.ratios = ratios;
+  cd.hop = 1;
+  for (int r : ratios) cd.hop *= r;
+  const int nf = c->cfg.n_filters, D = c->cfg.rep_dims, nres = c->cfg.n_residual_layers, nl = c->cfg.lstm;
+  WeightReader wr{c, which, ""};
+  // ---- encoder ----
+  {
+    int idx = 0, mult = 1;
+    SeaOp first;
+    first.kind = SeaOp::CONV_CIN1; first.cin = 1; first.cout = nf; first.k = 7;
+    {
+      const std::string p = "encoder.model.0.conv.conv";
+      HostTensor* b = wr.get(p + ".bias", {nf});
+      HostTensor* g = wr.get(p + ".weight_g", {nf, 1, 1});
+      HostTensor* v = wr.get(p + ".weight_v", {nf, 1, 7});
+      if (b && g && v) {
+        std::vector<float> w = fold_weight_norm(*g, *v);
+        LDCCHK(c->wmem.upload(&first.w1, w));
+        LDCCHK(c->wmem.upload(&first.b1, b->data));
+      }
+    }
+    cd.enc.push_back(first);
+    idx = 1;
+    std::vector<int> rev(ratios.rbegin(), ratios.rend());
+    for (int ratio : rev) {
+      const int ch = mult * nf;
+      for (int j = 0; j < nres; ++j) {
+        SeaOp op;
+        int dil = 1;
+        for (int q = 0; q < j; ++q) dil *= 2;
+        LDCCHK(build_res(c, wr, "encoder.model." + std::to_string(idx), ch, dil, &op));
+        cd.enc.push_back(op);
+        ++idx;
+      }
+      ++idx;   // ELU
+      SeaOp op;
+      op.kind = SeaOp::CONV; op.cin = ch; op.cout = 2 * ch; op.k = 2 * ratio; op.stride = ratio;
+      LDCCHK(build_wn_conv(c, wr, "encoder.model." + std::to_string(idx) + ".conv.conv", ch, 2 * ch, 2 * ratio, ratio, 1,
+                           ACT_ELU, &op.conv));
+      cd.enc.push_back(op);
+      ++idx;
+      mult *= 2;
+    }
+    const int ch = mult * nf;
+    bool pre = false;
+    if (nl) {
+      SeaOp op;
+      op.kind = SeaOp::LSTM; op.cin = op.cout = ch;
+      LDCCHK(build_lstm(c, wr, "encoder.model." + std::to_string(idx), ch, nl, &op.lstm));
+      cd.enc.push_back(op);
+      ++idx;
+    }
+    (void)pre;
+    ++idx;   // ELU
+    SeaOp op;
+    op.kind = SeaOp::CONV; op.cin = ch; op.cout = D; op.k = 7;
+    LDCCHK(build_wn_conv(c, wr, "encoder.model." + std::to_string(idx) + ".conv.conv", ch, D, 7, 1, 1, ACT_ELU, &op.conv));
+    cd.enc.push_back(op);
+  }
+  // ---- decoder ----
+  {
+    int idx = 0;
+    int mult = 1 << ratios.size();
+    SeaOp op0;
+    op0.kind = SeaOp::CONV; op0.cin = D; op0.cout = mult * nf; op0.k = 7;
+    LDCCHK(build_wn_conv(c, wr, "decoder.model.0.conv.conv", D, mult * nf, 7, 1, 1, ACT_NONE, &op0.conv));
+    cd.dec.push_back(op0);
+    idx = 1;
+    if (nl) {
+      SeaOp op;
+      op.kind = SeaOp::LSTM; op.cin = op.cout = mult * nf;
+      LDCCHK(build_lstm(c, wr, "decoder.model.1", mult * nf, nl, &op.lstm));
+      cd.dec.push_back(op);
+      idx = 2;
+    }
+    for (int ratio : ratios) {
+      const int ch = mult * nf;
+      ++idx;   // ELU
+      SeaOp op;
+      op.kind = SeaOp::CONVTR; op.cin = ch; op.cout = ch / 2; op.k = 2 * ratio; op.stride = ratio;
+      {
+        const std::string p = "decoder.model." + std::to_string(idx) + ".convtr.convtr";
+        HostTensor* b = wr.get(p + ".bias", {ch / 2});
+        HostTensor* g = wr.get(p + ".weight_g", {ch, 1, 1});
+        HostTensor* v = wr.get(p + ".weight_v", {ch, ch / 2, 2 * ratio});
+        if (b && g && v) {
+          std::vector<float> w = fold_weight_norm(*g, *v);
+          // causal: trim everything (k - s = s) on the right (conv.py:263-268) -> trim_left = 0
+          LDCCHK(make_convtr(c, DT_F32, ch, ch / 2, ratio, 0, ACT_ELU, w.data(), b->data.data(), &op.conv));
+        }
+      }
+      cd.dec.push_back(op);
+      ++idx;
+      for (int j = 0; j < nres; ++j) {
+        SeaOp r;
+        int dil = 1;
+        for (int q = 0; q < j; ++q) dil *= 2;
+        LDCCHK(build_res(c, wr, "decoder.model." + std::to_string(idx), ch / 2, dil, &r));
+        cd.dec.push_back(r);
+        ++idx;
+      }
+      mult /= 2;
+    }
+    ++idx;   // ELU
+    SeaOp last;
+    last.kind = SeaOp::CONV; last.cin = nf; last.cout = 1; last.k = 7;
+    LDCCHK(build_wn_conv(c, wr, "decoder.model." + std::to_string(idx) + ".conv.conv", nf, 1, 7, 1, 1, ACT_ELU, &last.conv));
+    cd.dec.push_back(last);
+  }
+  // ---- RVQ ----
+  cd.n_q_layers = n_q_layers;
+  if (n_q_layers > 0) {
+    std::vector<float> all((size_t)n_q_layers * cd.bins * D);
+    bool ok = true;
+    for (int q = 0; q < n_q_layers; ++q) {
+      const std::string p = "quantizer.vq.layers." + std::to_string(q) + "._codebook";
+      HostTensor* e = wr.get(p + ".embed", {cd.bins, D});
+      wr.get(p + ".inited", {1});
+      wr.get(p + ".cluster_size", {cd.bins});
+      wr.get(p + ".embed_avg", {cd.bins, D});
+      if (!e) { ok = false; continue; }
+      memcpy(all.data() + (size_t)q * cd.bins * D, e->data.data(), (size_t)cd.bins * D * sizeof(float));
+    }
+    if (ok) {
+      LDCCHK(c->wmem.upload(&cd.codebooks, all));
+      void* p = nullptr;
+      LDCCHK(c->wmem.alloc(&p, (size_t)n_q_layers * cd.bins * sizeof(float)));
+      cd.cb_sqnorm = reinterpret_cast<float*>(p);
+      HIPCHK(launch_sqnorm_rows(cd.codebooks, n_q_layers * cd.bins, D, cd.cb_sqnorm, c->own_stream));
+      HIPCHK(hipStreamSynchronize(c->own_stream));
+    }
+  }
+  cd.present = true;
+  *missing += wr.missing;
+  return LDC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Unet1D construction (reference srcs/modules/unet.py:307-377)
+// ------------------------------------------------------------------------------------------------
+static int build_resnet(ldc_ctx* c, WeightReader& wr, const std::string& p, int cin1, int cin2, int cout, ResnetW* r) {
+  const int cin = cin1 + cin2;
+  r->cin1 = cin1; r->cin2 = cin2; r->cout = cout;
+  HostTensor* w1 = wr.get(p + ".block1.proj.weight", {cout, cin, 3});
+  HostTensor* b1 = wr.get(p + ".block1.proj.bias", {cout});
+  HostTensor* g1 = wr.get(p + ".block1.norm.weight", {cout});
+  HostTensor* be1 = wr.get(p + ".block1.norm.bias", {cout});
+  HostTensor* w2 = wr.get(p + ".block2.proj.weight", {cout, cout, 3});
+  HostTensor* b2 = wr.get(p + ".block2.proj.bias", {cout});
+  HostTensor* g2 = wr.get(p + ".block2.norm.weight", {cout});
+  HostTensor* be2 = wr.get(p + ".block2.norm.bias", {cout});
+  wr.get(p + ".mlp.1.weight", {2 * cout, c->unet.time_dim});
+  wr.get(p + ".mlp.1.bias", {2 * cout});
+  r->has_res = cin != cout;
+  HostTensor *wr_ = nullptr, *br_ = nullptr;
+  if (r->has_res) {
+    wr_ = wr.get(p + ".res_conv.weight", {cout, cin, 1});
+    br_ = wr.get(p + ".res_conv.bias", {cout});
+  }
+  if (!w1 || !b1 || !g1 || !be1 || !w2 || !b2 || !g2 || !be2 || (r->has_res && (!wr_ || !br_))) return LDC_OK;
+  ConvSpec sp;
+  sp.dt = c->dt; sp.cin1 = cin1; sp.cin2 = cin2; sp.cout = cout; sp.k = 3; sp.pad_left = 1;
+  {
+    std::vector<float> w = fold_weight_std(*w1);
+    LDCCHK(make_conv(c, sp, w.data(), b1->data.data(), &r->c1));
+  }
+  {
+    std::vector<float> w = fold_weight_std(*w2);
+    ConvSpec s2 = sp;
+    s2.cin1 = cout; s2.cin2 = 0;
+    LDCCHK(make_conv(c, s2, w.data(), b2->data.data(), &r->c2));
+  }
+  if (r->has_res) {
+    ConvSpec s3 = sp;
+    s3.k = 1; s3.pad_left = 0;
+    LDCCHK(make_conv(c, s3, wr_->data.data(), br_->data.data(), &r->res));
+  }
+  LDCCHK(c->wmem.upload(&r->g1, g1->data));
+  LDCCHK(c->wmem.upload(&r->b1, be1->data));
+  LDCCHK(c->wmem.upload(&r->g2, g2->data));
+  LDCCHK(c->wmem.upload(&r->b2, be2->data));
+  c->unet.weight_elems += (double)w1->numel() + w2->numel() + (wr_ ? wr_->numel() : 0);
+  return LDC_OK;
+}
+
+static int build_attn(ldc_ctx* c, WeightReader& wr, const std::string& p, int dim, bool linear, LinAttnW* a) {
+  const int hidden = c->unet.heads * c->unet.dim_head;
+  a->dim = dim;
+  HostTensor* ng = wr.get(p + ".fn.norm.g", {1, dim, 1});
+  HostTensor* wq = wr.get(p + ".fn.fn.to_qkv.weight", {3 * hidden, dim, 1});
+  HostTensor* wo = wr.get(p + (linear ? ".fn.fn.to_out.0.weight" : ".fn.fn.to_out.weight"), {dim, hidden, 1});
+  HostTensor* bo = wr.get(p + (linear ? ".fn.fn.to_out.0.bias" : ".fn.fn.to_out.bias"), {dim});
+  HostTensor* og = linear ? wr.get(p + ".fn.fn.to_out.1.g", {1, dim, 1}) : nullptr;
+  if (!ng || !wq || !wo || !bo || (linear && !og)) return LDC_OK;
+  ConvSpec sq;
+  sq.dt = c->dt; sq.cin1 = dim; sq.cout = 3 * hidden; sq.k = 1;
+  LDCCHK(make_conv(c, sq, wq->data.data(), nullptr, &a->qkv));
+  ConvSpec so;
+  so.dt = c->dt; so.cin1 = hidden; so.cout = dim; so.k = 1;
+  LDCCHK(make_conv(c, so, wo->data.data(), bo->data.data(), &a->out));
+  LDCCHK(c->wmem.upload(&a->norm_g, ng->data));
+  if (og) LDCCHK(c->wmem.upload(&a->out_g, og->data));
+  c->unet.weight_elems += (double)wq->numel() + wo->numel();
+  return LDC_OK;
+}
+
+static int build_plain_conv(ldc_ctx* c, WeightReader& wr, const std::string& p, int cin1, int cin2, int cout, int k,
+                            int stride, int pad, int ups, ConvLayer* out) {
+  HostTensor* w = wr.get(p + ".weight", {cout, cin1 + cin2, k});
+  HostTensor* b = wr.get(p + ".bias", {cout});
+  if (!w || !b) return LDC_OK;
+  ConvSpec sp;
+  sp.dt = c->dt; sp.cin1 = cin1; sp.cin2 = cin2; sp.cout = cout; sp.k = k; sp.stride = stride; sp.pad_left = pad; sp.ups = ups;
+  c->unet.weight_elems += (double)w->numel();
+  return make_conv(c, sp, w->data.data(), b->data.data(), out);
+}
+
+static int build_time_table(ldc_ctx* c, WeightReader& wr);
+
+static int build_unet(ldc_ctx* c, std::string* missing) {
+  UnetW& u = c->unet;
+  u = UnetW();
+  u.dim = c->cfg.diff_dims;
+  u.time_dim = 4 * u.dim;
+  u.channels = c->cfg.rep_dims;
+  u.cond_channels = 128;
+  static const int mults[5] = {1, 2, 2, 4, 4};   // DiffAudioRep fixes dim_mults=(1,2,2,4,4) (model.py:74)
+  u.dims.push_back(u.dim);
+  for (int m : mults) u.dims.push_back(u.dim * m);
+  WeightReader wr{c, LDC_MODEL_MAIN, ""};
+  const std::string P = "diff_model";
+  LDCCHK(build_plain_conv(c, wr, P + ".init_conv", u.cond_channels, u.channels, u.dim, 7, 1, 3, 0, &u.init));
+  const int nlev = (int)u.dims.size() - 1;
+  int ss_off = 0;
+  auto take_ss = [&](ResnetW& r) { r.ss_off = ss_off; ss_off += 2 * r.cout; };
+  for (int i = 0; i < nlev; ++i) {
+    const int din = u.dims[i], dout = u.dims[i + 1];
+    const bool last = i >= nlev - 1;
+    LevelW lv;
+    const std::string p = P + ".downs." + std::to_string(i);
+    LDCCHK(build_resnet(c, wr, p + ".0", din, 0, din, &lv.b1)); take_ss(lv.b1);
+    LDCCHK(build_resnet(c, wr, p + ".1", din, 0, din, &lv.b2)); take_ss(lv.b2);
+    LDCCHK(build_attn(c, wr, p + ".2", din, true, &lv.attn));
+    lv.kind = last ? 2 : 0; lv.cin = din; lv.cout = dout;
+    if (last) LDCCHK(build_plain_conv(c, wr, p + ".3", din, 0, dout, 3, 1, 1, 0, &lv.resample));
+    else LDCCHK(build_plain_conv(c, wr, p + ".3", din, 0, dout, 4, 2, 1, 0, &lv.resample));
+    u.downs.push_back(lv);
+  }
+  const int mid = u.dims.back();
+  LDCCHK(build_resnet(c, wr, P + ".mid_block1", mid, 0, mid, &u.mid1)); take_ss(u.mid1);
+  LDCCHK(build_attn(c, wr, P + ".mid_attn", mid, false, &u.mid_attn));
+  LDCCHK(build_resnet(c, wr, P + ".mid_block2", mid, 0, mid, &u.mid2)); take_ss(u.mid2);
+  for (int i = 0; i < nlev; ++i) {
+    const int din = u.dims[nlev - 1 - i], dout = u.dims[nlev - i];
+    const bool last = i == nlev - 1;
+    LevelW lv;
+    const std::string p = P + ".ups." + std::to_string(i);
+    LDCCHK(build_resnet(c, wr, p + ".0", dout, din, dout, &lv.b1)); take_ss(lv.b1);
+    LDCCHK(build_resnet(c, wr, p + ".1", dout, din, dout, &lv.b2)); take_ss(lv.b2);
+    LDCCHK(build_attn(c, wr, p + ".2", dout, true, &lv.attn));
+    lv.kind = last ? 2 : 1; lv.cin = dout; lv.cout = din;
+    if (last) LDCCHK(build_plain_conv(c, wr, p + ".3", dout, 0, din, 3, 1, 1, 0, &lv.resample));
+    else LDCCHK(build_plain_conv(c, wr, p + ".3.1", dout, 0, din, 3, 1, 1, 1, &lv.resample));
+    u.ups.push_back(lv);
+  }
+  LDCCHK(build_resnet(c, wr, P + ".final_res_block", u.dim, u.dim, u.dim, &u.fin)); take_ss(u.fin);
+  LDCCHK(build_plain_conv(c, wr, P + ".final_conv", u.dim, 0, u.channels, 1, 1, 0, 0, &u.final_conv));
+  u.ss_stride = ss_off;
+  // cond upsampler: non-causal SConvTranspose1d(k=2r, s=r), no weight-norm (unet.py:372-377, conv.py:270-273)
+  for (int i = 0; i < c->cfg.n_upsampling_ratios; ++i) {
+    const int r = c->cfg.upsampling_ratios[i];
+    const std::string p = P + ".upsampling_layers." + std::to_string(i) + ".convtr.convtr";
+    HostTensor* w = wr.get(p + ".weight", {u.cond_channels, u.cond_channels, 2 * r});
+    HostTensor* b = wr.get(p + ".bias", {u.cond_channels});
+    u.up_ratios.push_back(r);
+    if (!w || !b) continue;
+    ConvLayer ly;
+    const int padding_total = r, right = padding_total / 2, left = padding_total - right;
+    LDCCHK(make_convtr(c, DT_F32, u.cond_channels, u.cond_channels, r, left, ACT_NONE, w->data.data(), b->data.data(), &ly));
+    u.upsamplers.push_back(ly);
+  }
+  // schedule buffers come from the checkpoint (they are registered buffers, ddpm_loss.py:138-168)
+  static const char* names[13] = {"betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                                  "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
+                                  "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                                  "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2",
+                                  "p2_loss_weight"};
+  std::map<std::string, float*> dev;
+  for (const char* n : names) {
+    HostTensor* t = wr.get(std::string("diffusion.") + n, {u.timesteps});
+    if (!t) continue;
+    float* d = nullptr;
+    LDCCHK(c->wmem.upload(&d, t->data));
+    dev[n] = d;
+  }
+  c->sched.sqrt_recip_alphas_cumprod = dev["sqrt_recip_alphas_cumprod"];
+  c->sched.sqrt_recipm1_alphas_cumprod = dev["sqrt_recipm1_alphas_cumprod"];
+  c->sched.posterior_mean_coef1 = dev["posterior_mean_coef1"];
+  c->sched.posterior_mean_coef2 = dev["posterior_mean_coef2"];
+  c->sched.posterior_log_variance_clipped = dev["posterior_log_variance_clipped"];
+  if (wr.missing.empty()) LDCCHK(build_time_table(c, wr));
+  *missing += wr.missing;
+  return LDC_OK;
+}
+
+// SinusoidalPosEmb + time_mlp + every ResnetBlock.mlp evaluated for all t = 0..T-1 at load time
+// (they depend on t only; reference unet.py:109-116, 327-332, 162-165, 183-186).  fp32 on the GPU,
+// through the same conv-GEMM kernel (a Linear is a k=1 conv over T "positions").
+static int build_time_table(ldc_ctx* c, WeightReader& wr) {
+  UnetW& u = c->unet;
+  const int T = u.timesteps, dim = u.dim, td = u.time_dim;
+  const std::string P = "diff_model";
+  HostTensor* w1 = wr.get(P + ".time_mlp.1.weight", {td, dim});
+  HostTensor* b1 = wr.get(P + ".time_mlp.1.bias", {td});
+  HostTensor* w2 = wr.get(P + ".time_mlp.3.weight", {td, td});
+  HostTensor* b2 = wr.get(P + ".time_mlp.3.bias", {td});
+  if (!w1 || !b1 || !w2 || !b2) return LDC_OK;
+  const int half = dim / 2;
+  std::vector<float> emb((size_t)T * dim);
+  const float lg = logf(10000.0f) / (float)(half - 1);
+  for (int t = 0; t < T; ++t)
+    for (int k = 0; k < half; ++k) {
+      const float f = expf((float)k * -lg);
+      const float a = (float)t * f;
+      emb[(size_t)t * dim + k] = sinf(a);
+      emb[(size_t)t * dim + half + k] = cosf(a);
+    }
+  DevMem tmp;
+  float *d_emb = nullptr, *d_h1 = nullptr, *d_h2 = nullptr;
+  LDCCHK(tmp.upload(&d_emb, emb));
+  void* p = nullptr;
+  LDCCHK(tmp.alloc(&p, (size_t)T * td * 4)); d_h1 = (float*)p;
+  LDCCHK(tmp.alloc(&p, (size_t)T * td * 4)); d_h2 = (float*)p;
+  LDCCHK(c->wmem.alloc(&p, (size_t)T * u.ss_stride * 4));
+  u.ss_table = (float*)p;
+  hipStream_t s = c->own_stream;
+  ConvLayer l1, l2;
+  ConvSpec sp;
+  sp.dt = DT_F32; sp.cin1 = dim; sp.cout = td; sp.k = 1; sp.post_act = ACT_GELU;
+  LDCCHK(make_conv(c, sp, w1->data.data(), b1->data.data(), &l1));
+  sp.cin1 = td; sp.post_act = ACT_SILU;   // SiLU of ResnetBlock.mlp[0] folded here: every block consumes SiLU(temb)
+  LDCCHK(make_conv(c, sp, w2->data.data(), b2->data.data(), &l2));
+  ConvCall cc;
+  cc.B = 1; cc.L_in = T; cc.L_rows = T;
+  cc.x1 = d_emb; cc.y = d_h1; cc.y_ld = td;
+  HIPCHK(launch_conv(l1, cc, s));
+  cc.x1 = d_h1; cc.y = d_h2;
+  HIPCHK(launch_conv(l2, cc, s));
+  std::vector<ResnetW*> blocks;
+  for (auto& lv : u.downs) { blocks.push_back(&lv.b1); blocks.push_back(&lv.b2); }
+  blocks.push_back(&u.mid1); blocks.push_back(&u.mid2);
+  for (auto& lv : u.ups) { blocks.push_back(&lv.b1); blocks.push_back(&lv.b2); }
+  blocks.push_back(&u.fin);
+  std::vector<std::string> prefixes;
+  for (size_t i = 0; i < u.downs.size(); ++i) { prefixes.push_back(P + ".downs." + std::to_string(i) + ".0"); prefixes.push_back(P + ".downs." + std::to_string(i) + ".1"); }
+  prefixes.push_back(P + ".mid_block1"); prefixes.push_back(P + ".mid_block2");
+  for (size_t i = 0; i < u.ups.size(); ++i) { prefixes.push_back(P + ".ups." + std::to_string(i) + ".0"); prefixes.push_back(P + ".ups." + std::to_string(i) + ".1"); }
+  prefixes.push_back(P + ".final_res_block");
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    ResnetW* r = blocks[i];
+    HostTensor* wm = wr.get(prefixes[i] + ".mlp.1.weight", {2 * r->cout, td});
+    HostTensor* bm = wr.get(prefixes[i] + ".mlp.1.bias", {2 * r->cout});
+    if (!wm || !bm) continue;
+    ConvLayer lm;
+    ConvSpec sm;
+    sm.dt = DT_F32; sm.cin1 = td; sm.cout = 2 * r->cout; sm.k = 1;
+    LDCCHK(make_conv(c, sm, wm->data.data(), bm->data.data(), &lm));
+    ConvCall cm;
+    cm.B = 1; cm.L_in = T; cm.L_rows = T; cm.x1 = d_h2; cm.y = u.ss_table + r->ss_off; cm.y_ld = u.ss_stride;
+    HIPCHK(launch_conv(lm, cm, s));
+    u.weight_elems += (double)wm->numel();
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return LDC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
+  if (!cfg || !out) return fail(LDC_E_INVALID, "null argument");
+  if (cfg->compute_dtype != LDC_F32 && cfg->compute_dtype != LDC_BF16) return fail(LDC_E_INVALID, "compute_dtype must be LDC_F32 or LDC_BF16");
+  if (cfg->n_enc_ratios < 1 || cfg->n_enc_ratios > LDC_MAX_RATIOS || cfg->n_upsampling_ratios < 0 ||
+      cfg->n_upsampling_ratios > LDC_MAX_RATIOS)
+    return fail(LDC_E_INVALID, "bad ratio counts");
+  if (cfg->rep_dims != 128) return fail(LDC_E_INVALID, "rep_dims must be 128 (RVQ / UNet channel width of the reference checkpoints)");
+  if (cfg->diff_dims % 32 || cfg->diff_dims <= 0) return fail(LDC_E_INVALID, "diff_dims must be a positive multiple of 32");
+  if (cfg->n_filters % 32) return fail(LDC_E_INVALID, "n_filters must be a multiple of 32");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(LDC_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(LDC_E_INVALID, "this library is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+  std::unique_ptr<ldc_ctx> c(new ldc_ctx());
+  c->cfg = *cfg;
+  c->device = device;
+  c->dt = cfg->compute_dtype == LDC_BF16 ? DT_BF16 : DT_F32;
+  HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, 2 * sizeof(int)));
+  c->step_state = (int*)p;
+  *out = c.release();
+  return LDC_OK;
+}
+
+static void drop_plans(ldc_ctx* c) {
+  for (auto& pl : c->plans)
+    if (pl->graph) (void)hipGraphExecDestroy(pl->graph);
+  c->plans.clear();
+  for (void* p : c->plan_mem) (void)hipFree(p);
+  c->plan_mem.clear();
+}
+
+extern "C" int ldc_destroy(ldc_ctx* c) {
+  if (!c) return LDC_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  drop_plans(c);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->outnorm_ws) (void)hipFree(c->outnorm_ws);
+  if (c->step_state) (void)hipFree(c->step_state);
+  for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return LDC_OK;
+}
+
+extern "C" int ldc_set_weight(ldc_ctx* c, int which, const char* key, const float* data, const int64_t* shape, int ndim) {
+  if (!c || !key || !data || (ndim > 0 && !shape)) return fail(LDC_E_INVALID, "null argument");
+  if (which != LDC_MODEL_MAIN && which != LDC_MODEL_COND) return fail(LDC_E_INVALID, "which must be LDC_MODEL_MAIN or LDC_MODEL_COND");
+  if (c->finalized) return fail(LDC_E_STATE, "weights already finalized");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(data, data + t.numel());
+  c->raw[which][key] = std::move(t);
+  return LDC_OK;
+}
+
+extern "C" int ldc_finalize_weights(ldc_ctx* c, int strict) {
+  if (!c) return fail(LDC_E_INVALID, "null ctx");
+  if (c->finalized) return fail(LDC_E_STATE, "already finalized");
+  HIPCHK(hipSetDevice(c->device));
+  std::string missing;
+  std::vector<int> main_ratios(c->cfg.enc_ratios, c->cfg.enc_ratios + c->cfg.n_enc_ratios);
+  LDCCHK(build_codec(c, LDC_MODEL_MAIN, main_ratios, 0, &missing));
+  LDCCHK(build_unet(c, &missing));
+  if (c->cfg.has_cond_model) {
+    // quirk Q1: the cond codec is always built with the default ratios [8,5,4,2] (sample.py:63, model.py:34)
+    const int frame_rate_ceil = 50;
+    const int n_q = (int)floor(1000.0 * c->cfg.cond_bandwidth / (frame_rate_ceil * 10));   // model.py:65
+    LDCCHK(build_codec(c, LDC_MODEL_COND, {8, 5, 4, 2}, n_q, &missing));
+  }
+  if (!missing.empty()) return fail(LDC_E_MISSING, "missing or mis-shaped keys in state_dict: %s", missing.c_str());
+  if (strict) {
+    std::string unexpected;
+    for (int w = 0; w < 2; ++w)
+      for (auto& kv : c->raw[w])
+        if (!kv.second.used) {
+          // the UNet is registered twice (diff_model.* and diffusion.model.*): either alias satisfies the other
+          const std::string& k = kv.first;
+          std::string alias;
+          if (k.rfind("diffusion.model.", 0) == 0) alias = "diff_model." + k.substr(16);
+          else if (k.rfind("diff_model.", 0) == 0) alias = "diffusion.model." + k.substr(11);
+          auto it = alias.empty() ? c->raw[w].end() : c->raw[w].find(alias);
+          if (it != c->raw[w].end() && it->second.used && it->second.shape == kv.second.shape) continue;
+          if (unexpected.size() < 600) unexpected += k + " ";
+        }
+    if (!unexpected.empty()) return fail(LDC_E_MISSING, "unexpected keys in state_dict: %s", unexpected.c_str());
+  }
+  c->raw[0].clear();
+  c->raw[1].clear();
+  c->finalized = true;
+  return LDC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scratch
+// ------------------------------------------------------------------------------------------------
+static int ensure_scratch(ldc_ctx* c, size_t bytes, hipStream_t s) {
+  if (bytes <= c->scratch_cap) return LDC_OK;
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipDeviceSynchronize());
+  if (c->scratch) HIPCHK(hipFree(c->scratch));
+  c->scratch = nullptr;
+  c->scratch_cap = 0;
+  void* p = nullptr;
+  const size_t want = bytes + bytes / 4;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) return fail(LDC_E_NOMEM, "hipMalloc(%zu) for scratch failed: %s", want, hipGetErrorString(e));
+  c->scratch = (char*)p;
+  c->scratch_cap = want;
+  return LDC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SEANet execution (codec dtype = fp32, channels-last)
+// ------------------------------------------------------------------------------------------------
+static int conv_out_len(const ConvLayer& ly, int L) {
+  // SConv1d output length with the reference's extra right padding (conv.py:56-63): ceil(L / stride)
+  const int eff_k = (ly.taps - 1) * ly.dil + 1;
+  const int padding_total = eff_k - ly.stride;
+  const double n_frames = (double)(L - eff_k + padding_total) / ly.stride + 1.0;
+  return (int)ceil(n_frames);
+}
+
+struct SeaRun {   // measures or runs a SEANet stack
+  ldc_ctx* c;
+  Arena* ar;
+  hipStream_t s;
+  bool dry;
+  int B;
+};
+
+static int sea_conv(SeaRun& R, const ConvLayer& ly, const void* x, const void* residual, int L_in, void** y, int* L_out,
+                    int cout) {
+  ConvCall cc;
+  cc.B = R.B; cc.L_in = L_in; cc.x1 = x; cc.residual = residual;
+  if (ly.tr_stride) {
+    cc.L_rows = L_in + 1;
+    cc.L_final = L_in * ly.tr_stride;
+    *L_out = cc.L_final;
+    cc.y_ld = ly.tr_cout;
+  } else {
+    cc.L_rows = conv_out_len(ly, L_in);
+    *L_out = cc.L_rows;
+    cc.y_ld = cout;
+  }
+  *y = R.ar->alloc((size_t)R.B * (*L_out) * cc.y_ld * 4);
+  cc.y = *y;
+  if (!R.dry) HIPCHK(launch_conv(ly, cc, R.s));
+  return LDC_OK;
+}
+
+static int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in, int L, void** out, int* L_out, int* C_out) {
+  const void* x = x_in;
+  int C = 0;
+  for (const SeaOp& op : ops) {
+    void* y = nullptr;
+    int Ln = L;
+    switch (op.kind) {
+      case SeaOp::CONV_CIN1: {
+        if (L <= op.k - 1) return fail(LDC_E_INVALID, "input shorter than the first conv's receptive field");
+        y = R.ar->alloc((size_t)R.B * L * op.cout * 4);
+        if (!R.dry) HIPCHK(launch_conv_cin1(DT_F32, (const float*)x, y, op.w1, op.b1, R.B, L, op.cout, op.k, R.s));
+        C = op.cout;
+        break;
+      }
+      case SeaOp::CONV:
+      case SeaOp::CONVTR:
+        LDCCHK(sea_conv(R, op.conv, x, nullptr, L, &y, &Ln, op.cout));
+        C = op.cout;
+        break;
+      case SeaOp::RES: {
+        void *sc = nullptr, *h = nullptr;
+        int l1 = L, l2 = L, l3 = L;
+        LDCCHK(sea_conv(R, op.shortcut, x, nullptr, L, &sc, &l1, op.cout));
+        LDCCHK(sea_conv(R, op.conv, x, nullptr, L, &h, &l2, op.hidden));
+        LDCCHK(sea_conv(R, op.conv2, h, sc, l2, &y, &l3, op.cout));
+        Ln = l3;
+        C = op.cout;
+        break;
+      }
+      case SeaOp::LSTM: {
+        const int H = op.cout;
+        const void* in = x;
+        for (size_t n = 0; n < op.lstm.size(); ++n) {
+          void* pre = R.ar->alloc((size_t)R.B * L * 4 * H * 4);
+          void* o = R.ar->alloc((size_t)R.B * L * H * 4);
+          if (!R.dry) {
+            ConvCall cc;
+            cc.B = R.B; cc.L_in = L; cc.L_rows = L; cc.x1 = in; cc.y = pre; cc.y_ld = 4 * H;
+            HIPCHK(launch_conv(op.lstm[n].in_proj, cc, R.s));
+            const bool lastl = n + 1 == op.lstm.size();
+            HIPCHK(launch_lstm_layer(DT_F32, pre, op.lstm[n].w_hh, o, lastl ? x : nullptr, R.B, L, H, R.s));
+          }
+          in = o;
+          y = o;
+        }
+        C = H;
+        break;
+      }
+    }
+    x = y;
+    L = Ln;
+  }
+  *out = const_cast<void*>(x);
+  *L_out = L;
+  *C_out = C;
+  return LDC_OK;
+}
+
+// runs `body` twice: once against a measuring arena, then (after sizing the scratch) for real
+template <typename F>
+static int with_scratch(ldc_ctx* c, hipStream_t s, F body) {
+  Arena measure;
+  LDCCHK(body(measure, true));
+  LDCCHK(ensure_scratch(c, measure.off + 4096, s));
+  Arena real;
+  real.base = c->scratch;
+  real.cap = c->scratch_cap;
+  return body(real, false);
+}
+
+static int check_ready(ldc_ctx* c, int which, bool need_cond_codec = false) {
+  if (!c) return fail(LDC_E_INVALID, "null ctx");
+  if (!c->finalized) return fail(LDC_E_STATE, "ldc_finalize_weights has not been called");
+  if (which != LDC_MODEL_MAIN && which != LDC_MODEL_COND) return fail(LDC_E_INVALID, "bad model selector");
+  if ((which == LDC_MODEL_COND || need_cond_codec) && !c->codec[LDC_MODEL_COND].present)
+    return fail(LDC_E_STATE, "no cond model configured (has_cond_model = 0)");
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(LDC_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
+  return LDC_OK;
+}
+
+extern "C" int ldc_seanet_encode(ldc_ctx* c, int which, const float* wav, int B, int T, float* z_out, void* stream) {
+  LDCCHK(check_ready(c, which));
+  if (!wav || !z_out || B <= 0 || T <= 0) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  const Codec& cd = c->codec[which];
+  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    SeaRun R{c, &ar, s, dry, B};
+    void* z = nullptr;
+    int L = 0, C = 0;
+    LDCCHK(run_seanet(R, cd.enc, wav, T, &z, &L, &C));
+    if (!dry) HIPCHK(launch_from_cl(DT_F32, z, z_out, B, C, L, nullptr, 0, 0.f, s));
+    return LDC_OK;
+  }));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_seanet_decode(ldc_ctx* c, int which, const float* z, int B, int L, float* wav_out, void* stream) {
+  LDCCHK(check_ready(c, which));
+  if (!z || !wav_out || B <= 0 || L <= 0) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  const Codec& cd = c->codec[which];
+  const int D = c->cfg.rep_dims;
+  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    SeaRun R{c, &ar, s, dry, B};
+    void* zc = ar.alloc((size_t)B * L * D * 4);
+    if (!dry) HIPCHK(launch_to_cl(DT_F32, z, zc, B, D, L, nullptr, 0, 0.f, s));
+    void* y = nullptr;
+    int Lo = 0, C = 0;
+    LDCCHK(run_seanet(R, cd.dec, zc, L, &y, &Lo, &C));
+    // last conv has Cout = 1: channels-last [B*T][1] is already [B,1,T]
+    if (!dry) HIPCHK(hipMemcpyAsync(wav_out, y, (size_t)B * Lo * 4, hipMemcpyDeviceToDevice, s));
+    return LDC_OK;
+  }));
+  return finish_stream(c, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RVQ
+// ------------------------------------------------------------------------------------------------
+static int rvq_rows(ldc_ctx* c, const float* z_rows, int rows, int n_q, int64_t* codes, float* q_rows, Arena& ar, bool dry,
+                    hipStream_t s) {
+  const Codec& cd = c->codec[LDC_MODEL_COND];
+  int64_t* cw = codes;
+  if (!cw) cw = (int64_t*)ar.alloc((size_t)n_q * rows * sizeof(int64_t));
+  if (!dry) HIPCHK(launch_rvq(z_rows, rows, c->cfg.rep_dims, cd.codebooks, cd.cb_sqnorm, cd.bins, n_q, cw, q_rows, s));
+  return LDC_OK;
+}
+
+static int n_q_for_bandwidth(ldc_ctx* c, float bandwidth) {
+  // vq.py:86-98 with frame_rate = 16000/320 = 50: bw_per_q = log2(1024)*50/1000 = 0.5
+  const Codec& cd = c->codec[LDC_MODEL_COND];
+  const double bw = bandwidth > 0 ? bandwidth : c->cfg.cond_bandwidth;
+  const double bw_per_q = log2((double)cd.bins) * (16000.0 / cd.hop) / 1000.0;
+  int n_q = cd.n_q_layers;
+  if (bw > 0) n_q = (int)std::max(1.0, floor(bw / bw_per_q));
+  return std::min(n_q, cd.n_q_layers);
+}
+
+extern "C" int ldc_rvq_encode(ldc_ctx* c, const float* z, int B, int F, int n_q, int64_t* codes_out, float* quantized_out,
+                              void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_COND));
+  const Codec& cd = c->codec[LDC_MODEL_COND];
+  if (!z || !quantized_out || B <= 0 || F <= 0 || n_q < 1 || n_q > cd.n_q_layers)
+    return fail(LDC_E_INVALID, "bad arguments (n_q must be in [1,%d])", cd.n_q_layers);
+  hipStream_t s = pick_stream(c, stream);
+  const int D = c->cfg.rep_dims;
+  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    float* zr = (float*)ar.alloc((size_t)B * F * D * 4);
+    float* qr = (float*)ar.alloc((size_t)B * F * D * 4);
+    if (!dry) HIPCHK(launch_to_cl(DT_F32, z, zr, B, D, F, nullptr, 0, 0.f, s));
+    LDCCHK(rvq_rows(c, zr, B * F, n_q, codes_out, qr, ar, dry, s));
+    if (!dry) HIPCHK(launch_from_cl(DT_F32, qr, quantized_out, B, D, F, nullptr, 0, 0.f, s));
+    return LDC_OK;
+  }));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_rvq_decode(ldc_ctx* c, const int64_t* codes, int B, int F, int n_q, float* quantized_out, void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_COND));
+  const Codec& cd = c->codec[LDC_MODEL_COND];
+  if (!codes || !quantized_out || B <= 0 || F <= 0 || n_q < 1 || n_q > cd.n_q_layers) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  const int D = c->cfg.rep_dims;
+  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    float* qr = (float*)ar.alloc((size_t)B * F * D * 4);
+    if (!dry) {
+      HIPCHK(launch_rvq_decode(codes, B * F, D, cd.codebooks, cd.bins, n_q, qr, s));
+      HIPCHK(launch_from_cl(DT_F32, qr, quantized_out, B, D, F, nullptr, 0, 0.f, s));
+    }
+    return LDC_OK;
+  }));
+  return finish_stream(c, stream);
+}
+
+// encoder -> RVQ, rows stay channels-last in between; returns the quantized rows pointer (scratch)
+static int get_cond_rows(ldc_ctx* c, const float* wav, int B, int T, float bandwidth, Arena& ar, bool dry, hipStream_t s,
+                         float** q_rows, int* F_out, int64_t* codes_out) {
+  const Codec& cd = c->codec[LDC_MODEL_COND];
+  SeaRun R{c, &ar, s, dry, B};
+  void* z = nullptr;
+  int F = 0, C = 0;
+  LDCCHK(run_seanet(R, cd.enc, wav, T, &z, &F, &C));
+  float* qr = (float*)ar.alloc((size_t)B * F * C * 4);
+  LDCCHK(rvq_rows(c, (const float*)z, B * F, n_q_for_bandwidth(c, bandwidth), codes_out, qr, ar, dry, s));
+  *q_rows = qr;
+  *F_out = F;
+  return LDC_OK;
+}
+
+extern "C" int ldc_get_cond(ldc_ctx* c, const float* wav, int B, int T, float bandwidth, float* cond_out, int64_t* codes_out,
+                            void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_COND));
+  if (!wav || !cond_out || B <= 0 || T <= 0) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    float* qr = nullptr;
+    int F = 0;
+    LDCCHK(get_cond_rows(c, wav, B, T, bandwidth, ar, dry, s, &qr, &F, codes_out));
+    if (!dry) HIPCHK(launch_from_cl(DT_F32, qr, cond_out, B, c->cfg.rep_dims, F, nullptr, 0, 0.f, s));
+    return LDC_OK;
+  }));
+  return finish_stream(c, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cond upsampler (fp32): rows [B*F][C] -> rows [B*L][C]
+// ------------------------------------------------------------------------------------------------
+static int upsample_rows(ldc_ctx* c, const void* rows_in, int B, int F, Arena& ar, bool dry, hipStream_t s, void** out,
+                         int* L_out) {
+  const UnetW& u = c->unet;
+  const void* x = rows_in;
+  int L = F;
+  for (const ConvLayer& ly : u.upsamplers) {
+    ConvCall cc;
+    cc.B = B; cc.L_in = L; cc.L_rows = L + 1; cc.L_final = L * ly.tr_stride; cc.y_ld = ly.tr_cout; cc.x1 = x;
+    void* y = ar.alloc((size_t)B * cc.L_final * ly.tr_cout * 4);
+    cc.y = y;
+    if (!dry) HIPCHK(launch_conv(ly, cc, s));
+    x = y;
+    L = cc.L_final;
+  }
+  *out = const_cast<void*>(x);
+  *L_out = L;
+  return LDC_OK;
+}
+
+static int upsample_factor(const ldc_ctx* c) {
+  int f = 1;
+  for (int r : c->unet.up_ratios) f *= r;
+  return f;
+}
+
+extern "C" int ldc_cond_upsample(ldc_ctx* c, const float* cond, int B, int F, int normalise, float* img_out, void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!cond || !img_out || B <= 0 || F <= 0 || normalise < 0 || normalise > 2) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  const int C = c->unet.cond_channels;
+  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    void* rows = ar.alloc((size_t)B * F * C * 4);
+    float* mx = (float*)ar.alloc((size_t)B * 4);
+    if (!dry) HIPCHK(launch_to_cl(DT_F32, cond, rows, B, C, F, nullptr, 0, 0.f, s));
+    void* up = nullptr;
+    int L = 0;
+    LDCCHK(upsample_rows(c, rows, B, F, ar, dry, s, &up, &L));
+    if (!dry) {
+      if (normalise) {
+        HIPCHK(hipMemsetAsync(mx, 0, (size_t)B * 4, s));
+        HIPCHK(launch_maxabs(DT_F32, up, B, (int64_t)L * C, normalise == 2, mx, s));
+        HIPCHK(launch_from_cl(DT_F32, up, img_out, B, C, L, mx, normalise == 2, 1e-8f, s));
+      } else {
+        HIPCHK(launch_from_cl(DT_F32, up, img_out, B, C, L, nullptr, 0, 0.f, s));
+      }
+    }
+    return LDC_OK;
+  }));
+  return finish_stream(c, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// UNet plan
+// ------------------------------------------------------------------------------------------------
+struct PlanBuilder {
+  ldc_ctx* c;
+  Plan* pl;
+  Arena* ar;
+  int B;
+  size_t es;   // element size of the UNet dtype
+  float* stats_pool = nullptr;   // [n_gn][B][groups][2]
+  int stats_used = 0;
+  float* linattn_ws = nullptr;
+
+  void* act(int rows, int C) {
+    pl->act_bytes += (double)rows * C * es;
+    return ar->alloc((size_t)rows * C * es);
+  }
+  void add(std::function<hipError_t(hipStream_t)> f, bool is_conv = false, double flops = 0) {
+    pl->step_ops.push_back(std::move(f));
+    pl->step_is_conv.push_back(is_conv ? 1 : 0);
+    pl->step_flops.push_back(flops);
+    pl->flops += flops;
+  }
+  void conv(const ConvLayer& ly, const void* x1, const void* x2, void* y, const void* residual, int L_in, int L_out) {
+    ConvCall cc;
+    cc.B = B; cc.L_in = L_in; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.residual = residual; cc.y_ld = ly.n;
+    const ConvLayer* lp = &ly;
+    add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out);
+  }
+  float* next_stats() {
+    const int g = c->unet.groups;
+    return stats_pool + (size_t)(stats_used++) * B * g * 2;
+  }
+  // ResnetBlock.forward (unet.py:176-192)
+  void* resnet(const ResnetW& r, const void* x1, const void* x2, int L) {
+    const int rows = B * L, dt = c->dt, g = c->unet.groups, Bn = B;
+    const UnetW* u = &c->unet;
+    void* a = act(rows, r.cout);
+    void* b = act(rows, r.cout);
+    void* d = act(rows, r.cout);
+    void* out = act(rows, r.cout);
+    float* st1 = next_stats();
+    float* st2 = next_stats();
+    const int* tptr = c->step_state;
+    conv(r.c1, x1, x2, a, nullptr, L, L);
+    const ResnetW* rp = &r;
+    add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
+    add([=](hipStream_t s) {
+      return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, u->ss_table + rp->ss_off,
+                             u->ss_stride, tptr, ACT_SILU, s);
+    });
+    conv(r.c2, b, nullptr, d, nullptr, L, L);
+    add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
+    const void* res = x1;
+    if (r.has_res) {
+      void* rr = act(rows, r.cout);
+      conv(r.res, x1, x2, rr, nullptr, L, L);
+      res = rr;
+    }
+    add([=](hipStream_t s) {
+      return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s);
+    });
+    return out;
+  }
+  // Residual(PreNorm(LinearAttention)) (unet.py:208-222) / Residual(PreNorm(Attention)) (:234-246)
+  void* attention(const LinAttnW& a, const void* x, int L, bool linear) {
+    const int rows = B * L, dt = c->dt, Bn = B;
+    const int H = c->unet.heads, Dh = c->unet.dim_head, hid = H * Dh;
+    void* xn = act(rows, a.dim);
+    void* qkv = act(rows, 3 * hid);
+    void* o = act(rows, hid);
+    void* out = act(rows, a.dim);
+    const LinAttnW* ap = &a;
+    float* ws = linattn_ws;
+    add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s); });
+    conv(a.qkv, xn, nullptr, qkv, nullptr, L, L);
+    if (linear) {
+      add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, s); });
+      void* t = act(rows, a.dim);
+      conv(a.out, o, nullptr, t, nullptr, L, L);
+      add([=](hipStream_t s) { return launch_ln_rows(dt, t, out, x, ap->out_g, rows, ap->dim, s); });
+    } else {
+      add([=](hipStream_t s) { return launch_attn_full(dt, qkv, o, Bn, L, H, Dh, s); });
+      conv(a.out, o, nullptr, out, x, L, L);   // + x in the epilogue
+    }
+    return out;
+  }
+};
+
+static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
+  const UnetW& u = c->unet;
+  pl->B = B; pl->L = L; pl->F = F;
+  pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_flops.clear(); pl->taps.clear();
+  pl->flops = 0; pl->act_bytes = 0;
+  const int dt = c->dt;
+  const size_t es = dt_size(dt);
+  const int Cc = u.cond_channels, Cx = u.channels;
+  PlanBuilder pb{c, pl, &ar, B, es};
+  const int n_gn = 2 * (int)(2 * u.downs.size() + 2 + 2 * u.ups.size() + 1);
+  pb.stats_pool = (float*)ar.alloc((size_t)n_gn * B * u.groups * 2 * 4);
+  const size_t stats_bytes = (size_t)n_gn * B * u.groups * 2 * 4;
+  pb.linattn_ws = (float*)ar.alloc((size_t)B * (2 * u.heads * u.dim_head + u.heads * u.dim_head * u.dim_head) * 4);
+  pl->maxabs = (float*)ar.alloc((size_t)B * 4);
+  pl->x_cl = ar.alloc((size_t)B * L * Cx * es);
+  pl->eps_cl = ar.alloc((size_t)B * L * Cx * es);
+  pl->cond_cl = ar.alloc((size_t)B * L * Cc * es);
+  // ---- process_cond (unet.py:407-420): fp32 upsampler, per-item max-abs, cast to the UNet dtype ----
+  void* cond_in = ar.alloc((size_t)B * F * Cc * 4);
+  pl->cond_in_cl = cond_in;
+  {
+    const void* x = cond_in;
+    int Lc = F;
+    for (const ConvLayer& ly : u.upsamplers) {
+      ConvCall cc;
+      cc.B = B; cc.L_in = Lc; cc.L_rows = Lc + 1; cc.L_final = Lc * ly.tr_stride; cc.y_ld = ly.tr_cout; cc.x1 = x;
+      void* y = ar.alloc((size_t)B * cc.L_final * ly.tr_cout * 4);
+      cc.y = y;
+      const ConvLayer* lp = &ly;
+      pl->cond_ops.push_back([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); });
+      x = y;
+      Lc = cc.L_final;
+    }
+    if (Lc != L) return fail(LDC_E_INVALID, "upsampled condition length %d != latent length %d (F=%d, upsampling product %d)", Lc, L, F, upsample_factor(c));
+    float* mx = pl->maxabs;
+    void* cond_cl = pl->cond_cl;
+    const bool scale = c->cfg.unet_scale_cond != 0;
+    const int Bn = B;
+    const int64_t npi = (int64_t)L * Cc;
+    // fp32 rows -> (scaled) rows in the UNet dtype.  A [rows][C] fp32 -> dt copy is a "transpose" of a
+    // [B][C=1][L*C] tensor: reuse to_cl with C=1 (pure cast + scale).
+    if (scale) {
+      pl->cond_ops.push_back([=](hipStream_t s) { return hipMemsetAsync(mx, 0, (size_t)Bn * 4, s); });
+      pl->cond_ops.push_back([=](hipStream_t s) { return launch_maxabs(DT_F32, x, Bn, npi, 1, mx, s); });
+      pl->cond_ops.push_back([=](hipStream_t s) { return launch_to_cl(dt, (const float*)x, cond_cl, Bn, 1, (int)npi, mx, 1, 1e-20f, s); });
+    } else {
+      pl->cond_ops.push_back([=](hipStream_t s) { return launch_to_cl(dt, (const float*)x, cond_cl, Bn, 1, (int)npi, nullptr, 0, 0.f, s); });
+    }
+  }
+  pl->taps["cond_proc"] = {pl->cond_cl, Cc, L};
+  if (c->cfg.unet_scale_x) return fail(LDC_E_INVALID, "--unet_scale_x is not supported");
+  // ---- Unet1D.forward (unet.py:430-469) ----
+  {
+    float* sp = pb.stats_pool;
+    pb.add([=](hipStream_t s) { return hipMemsetAsync(sp, 0, stats_bytes, s); });
+  }
+  void* x0 = pb.act(B * L, u.dim);
+  pb.conv(u.init, pl->cond_cl, pl->x_cl, x0, nullptr, L, L);
+  pl->taps["init"] = {x0, u.dim, L};
+  const void* x = x0;
+  int Lc = L;
+  std::vector<std::pair<const void*, int>> hs;
+  for (size_t i = 0; i < u.downs.size(); ++i) {
+    const LevelW& lv = u.downs[i];
+    x = pb.resnet(lv.b1, x, nullptr, Lc); hs.push_back({x, Lc});
+    x = pb.resnet(lv.b2, x, nullptr, Lc);
+    x = pb.attention(lv.attn, x, Lc, true); hs.push_back({x, Lc});
+    int Ln = Lc;
+    if (lv.kind == 0) Ln = (Lc + 2 - 4) / 2 + 1;
+    void* y = pb.act(B * Ln, lv.cout);
+    pb.conv(lv.resample, x, nullptr, y, nullptr, Lc, Ln);
+    x = y; Lc = Ln;
+    pl->taps["down" + std::to_string(i)] = {y, lv.cout, Lc};
+  }
+  x = pb.resnet(u.mid1, x, nullptr, Lc);
+  x = pb.attention(u.mid_attn, x, Lc, false);
+  x = pb.resnet(u.mid2, x, nullptr, Lc);
+  pl->taps["mid"] = {const_cast<void*>(x), u.dims.back(), Lc};
+  for (size_t i = 0; i < u.ups.size(); ++i) {
+    const LevelW& lv = u.ups[i];
+    if (hs.back().second != Lc) return fail(LDC_E_INVALID, "latent length %d is not divisible by 2^%zu", L, u.downs.size() - 1);
+    x = pb.resnet(lv.b1, x, hs.back().first, Lc); hs.pop_back();
+    x = pb.resnet(lv.b2, x, hs.back().first, Lc); hs.pop_back();
+    x = pb.attention(lv.attn, x, Lc, true);
+    const int Ln = lv.kind == 1 ? 2 * Lc : Lc;
+    void* y = pb.act(B * Ln, lv.cout);
+    pb.conv(lv.resample, x, nullptr, y, nullptr, Lc, Ln);
+    x = y; Lc = Ln;
+    pl->taps["up" + std::to_string(i)] = {y, lv.cout, Lc};
+  }
+  if (Lc != L) return fail(LDC_E_INVALID, "latent length %d does not survive the down/up path (got %d)", L, Lc);
+  x = pb.resnet(u.fin, x, x0, L);
+  {
+    void* th = pb.act(B * L, u.dim);
+    const void* xin = x;
+    const int64_t n = (int64_t)B * L * u.dim;
+    pb.add([=](hipStream_t s) { return launch_act(dt, xin, th, n, ACT_TANH, s); });
+    pb.conv(u.final_conv, th, nullptr, pl->eps_cl, nullptr, L, L);
+  }
+  return LDC_OK;
+}
+
+static int get_plan(ldc_ctx* c, int B, int L, int F, hipStream_t s, Plan** out) {
+  for (auto& p : c->plans)
+    if (p->B == B && p->L == L && p->F == F) {
+      *out = p.get();
+      return LDC_OK;
+    }
+  std::unique_ptr<Plan> pl(new Plan());
+  Arena measure;
+  LDCCHK(build_plan(c, pl.get(), measure, B, L, F));
+  void* base = nullptr;
+  hipError_t e = hipMalloc(&base, measure.off + 4096);
+  if (e != hipSuccess) return fail(LDC_E_NOMEM, "hipMalloc(%zu) for the UNet workspace failed: %s", measure.off, hipGetErrorString(e));
+  c->plan_mem.push_back(base);
+  Arena real;
+  real.base = (char*)base;
+  real.cap = measure.off + 4096;
+  LDCCHK(build_plan(c, pl.get(), real, B, L, F));
+  pl->arena_base = base;
+  pl->arena_bytes = real.cap;
+  *out = pl.get();
+  c->plans.push_back(std::move(pl));
+  (void)s;
+  return LDC_OK;
+}
+
+static int run_ops(ldc_ctx* c, Plan* pl, const std::vector<std::function<hipError_t(hipStream_t)>>& ops, bool is_step,
+                   hipStream_t s) {
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const bool prof = c->profile && is_step && pl->step_is_conv[i];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+      HIPCHK(hipEventCreate(&e0));
+      HIPCHK(hipEventCreate(&e1));
+      HIPCHK(hipEventRecord(e0, s));
+    }
+    HIPCHK(ops[i](s));
+    if (prof) {
+      HIPCHK(hipEventRecord(e1, s));
+      c->prof_events.push_back({e0, e1});
+      c->prof_event_flops.push_back(pl->step_flops[i]);
+    }
+  }
+  return LDC_OK;
+}
+
+static int load_cond(ldc_ctx* c, Plan* pl, const float* cond, hipStream_t s) {
+  HIPCHK(launch_to_cl(DT_F32, cond, pl->cond_in_cl, pl->B, c->unet.cond_channels, pl->F, nullptr, 0, 0.f, s));
+  return run_ops(c, pl, pl->cond_ops, false, s);
+}
+
+static int check_unet_args(ldc_ctx* c, int B, int L, int F) {
+  if (B <= 0 || L <= 0 || F <= 0) return fail(LDC_E_INVALID, "bad sizes");
+  if (c->unet.upsamplers.empty()) return fail(LDC_E_INVALID, "upsampling_ratios=None is not supported on the other_cond path");
+  if (F * upsample_factor(c) != L) return fail(LDC_E_INVALID, "L (%d) must equal F (%d) x prod(upsampling_ratios) (%d)", L, F, upsample_factor(c));
+  return LDC_OK;
+}
+
+extern "C" int ldc_unet_forward(ldc_ctx* c, const float* x, int t, const float* cond, int B, int L, int F, float* eps_out,
+                                void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!x || !cond || !eps_out) return fail(LDC_E_INVALID, "null tensor");
+  if (t < 0 || t >= c->unet.timesteps) return fail(LDC_E_INVALID, "t out of range");
+  LDCCHK(check_unet_args(c, B, L, F));
+  hipStream_t s = pick_stream(c, stream);
+  Plan* pl = nullptr;
+  LDCCHK(get_plan(c, B, L, F, s, &pl));
+  LDCCHK(load_cond(c, pl, cond, s));
+  HIPCHK(launch_to_cl(c->dt, x, pl->x_cl, B, c->unet.channels, L, nullptr, 0, 0.f, s));
+  HIPCHK(launch_step_set(c->step_state, t, 0, s));
+  LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
+  HIPCHK(launch_from_cl(c->dt, pl->eps_cl, eps_out, B, c->unet.channels, L, nullptr, 0, 0.f, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_unet_debug_tap(ldc_ctx* c, const char* name, float* out, int64_t capacity, void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!name || !out) return fail(LDC_E_INVALID, "null argument");
+  if (c->plans.empty()) return fail(LDC_E_STATE, "no UNet call has been made yet");
+  Plan* pl = c->plans.back().get();
+  auto it = pl->taps.find(name);
+  if (it == pl->taps.end()) return fail(LDC_E_INVALID, "unknown tap '%s'", name);
+  const int64_t need = (int64_t)pl->B * it->second.C * it->second.L;
+  if (capacity < need) return fail(LDC_E_INVALID, "tap '%s' needs %lld elements", name, (long long)need);
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_from_cl(c->dt, it->second.p, out, pl->B, it->second.C, it->second.L, nullptr, 0, 0.f, s));
+  return finish_stream(c, stream);
+}
+
+static int one_step(ldc_ctx* c, Plan* pl, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
+  LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
+  HIPCHK(launch_p_sample_update(c->dt, x, pl->eps_cl, noise, noise_stride, pl->x_cl, pl->B, c->unet.channels, pl->L, c->sched,
+                                c->step_state, c->cfg.noise_seed, s));
+  HIPCHK(launch_step_advance(c->step_state, s));
+  return LDC_OK;
+}
+
+extern "C" int ldc_p_sample(ldc_ctx* c, float* x, int t, const float* cond, const float* noise, int B, int L, int F,
+                            void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!x || !cond) return fail(LDC_E_INVALID, "null tensor");
+  if (t < 0 || t >= c->unet.timesteps) return fail(LDC_E_INVALID, "t out of range");
+  LDCCHK(check_unet_args(c, B, L, F));
+  hipStream_t s = pick_stream(c, stream);
+  Plan* pl = nullptr;
+  LDCCHK(get_plan(c, B, L, F, s, &pl));
+  LDCCHK(load_cond(c, pl, cond, s));
+  HIPCHK(launch_to_cl(c->dt, x, pl->x_cl, B, c->unet.channels, L, nullptr, 0, 0.f, s));
+  HIPCHK(launch_step_set(c->step_state, t, 0, s));
+  LDCCHK(one_step(c, pl, x, noise, 0, s));
+  return finish_stream(c, stream);
+}
+
+// the denoise loop on a prepared plan (cond already processed, x_cl already set)
+static int denoise_loop(ldc_ctx* c, Plan* pl, float* x, const float* noise, int n_steps, hipStream_t s) {
+  const int64_t stride = (int64_t)pl->B * c->unet.channels * pl->L;
+  HIPCHK(launch_step_set(c->step_state, n_steps - 1, 0, s));
+  if (c->profile || n_steps < 3) {
+    for (int i = 0; i < n_steps; ++i) LDCCHK(one_step(c, pl, x, noise, stride, s));
+    return LDC_OK;
+  }
+  int done = 0;
+  if (!pl->graph || pl->graph_noise != noise || pl->graph_x != x || pl->graph_stream != s) {
+    if (pl->graph) { (void)hipGraphExecDestroy(pl->graph); pl->graph = nullptr; }
+    // first step eagerly: loads code objects / sets function attributes outside of the capture
+    LDCCHK(one_step(c, pl, x, noise, stride, s));
+    done = 1;
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    int r = one_step(c, pl, x, noise, stride, s);
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (r != LDC_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (e != hipSuccess) return fail(LDC_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&pl->graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { pl->graph = nullptr; return fail(LDC_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    pl->graph_noise = noise; pl->graph_x = x; pl->graph_stream = s;
+  }
+  for (int i = done; i < n_steps; ++i) HIPCHK(hipGraphLaunch(pl->graph, s));
+  return LDC_OK;
+}
+
+extern "C" int ldc_denoise(ldc_ctx* c, float* img, const float* cond, const float* noise, int n_steps, int B, int L, int F,
+                           void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!img || !cond) return fail(LDC_E_INVALID, "null tensor");
+  if (n_steps < 1 || n_steps > c->unet.timesteps) return fail(LDC_E_INVALID, "n_steps must be in [1,%d]", c->unet.timesteps);
+  LDCCHK(check_unet_args(c, B, L, F));
+  hipStream_t s = pick_stream(c, stream);
+  Plan* pl = nullptr;
+  LDCCHK(get_plan(c, B, L, F, s, &pl));
+  LDCCHK(load_cond(c, pl, cond, s));
+  HIPCHK(launch_to_cl(c->dt, img, pl->x_cl, B, c->unet.channels, L, nullptr, 0, 0.f, s));
+  LDCCHK(denoise_loop(c, pl, img, noise, n_steps, s));
+  return finish_stream(c, stream);
+}
+
+static int ensure_outnorm(ldc_ctx* c, int B) {
+  const size_t need = output_normalise_ws_bytes(B);
+  if (need <= c->outnorm_ws_bytes) return LDC_OK;
+  HIPCHK(hipDeviceSynchronize());
+  if (c->outnorm_ws) HIPCHK(hipFree(c->outnorm_ws));
+  c->outnorm_ws = nullptr;
+  HIPCHK(hipMalloc(&c->outnorm_ws, need * 2));
+  c->outnorm_ws_bytes = need * 2;
+  return LDC_OK;
+}
+
+extern "C" int ldc_output_normalise(ldc_ctx* c, float* wav, int B, int T, int per_item, void* stream) {
+  if (!c) return fail(LDC_E_INVALID, "null ctx");
+  if (!wav || B <= 0 || T <= 0) return fail(LDC_E_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  LDCCHK(ensure_outnorm(c, B));
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_output_normalise(wav, B, T, per_item ? 1 : 0, c->outnorm_ws, s));
+  return finish_stream(c, stream);
+}
+
+// synthesis() body for one resident batch (sample.py:94-134)
+extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_steps, const float* noise, int per_item,
+                          float* wav_out, float* latents_out, float* cond_out, int64_t* codes_out, void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN, true));
+  if (!wav || !wav_out || B <= 0 || T <= 0) return fail(LDC_E_INVALID, "bad arguments");
+  if (n_steps < 1 || n_steps > c->unet.timesteps) return fail(LDC_E_INVALID, "n_steps must be in [1,%d]", c->unet.timesteps);
+  const Codec& cc = c->codec[LDC_MODEL_COND];
+  const Codec& mc = c->codec[LDC_MODEL_MAIN];
+  if (T % cc.hop || T % mc.hop) return fail(LDC_E_INVALID, "T must be a multiple of %d and %d (sample.py:87 trims to 640)", cc.hop, mc.hop);
+  const int F = T / cc.hop, L = T / mc.hop, D = c->cfg.rep_dims;
+  LDCCHK(check_unet_args(c, B, L, F));
+  LDCCHK(ensure_outnorm(c, B));
+  hipStream_t s = pick_stream(c, stream);
+  Plan* pl = nullptr;
+  LDCCHK(get_plan(c, B, L, F, s, &pl));
+  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    float* qr = nullptr;
+    int Fq = 0;
+    LDCCHK(get_cond_rows(c, wav, B, T, 0.f, ar, dry, s, &qr, &Fq, codes_out));
+    if (!dry && Fq != F) return fail(LDC_E_INVALID, "internal: encoder produced %d frames, expected %d", Fq, F);
+    float* x = latents_out ? latents_out : (float*)ar.alloc((size_t)B * D * L * 4);
+    float* mx = (float*)ar.alloc((size_t)B * 4);
+    // start image: upsample, /= max|.|+1e-8 (sample.py:125-129)
+    void* up = nullptr;
+    int Lu = 0;
+    LDCCHK(upsample_rows(c, qr, B, F, ar, dry, s, &up, &Lu));
+    if (!dry) {
+      if (cond_out) HIPCHK(launch_from_cl(DT_F32, qr, cond_out, B, D, F, nullptr, 0, 0.f, s));
+      HIPCHK(hipMemsetAsync(mx, 0, (size_t)B * 4, s));
+      HIPCHK(launch_maxabs(DT_F32, up, B, (int64_t)L * D, per_item ? 1 : 0, mx, s));
+      HIPCHK(launch_from_cl(DT_F32, up, x, B, D, L, mx, per_item ? 1 : 0, 1e-8f, s));
+      // process_cond for the UNet (rows are already channels-last fp32)
+      HIPCHK(hipMemcpyAsync(pl->cond_in_cl, qr, (size_t)B * F * D * 4, hipMemcpyDeviceToDevice, s));
+      LDCCHK(run_ops(c, pl, pl->cond_ops, false, s));
+      HIPCHK(launch_to_cl(c->dt, x, pl->x_cl, B, D, L, nullptr, 0, 0.f, s));
+      LDCCHK(denoise_loop(c, pl, x, noise, n_steps, s));
+    }
+    // decoder (quirk Q3: no x18 un-scaling on this path, sample.py:131)
+    SeaRun R{c, &ar, s, dry, B};
+    void* zc = ar.alloc((size_t)B * L * D * 4);
+    if (!dry) HIPCHK(launch_to_cl(DT_F32, x, zc, B, D, L, nullptr, 0, 0.f, s));
+    void* y = nullptr;
+    int Lo = 0, C = 0;
+    LDCCHK(run_seanet(R, mc.dec, zc, L, &y, &Lo, &C));
+    if (!dry) {
+      HIPCHK(hipMemcpyAsync(wav_out, y, (size_t)B * Lo * 4, hipMemcpyDeviceToDevice, s));
+      HIPCHK(launch_output_normalise(wav_out, B, Lo, per_item ? 1 : 0, c->outnorm_ws, s));
+    }
+    return LDC_OK;
+  }));
+  return finish_stream(c, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// L1 primitives for the parity tests
+// ------------------------------------------------------------------------------------------------
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int ldc_sconv1d(ldc_ctx* c, const float* x, int B, int Cin, int L, const float* w_host, const float* b_host,
+                           int Cout, int k, int stride, int dilation, int causal, int pre_elu, float* y, void* stream) {
+  if (!c || !x || !w_host || !y) return fail(LDC_E_INVALID, "null argument");
+  if (B <= 0 || Cin <= 0 || L <= 0 || Cout <= 0 || k <= 0 || stride <= 0 || dilation <= 0) return fail(LDC_E_INVALID, "bad sizes");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = pick_stream(c, stream);
+  const int cp = round_up(Cin, 16);
+  std::vector<float> wp((size_t)Cout * cp * k, 0.f);
+  for (int o = 0; o < Cout; ++o)
+    for (int i = 0; i < Cin; ++i)
+      for (int t = 0; t < k; ++t) wp[((size_t)o * cp + i) * k + t] = w_host[((size_t)o * Cin + i) * k + t];
+  DevMem keep;
+  std::swap(keep.ptrs, c->wmem.ptrs);   // make_conv allocates from c->wmem; give it a temporary pool
+  ConvLayer ly;
+  ConvSpec sp;
+  sp.dt = DT_F32; sp.cin1 = cp; sp.cout = Cout; sp.k = k; sp.stride = stride; sp.dil = dilation;
+  const int padding_total = (k - 1) * dilation - (stride - 1);
+  sp.pad_left = causal ? padding_total : padding_total - padding_total / 2;
+  sp.pad_mode = PAD_REFLECT; sp.pre_act = pre_elu ? ACT_ELU : ACT_NONE;
+  int rc = make_conv(c, sp, wp.data(), b_host, &ly);
+  std::swap(keep.ptrs, c->wmem.ptrs);   // `keep` now owns the temporaries and frees them on return
+  LDCCHK(rc);
+  const int Lout = conv_out_len(ly, L);
+  if (L <= sp.pad_left) return fail(LDC_E_INVALID, "input shorter than the reflect padding is not supported (L=%d pad=%d)", L, sp.pad_left);
+  void *xc = nullptr, *yc = nullptr;
+  LDCCHK(keep.alloc(&xc, (size_t)B * L * cp * 4));
+  LDCCHK(keep.alloc(&yc, (size_t)B * Lout * Cout * 4));
+  HIPCHK(hipMemsetAsync(xc, 0, (size_t)B * L * cp * 4, s));
+  // [B][Cin][L] -> rows [B*L][cp]: transpose into the first Cin columns
+  {
+    void* tmp = nullptr;
+    LDCCHK(keep.alloc(&tmp, (size_t)B * L * Cin * 4));
+    HIPCHK(launch_to_cl(DT_F32, x, tmp, B, Cin, L, nullptr, 0, 0.f, s));
+    HIPCHK(hipMemcpy2DAsync(xc, (size_t)cp * 4, tmp, (size_t)Cin * 4, (size_t)Cin * 4, (size_t)B * L, hipMemcpyDeviceToDevice, s));
+  }
+  ConvCall cc;
+  cc.B = B; cc.L_in = L; cc.L_rows = Lout; cc.x1 = xc; cc.y = yc; cc.y_ld = Cout;
+  HIPCHK(launch_conv(ly, cc, s));
+  HIPCHK(launch_from_cl(DT_F32, yc, y, B, Cout, Lout, nullptr, 0, 0.f, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return LDC_OK;
+}
+
+extern "C" int ldc_sconvtr1d(ldc_ctx* c, const float* x, int B, int Cin, int L, const float* w_host, const float* b_host,
+                             int Cout, int k, int stride, int causal, float* y, void* stream) {
+  if (!c || !x || !w_host || !y) return fail(LDC_E_INVALID, "null argument");
+  if (k != 2 * stride) return fail(LDC_E_INVALID, "only kernel_size == 2*stride transposed convs exist on the decode path");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = pick_stream(c, stream);
+  const int cp = round_up(Cin, 16);
+  std::vector<float> wp((size_t)cp * Cout * k, 0.f);
+  memcpy(wp.data(), w_host, (size_t)Cin * Cout * k * 4);
+  DevMem keep;
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  ConvLayer ly;
+  const int padding_total = k - stride;
+  const int trim_left = causal ? 0 : padding_total - padding_total / 2;
+  int rc = make_convtr(c, DT_F32, cp, Cout, stride, trim_left, ACT_NONE, wp.data(), b_host, &ly);
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  LDCCHK(rc);
+  const int Lout = L * stride;
+  void *xc = nullptr, *yc = nullptr, *tmp = nullptr;
+  LDCCHK(keep.alloc(&xc, (size_t)B * L * cp * 4));
+  LDCCHK(keep.alloc(&yc, (size_t)B * Lout * Cout * 4));
+  LDCCHK(keep.alloc(&tmp, (size_t)B * L * Cin * 4));
+  HIPCHK(hipMemsetAsync(xc, 0, (size_t)B * L * cp * 4, s));
+  HIPCHK(launch_to_cl(DT_F32, x, tmp, B, Cin, L, nullptr, 0, 0.f, s));
+  HIPCHK(hipMemcpy2DAsync(xc, (size_t)cp * 4, tmp, (size_t)Cin * 4, (size_t)Cin * 4, (size_t)B * L, hipMemcpyDeviceToDevice, s));
+  ConvCall cc;
+  cc.B = B; cc.L_in = L; cc.L_rows = L + 1; cc.L_final = Lout; cc.x1 = xc; cc.y = yc; cc.y_ld = Cout;
+  HIPCHK(launch_conv(ly, cc, s));
+  HIPCHK(launch_from_cl(DT_F32, yc, y, B, Cout, Lout, nullptr, 0, 0.f, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return LDC_OK;
+}
+
+extern "C" int ldc_slstm(ldc_ctx* c, const float* x, int B, int H, int T, const float* const* weights_host, int layers,
+                         float* y, void* stream) {
+  if (!c || !x || !weights_host || !y) return fail(LDC_E_INVALID, "null argument");
+  if (H % 16) return fail(LDC_E_INVALID, "H must be a multiple of 16");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = pick_stream(c, stream);
+  // stage the weights as a throw-away state dict so that build_lstm can be reused
+  ldc_ctx tmpc;
+  tmpc.cfg = c->cfg;
+  tmpc.device = c->device;
+  tmpc.own_stream = c->own_stream;
+  for (int n = 0; n < layers; ++n) {
+    const char* names[4] = {"weight_ih_l", "weight_hh_l", "bias_ih_l", "bias_hh_l"};
+    for (int j = 0; j < 4; ++j) {
+      HostTensor t;
+      if (j < 2) t.shape = {4 * H, H};
+      else t.shape = {4 * H};
+      t.data.assign(weights_host[4 * n + j], weights_host[4 * n + j] + t.numel());
+      tmpc.raw[0][std::string("p.lstm.") + names[j] + std::to_string(n)] = std::move(t);
+    }
+  }
+  WeightReader wr{&tmpc, 0, ""};
+  SeaOp op;
+  op.kind = SeaOp::LSTM; op.cin = op.cout = H;
+  int rc = build_lstm(&tmpc, wr, "p", H, layers, &op.lstm);
+  tmpc.own_stream = nullptr;
+  LDCCHK(rc);
+  if (!wr.missing.empty()) return fail(LDC_E_INVALID, "internal: %s", wr.missing.c_str());
+  std::vector<SeaOp> ops{op};
+  int ret = with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    SeaRun R{c, &ar, s, dry, B};
+    void* xc = ar.alloc((size_t)B * T * H * 4);
+    if (!dry) HIPCHK(launch_to_cl(DT_F32, x, xc, B, H, T, nullptr, 0, 0.f, s));
+    void* o = nullptr;
+    int Lo = 0, C = 0;
+    LDCCHK(run_seanet(R, ops, xc, T, &o, &Lo, &C));
+    if (!dry) HIPCHK(launch_from_cl(DT_F32, o, y, B, H, T, nullptr, 0, 0.f, s));
+    return LDC_OK;
+  });
+  hipError_t e = hipStreamSynchronize(s);
+  if (ret != LDC_OK) return ret;
+  if (e != hipSuccess) return fail(LDC_E_HIP, "sync failed: %s", hipGetErrorString(e));
+  return LDC_OK;   // tmpc.wmem frees the temporaries
+}
+
+// ------------------------------------------------------------------------------------------------
+// accounting / profiling
+// ------------------------------------------------------------------------------------------------
+extern "C" int ldc_unet_step_cost(ldc_ctx* c, int B, int L, double* flops, double* bytes) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  const int F = L / std::max(1, upsample_factor(c));
+  LDCCHK(check_unet_args(c, B, L, F));
+  Plan tmp;
+  Arena measure;
+  LDCCHK(build_plan(c, &tmp, measure, B, L, F));
+  if (flops) *flops = tmp.flops;
+  // algorithmic bytes with perfect intra-block fusion: every conv-boundary activation
+  // read + written once, the weights once per step
+  if (bytes) {
+    double conv_act = 0;
+    (void)conv_act;
+    *bytes = c->unet.weight_elems * dt_size(c->dt) + tmp.act_bytes;
+  }
+  return LDC_OK;
+}
+
+extern "C" int ldc_profile_enable(ldc_ctx* c, int on) {
+  if (!c) return fail(LDC_E_INVALID, "null ctx");
+  c->profile = on != 0;
+  if (on) {
+    for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    c->prof_events.clear();
+    c->prof_event_flops.clear();
+    c->prof_ms = 0; c->prof_flops = 0; c->prof_launches = 0;
+  }
+  return LDC_OK;
+}
+
+extern "C" int ldc_profile_read(ldc_ctx* c, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total) {
+  if (!c) return fail(LDC_E_INVALID, "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipDeviceSynchronize());
+  for (size_t i = 0; i < c->prof_events.size(); ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
+    c->prof_ms += ms;
+    c->prof_flops += c->prof_event_flops[i];
+    c->prof_launches += 1;
+    (void)hipEventDestroy(c->prof_events[i].first);
+    (void)hipEventDestroy(c->prof_events[i].second);
+  }
+  c->prof_events.clear();
+  c->prof_event_flops.clear();
+  if (conv_ms_total) *conv_ms_total = c->prof_ms;
+  if (conv_launches) *conv_launches = c->prof_launches;
+  if (conv_flops_total) *conv_flops_total = c->prof_flops;
+  return LDC_OK;
+}

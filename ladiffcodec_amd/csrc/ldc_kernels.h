@@ -1,0 +1,145 @@
+// Internal kernel-launcher interface of libladiffcodec (gfx950 / CDNA4 only).
+//
+// Internal activation layout is channels-last: a tensor of B items, L positions, C channels is a
+// row-major matrix [B*L][C] in the context's compute dtype (float or bf16).  This makes every conv
+// an "NT" GEMM whose two MFMA operands are both K(channel)-contiguous, turns channel concatenation
+// into a second input pointer, channel LayerNorm / RVQ / LSTM inputs into row operations, and
+// nearest-upsampling / striding / causal reflect padding into row-index arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ldc {
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_ELU = 2, ACT_TANH = 3, ACT_GELU = 4 };
+enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm.hip : implicit-GEMM Conv1d / ConvTranspose1d on MFMA
+// ------------------------------------------------------------------------------------------------
+// GEMM view: rows m = (item b, output position l), columns n = output channel, K = taps x Cin.
+// Input row gathered for (l, tap):  u = l*stride + tap*dil - pad_left ;  row = u >> ups
+//   (ups=1 folds nn.Upsample(scale 2, nearest) into the index), zero or reflect outside [0, L_in<<ups).
+// Transposed conv (kernel 2s, stride s) is the 2-tap conv over q in [0, L_in] with N = s*Cout
+// (phase-major); the epilogue scatters (q, phase) to position q*s + phase - trim_left.
+struct ConvLayer {
+  int dt = DT_F32;
+  int cin1 = 0, cin2 = 0;     // channels of the two (concatenated) inputs; cin2 = 0 for one input
+  int n = 0;                  // GEMM N actually stored (Cout, or s*Cout for transposed)
+  int n_pad = 0;              // N padded to the tile
+  int bn = 128;               // N tile: 32 | 64 | 128
+  int taps = 1, stride = 1, dil = 1, pad_left = 0, ups = 0, pad_mode = PAD_ZERO;
+  int pre_act = ACT_NONE, post_act = ACT_NONE;
+  int tr_stride = 0, tr_cout = 0, tr_trim_left = 0;   // transposed-conv scatter (tr_stride = 0: plain)
+  void* w = nullptr;          // packed [chunk][tap][n_pad][64 B of K]
+  float* bias = nullptr;      // [n] fp32 or null
+  double flops_per_row = 0;   // 2*K*N, for accounting
+};
+
+struct ConvCall {
+  const void* x1 = nullptr;
+  const void* x2 = nullptr;
+  void* y = nullptr;
+  const void* residual = nullptr;  // [rows][n], same dtype, added before post_act (plain conv only)
+  int B = 0;
+  int L_in = 0;               // positions per item of the input
+  int L_rows = 0;             // GEMM rows per item (output positions; L_in+1 for transposed)
+  int L_final = 0;            // transposed: final positions per item after trimming
+  int y_ld = 0;               // channels per output row
+  float* gn_sum = nullptr;    // optional fused GroupNorm statistics: [B][groups][2] (sum, sumsq), pre-zeroed
+  int gn_groups = 0;
+};
+
+hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
+size_t conv_packed_weight_bytes(const ConvLayer& ly);
+// host-side packers (fp32 [Cout][Cin][k] or, transposed, [Cin][Cout][k]) -> packed image in ly.dt
+void pack_conv_weights(const ConvLayer& ly, const float* w_oik, void* dst_host);
+void pack_convtr_weights(const ConvLayer& ly, const float* w_iok, int cin, int cout, int stride, void* dst_host);
+int conv_pick_bn(int n);
+
+// ------------------------------------------------------------------------------------------------
+// norm_act.hip
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics of x [B][L][C]: stats[b][g] = (sum, sumsq) accumulated with fp32 atomics into a
+// pre-zeroed buffer.
+hipError_t launch_gn_stats(int dt, const void* x, int B, int L, int C, int groups, float* stats, hipStream_t s);
+// y = act( GN(x)*(scale+1)+shift ) (+ residual).  scale_shift: fp32 [2*C] (scale then shift) selected
+// by *t_ptr from a table with row stride ss_stride, or null.  eps 1e-5.
+hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual, int B, int L, int C, int groups,
+                           const float* stats, const float* gamma, const float* beta, const float* ss_table,
+                           int ss_stride, const int* t_ptr, int act, hipStream_t s);
+// channel LayerNorm (gain only, biased var, eps 1e-5) per row; y = LN(x)*g (+ residual)
+hipError_t launch_ln_rows(int dt, const void* x, void* y, const void* residual, const float* g, int rows, int C,
+                          hipStream_t s);
+// elementwise tanh in place / out of place
+hipError_t launch_act(int dt, const void* x, void* y, int64_t n, int act, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// attention.hip   (heads x dim_head = 4 x 32 fixed by the reference, unet.py:195,225)
+// ------------------------------------------------------------------------------------------------
+// qkv [B*L][3*H*D] (q | k | v, head-major).  ctx_ws: fp32 [B][H][D][D].
+hipError_t launch_linattn(int dt, const void* qkv, void* out, float* ctx_ws, int B, int L, int heads, int dim_head,
+                          hipStream_t s);
+hipError_t launch_attn_full(int dt, const void* qkv, void* out, int B, int L, int heads, int dim_head, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// diffusion.hip
+// ------------------------------------------------------------------------------------------------
+// [B][C][L] fp32 -> [B][L][C] dt  (optionally multiplied by 1/(maxabs[b or 0] + eps))
+hipError_t launch_to_cl(int dt, const float* x_bcl, void* y_blc, int B, int C, int L, const float* maxabs,
+                        int maxabs_per_item, float eps, hipStream_t s);
+// [B][L][C] dt -> [B][C][L] fp32 (same optional scaling)
+hipError_t launch_from_cl(int dt, const void* x_blc, float* y_bcl, int B, int C, int L, const float* maxabs,
+                          int maxabs_per_item, float eps, hipStream_t s);
+// maxabs[b] (or maxabs[0] when !per_item) = max |x| ; buffer must be pre-zeroed.  Works on raw element
+// streams: n_per_item elements per item.
+hipError_t launch_maxabs(int dt, const void* x, int B, int64_t n_per_item, int per_item, float* maxabs,
+                         hipStream_t s);
+// Step state on the device: st[0] = current t, st[1] = iteration index j.
+struct StepTables {            // device pointers, fp32 [T]
+  const float* sqrt_recip_alphas_cumprod;
+  const float* sqrt_recipm1_alphas_cumprod;
+  const float* posterior_mean_coef1;
+  const float* posterior_mean_coef2;
+  const float* posterior_log_variance_clipped;
+};
+// x [B][C][L] fp32 in place; eps_cl [B][L][C] dt; noise [.. j ..][B][C][L] fp32 or null (Philox);
+// also writes x_cl [B][L][C] dt (the next step's UNet input).  Reads t, j from st.
+hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const float* noise, int64_t noise_step_stride,
+                                  void* x_cl, int B, int C, int L, StepTables tb, const int* st, uint64_t seed,
+                                  hipStream_t s);
+// x /= (maxabs[b or 0] + eps) in place on a raw element stream (n_per_item elements per item)
+hipError_t launch_scale_by_maxabs(int dt, void* x, int B, int64_t n_per_item, const float* maxabs, int per_item,
+                                  float eps, hipStream_t s);
+hipError_t launch_step_advance(int* st, hipStream_t s);      // t -= 1, j += 1
+hipError_t launch_step_set(int* st, int t, int j, hipStream_t s);
+// output normalisation (sample.py:133-134); ws: double [B][2] + float [B] zeroed by the launcher
+hipError_t launch_output_normalise(float* x, int B, int64_t n_per_item, int per_item, void* ws, hipStream_t s);
+size_t output_normalise_ws_bytes(int B);
+
+// ------------------------------------------------------------------------------------------------
+// seanet.hip
+// ------------------------------------------------------------------------------------------------
+// First SEANet conv: Cin = 1, causal reflect pad.  x [B][L] fp32 -> y [B][L][Cout] dt.  w [Cout][k] fp32.
+hipError_t launch_conv_cin1(int dt, const float* x, void* y, const float* w, const float* bias, int B, int L, int Cout,
+                            int k, hipStream_t s);
+// LSTM recurrence over T for one layer.  pre [B][T][4H] dt_pre (input GEMM + both biases), w_hh [4H][H]
+// fp32, out [B][T][H]; if skip != null: out = h + skip (SLSTM skip, lstm.py:25-26).
+hipError_t launch_lstm_layer(int dt, const void* pre, const float* w_hh, void* out, const void* skip, int B, int T,
+                             int H, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// rvq.hip
+// ------------------------------------------------------------------------------------------------
+// z_cl [B*F][D] fp32 rows; codebooks [n_q][bins][D] fp32 and their squared norms [n_q][bins].
+// codes [n_q][B*F] int64 (nullable), quantized_cl [B*F][D] fp32.
+hipError_t launch_rvq(const float* z_rows, int rows, int D, const float* codebooks, const float* cb_sqnorm, int bins,
+                      int n_q, int64_t* codes, float* quantized_rows, hipStream_t s);
+hipError_t launch_rvq_decode(const int64_t* codes, int rows, int D, const float* codebooks, int bins, int n_q,
+                             float* quantized_rows, hipStream_t s);
+hipError_t launch_sqnorm_rows(const float* x, int rows, int D, float* out, hipStream_t s);
+
+}  // namespace ldc

@@ -1,0 +1,269 @@
+// norm_act.hip -- GroupNorm(+timestep scale/shift)+SiLU, channel LayerNorm, elementwise activations.
+//
+// Replaces nn.GroupNorm + `x*(scale+1)+shift` + nn.SiLU of Block.forward (reference
+// srcs/modules/unet.py:145-154), the residual add of ResnetBlock.forward (:192), the gain-only
+// channel LayerNorm (:82-91) used by PreNorm (:93-101) and LinearAttention.to_out (:203-206), and
+// the tanh before final_conv (:467).  All are HBM-bound streaming kernels over channels-last rows:
+// algorithmic bytes = (reads + writes) * rows * C * sizeof(dtype).
+#include "ldc_kernels.h"
+
+namespace ldc {
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// 8 consecutive channels per thread: one 16 B (bf16) or two 16 B (f32) accesses
+template <typename T>
+struct Vec8;
+template <>
+struct Vec8<float> {
+  static __device__ __forceinline__ void load(const void* p, size_t idx, float (&v)[8]) {
+    const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + idx);
+    float4 a = q[0], b = q[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(void* p, size_t idx, const float (&v)[8]) {
+    float4* q = reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + idx);
+    q[0] = make_float4(v[0], v[1], v[2], v[3]);
+    q[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <>
+struct Vec8<__bf16> {
+  static __device__ __forceinline__ void load(const void* p, size_t idx, float (&v)[8]) {
+    uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p) + idx);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = bf2f((unsigned short)(w[i] & 0xffffu));
+      v[2 * i + 1] = bf2f((unsigned short)(w[i] >> 16));
+    }
+  }
+  static __device__ __forceinline__ void store(void* p, size_t idx, const float (&v)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p) + idx) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+__device__ __forceinline__ float act_f(float v, int act) {
+  switch (act) {
+    case ACT_SILU: return v / (1.0f + __expf(-v));
+    case ACT_ELU: return v > 0.0f ? v : expm1f(v);
+    case ACT_TANH: return tanhf(v);
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    default: return v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics.  grid (chunks, B); a block walks rows [r0, r1) of one item, thread -> fixed
+// 8-channel slice (so a fixed group), then LDS-reduces per group and issues one atomic pair per group.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const void* x, int L, int C, int groups, int rows_per_block,
+                                                       float* stats) {
+  __shared__ float red[2][64];   // up to 64 groups
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(L, r0 + rows_per_block);
+  const int vec_per_row = C / 8;
+  const int tid = threadIdx.x;
+  if (tid < 64) { red[0][tid] = 0.f; red[1][tid] = 0.f; }
+  __syncthreads();
+  const int cpg = C / groups;
+  // thread -> (row phase, vec): iterate flat over (rows x vec_per_row)
+  const int total = (r1 - r0) * vec_per_row;
+  float s = 0.f, ss = 0.f;
+  int cur_g = -1;
+  for (int idx = tid; idx < total; idx += 256) {
+    const int r = idx / vec_per_row, v = idx - r * vec_per_row;
+    const int g = (v * 8) / cpg;
+    float f[8];
+    Vec8<T>::load(x, ((size_t)(b * L + r0 + r)) * C + v * 8, f);
+    if (cpg >= 8) {
+      if (g != cur_g) {
+        if (cur_g >= 0) { atomicAdd(&red[0][cur_g], s); atomicAdd(&red[1][cur_g], ss); }
+        s = 0.f; ss = 0.f; cur_g = g;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s += f[i]; ss += f[i] * f[i]; }
+    } else {
+      // groups narrower than the vector (tiny test widths): per-element
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int gi = (v * 8 + i) / cpg;
+        atomicAdd(&red[0][gi], f[i]);
+        atomicAdd(&red[1][gi], f[i] * f[i]);
+      }
+    }
+  }
+  if (cur_g >= 0) { atomicAdd(&red[0][cur_g], s); atomicAdd(&red[1][cur_g], ss); }
+  __syncthreads();
+  if (tid < groups) {
+    atomicAdd(&stats[((size_t)b * groups + tid) * 2 + 0], red[0][tid]);
+    atomicAdd(&stats[((size_t)b * groups + tid) * 2 + 1], red[1][tid]);
+  }
+}
+
+hipError_t launch_gn_stats(int dt, const void* x, int B, int L, int C, int groups, float* stats, hipStream_t s) {
+  if (groups > 64 || C % 8 || C % groups) return hipErrorInvalidValue;
+  // ~64 KB of data per block
+  int rows_per_block = (int)std::max<size_t>(1, (64 * 1024) / ((size_t)C * dt_size(dt)));
+  // keep the 256-thread flat walk aligned so that a thread stays in one vec column when possible
+  dim3 grid((L + rows_per_block - 1) / rows_per_block, B);
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, x, L, C, groups, rows_per_block, stats);
+  else
+    hipLaunchKernelGGL(gn_stats_kernel<__bf16>, grid, dim3(256), 0, s, x, L, C, groups, rows_per_block, stats);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm apply: y = act( ((x-mean)*rstd*gamma+beta) * (scale+1) + shift ) (+ residual)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* x, void* y, const void* residual, int B, int L, int C,
+                                                       int groups, const float* stats, const float* gamma,
+                                                       const float* beta, const float* ss_table, int ss_stride,
+                                                       const int* t_ptr, int act) {
+  const int vec_per_row = C / 8;
+  const size_t total = (size_t)B * L * vec_per_row;
+  const int cpg = C / groups;
+  const float inv_n = 1.0f / ((float)L * (float)cpg);
+  const float* ss = nullptr;
+  if (ss_table) ss = ss_table + (size_t)(t_ptr ? *t_ptr : 0) * ss_stride;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / vec_per_row;
+    const int v = (int)(idx - row * vec_per_row);
+    const int b = (int)(row / L);
+    float f[8], o[8];
+    Vec8<T>::load(x, row * C + v * 8, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = v * 8 + i;
+      const int g = c / cpg;
+      const float sum = stats[((size_t)b * groups + g) * 2], sq = stats[((size_t)b * groups + g) * 2 + 1];
+      const float mean = sum * inv_n;
+      const float var = fmaxf(sq * inv_n - mean * mean, 0.0f);
+      const float rstd = rsqrtf(var + 1e-5f);
+      float val = (f[i] - mean) * rstd * gamma[c] + beta[c];
+      if (ss) val = val * (ss[c] + 1.0f) + ss[C + c];
+      o[i] = act_f(val, act);
+    }
+    if (residual) {
+      float r[8];
+      Vec8<T>::load(residual, row * C + v * 8, r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] += r[i];
+    }
+    Vec8<T>::store(y, row * C + v * 8, o);
+  }
+}
+
+hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual, int B, int L, int C, int groups,
+                           const float* stats, const float* gamma, const float* beta, const float* ss_table,
+                           int ss_stride, const int* t_ptr, int act, hipStream_t s) {
+  const size_t total = (size_t)B * L * (C / 8);
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, x, y, residual, B, L, C, groups, stats,
+                       gamma, beta, ss_table, ss_stride, t_ptr, act);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, x, y, residual, B, L, C, groups, stats,
+                       gamma, beta, ss_table, ss_stride, t_ptr, act);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel LayerNorm over each row (one wavefront per row)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const void* x, void* y, const void* residual, const float* g,
+                                                      int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * 256) >> 6;
+  const int vec_per_row = C / 8;
+  for (int row = wave; row < rows; row += nwaves) {
+    float s = 0.f;
+    // pass 1: mean
+    for (int v = lane; v < vec_per_row; v += 64) {
+      float f[8];
+      Vec8<T>::load(x, (size_t)row * C + v * 8, f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += f[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    // pass 2: biased variance about the mean (row is L1/L2 resident)
+    float ss = 0.f;
+    for (int v = lane; v < vec_per_row; v += 64) {
+      float f[8];
+      Vec8<T>::load(x, (size_t)row * C + v * 8, f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = f[i] - mean; ss += d * d; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rstd = rsqrtf(ss / (float)C + 1e-5f);
+    for (int v = lane; v < vec_per_row; v += 64) {
+      float f[8], o8[8];
+      Vec8<T>::load(x, (size_t)row * C + v * 8, f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o8[i] = (f[i] - mean) * rstd * g[v * 8 + i];
+      if (residual) {
+        float r[8];
+        Vec8<T>::load(residual, (size_t)row * C + v * 8, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] += r[i];
+      }
+      Vec8<T>::store(y, (size_t)row * C + v * 8, o8);
+    }
+  }
+}
+
+hipError_t launch_ln_rows(int dt, const void* x, void* y, const void* residual, const float* g, int rows, int C,
+                          hipStream_t s) {
+  if (C % 8) return hipErrorInvalidValue;
+  int blocks = std::min((rows + 3) / 4, 256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(ln_rows_kernel<float>, dim3(blocks), dim3(256), 0, s, x, y, residual, g, rows, C);
+  else
+    hipLaunchKernelGGL(ln_rows_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, x, y, residual, g, rows, C);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void act_kernel(const void* x, void* y, size_t nvec, int act) {
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
+    float f[8];
+    Vec8<T>::load(x, idx * 8, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = act_f(f[i], act);
+    Vec8<T>::store(y, idx * 8, f);
+  }
+}
+
+hipError_t launch_act(int dt, const void* x, void* y, int64_t n, int act, hipStream_t s) {
+  if (n % 8) return hipErrorInvalidValue;
+  const size_t nvec = (size_t)n / 8;
+  int blocks = (int)std::min<size_t>((nvec + 255) / 256, 256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (dt == DT_F32)
+    hipLaunchKernelGGL(act_kernel<float>, dim3(blocks), dim3(256), 0, s, x, y, nvec, act);
+  else
+    hipLaunchKernelGGL(act_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, x, y, nvec, act);
+  return hipGetLastError();
+}
+
+}  // namespace ldc

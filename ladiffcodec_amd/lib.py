@@ -1,0 +1,103 @@
+"""ctypes binding of libladiffcodec.so (the C ABI in include/ladiffcodec.h).
+
+There is deliberately no fallback: if the shared library is missing or does not load, `load()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libladiffcodec.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+LDC_F32, LDC_BF16 = 0, 1
+MODEL_MAIN, MODEL_COND = 0, 1
+MAX_RATIOS = 8
+
+EXPORTS = [
+    "ldc_last_error", "ldc_version", "ldc_create", "ldc_destroy", "ldc_set_weight", "ldc_finalize_weights",
+    "ldc_seanet_encode", "ldc_seanet_decode", "ldc_rvq_encode", "ldc_rvq_decode", "ldc_get_cond",
+    "ldc_cond_upsample", "ldc_unet_forward", "ldc_p_sample", "ldc_denoise", "ldc_output_normalise", "ldc_decode",
+    "ldc_sconv1d", "ldc_sconvtr1d", "ldc_slstm", "ldc_unet_debug_tap", "ldc_unet_step_cost", "ldc_profile_enable",
+    "ldc_profile_read",
+]
+
+
+class LdcConfig(C.Structure):
+    _fields_ = [
+        ("compute_dtype", C.c_int32), ("rep_dims", C.c_int32), ("n_filters", C.c_int32),
+        ("n_residual_layers", C.c_int32), ("lstm", C.c_int32), ("n_enc_ratios", C.c_int32),
+        ("enc_ratios", C.c_int32 * MAX_RATIOS), ("diff_dims", C.c_int32), ("n_upsampling_ratios", C.c_int32),
+        ("upsampling_ratios", C.c_int32 * MAX_RATIOS), ("unet_scale_cond", C.c_int32), ("unet_scale_x", C.c_int32),
+        ("has_cond_model", C.c_int32), ("cond_bandwidth", C.c_float), ("max_batch", C.c_int32),
+        ("max_latent_len", C.c_int32), ("noise_seed", C.c_uint64),
+    ]
+
+
+class LdcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libladiffcodec error {code}: {msg}")
+        self.code = code
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-8000:])
+    if r.returncode != 0:
+        raise RuntimeError("building libladiffcodec.so failed")
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(or `make -C {CSRC}`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64p, fp = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p
+    lib.ldc_last_error.restype = C.c_char_p
+    lib.ldc_version.restype = C.c_char_p
+    lib.ldc_create.argtypes = [C.POINTER(LdcConfig), i32, C.POINTER(vp)]
+    lib.ldc_destroy.argtypes = [vp]
+    lib.ldc_set_weight.argtypes = [vp, i32, C.c_char_p, vp, i64p, i32]
+    lib.ldc_finalize_weights.argtypes = [vp, i32]
+    lib.ldc_seanet_encode.argtypes = [vp, i32, fp, i32, i32, fp, vp]
+    lib.ldc_seanet_decode.argtypes = [vp, i32, fp, i32, i32, fp, vp]
+    lib.ldc_rvq_encode.argtypes = [vp, fp, i32, i32, i32, vp, fp, vp]
+    lib.ldc_rvq_decode.argtypes = [vp, vp, i32, i32, i32, fp, vp]
+    lib.ldc_get_cond.argtypes = [vp, fp, i32, i32, C.c_float, fp, vp, vp]
+    lib.ldc_cond_upsample.argtypes = [vp, fp, i32, i32, i32, fp, vp]
+    lib.ldc_unet_forward.argtypes = [vp, fp, i32, fp, i32, i32, i32, fp, vp]
+    lib.ldc_p_sample.argtypes = [vp, fp, i32, fp, fp, i32, i32, i32, vp]
+    lib.ldc_denoise.argtypes = [vp, fp, fp, fp, i32, i32, i32, i32, vp]
+    lib.ldc_output_normalise.argtypes = [vp, fp, i32, i32, i32, vp]
+    lib.ldc_decode.argtypes = [vp, fp, i32, i32, i32, fp, i32, fp, fp, fp, vp, vp]
+    lib.ldc_sconv1d.argtypes = [vp, fp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, fp, vp]
+    lib.ldc_sconvtr1d.argtypes = [vp, fp, i32, i32, i32, vp, vp, i32, i32, i32, i32, fp, vp]
+    lib.ldc_slstm.argtypes = [vp, fp, i32, i32, i32, C.POINTER(vp), i32, fp, vp]
+    lib.ldc_unet_debug_tap.argtypes = [vp, C.c_char_p, fp, C.c_int64, vp]
+    lib.ldc_unet_step_cost.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.ldc_profile_enable.argtypes = [vp, i32]
+    lib.ldc_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("ldc_last_error", "ldc_version"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise LdcError(rc, load().ldc_last_error().decode("utf-8", "replace"))

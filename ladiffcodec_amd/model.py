@@ -1,0 +1,373 @@
+"""Host-side mirror of the reference's model objects for the decode path.
+
+`DiffAudioRep` here exposes the attributes `synthesis()` touches in the reference
+(srcs/sample.py:56-131): `.get_cond(wav)`, `.encoder(wav)`, `.decoder(z)`, `.quantizer(...)`,
+`.diff_model(x, t, cond)`, `.diff_model.upsampling_layers` (applied in order),
+`.diffusion.halfway_sampling(img, t, condition)`, `.diffusion.p_sample(x, t, cond)`.
+Every one of them is a thin call into libladiffcodec.so on torch CUDA(ROCm) tensors; nothing is
+computed in Python.  One `Engine` (= one ldc_ctx) holds both models of a decode session, as the
+hipGraph, workspaces and step tables are shared.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import lib as L
+from .spec import CodecConfig, UnetConfig
+
+
+@dataclass
+class QuantizedResult:            # reference srcs/quantization/vq.py:19-25
+    quantized: "object"
+    codes: "object"
+    bandwidth: "object"
+    penalty: Optional["object"] = None
+
+
+class Engine:
+    """Owns the ldc_ctx.  dtype: 'bf16' (throughput) or 'f32' (exact-fp32 MFMA path, parity)."""
+
+    def __init__(self, main_codec: CodecConfig, unet: UnetConfig, cond_codec: Optional[CodecConfig] = None,
+                 dtype: str = "bf16", device: int = 0, noise_seed: int = 0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("ladiffcodec_amd needs an MI355X (gfx950) GPU; no CPU fallback exists")
+        self.lib = L.load()
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.main_codec, self.unet, self.cond_codec = main_codec, unet, cond_codec
+        cfg = L.LdcConfig()
+        cfg.compute_dtype = L.LDC_BF16 if dtype == "bf16" else L.LDC_F32
+        self.dtype = dtype
+        cfg.rep_dims, cfg.n_filters = main_codec.rep_dims, main_codec.n_filters
+        cfg.n_residual_layers, cfg.lstm = main_codec.n_residual_layers, main_codec.lstm
+        cfg.n_enc_ratios = len(main_codec.enc_ratios)
+        for i, r in enumerate(main_codec.enc_ratios):
+            cfg.enc_ratios[i] = r
+        cfg.diff_dims = unet.dim
+        ups = list(unet.upsampling_ratios or [])
+        cfg.n_upsampling_ratios = len(ups)
+        for i, r in enumerate(ups):
+            cfg.upsampling_ratios[i] = r
+        cfg.unet_scale_cond, cfg.unet_scale_x = int(unet.unet_scale_cond), int(unet.unet_scale_x)
+        cfg.has_cond_model = int(cond_codec is not None)
+        cfg.cond_bandwidth = float(cond_codec.bandwidth) if cond_codec is not None else 3.0
+        cfg.noise_seed = noise_seed
+        self._ctx = C.c_void_p()
+        L.check(self.lib.ldc_create(C.byref(cfg), device, C.byref(self._ctx)))
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._finalized = False
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self.torch.cuda.synchronize(self.device)
+            self.lib.ldc_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- load_model(model, path, strict) : utils.py:98-108 --------------------------------------
+    def load_state_dict(self, which: int, state_dict: Dict[str, np.ndarray]) -> None:
+        for key, arr in state_dict.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
+            L.check(self.lib.ldc_set_weight(self._ctx, which, key.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+
+    def finalize(self, strict: bool = True) -> None:
+        L.check(self.lib.ldc_finalize_weights(self._ctx, int(strict)))
+        self._finalized = True
+
+    # ---- plumbing --------------------------------------------------------------------------------
+    def _f32(self, t):
+        torch = self.torch
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(self.device, torch.float32).contiguous()
+        return t
+
+    def _enter(self):
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def _exit(self):
+        self.torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def _empty(self, *shape, dtype=None):
+        return self.torch.empty(*shape, device=self.device, dtype=dtype or self.torch.float32)
+
+    # ---- stages ----------------------------------------------------------------------------------
+    def encode(self, which: int, wav):
+        wav = self._f32(wav)
+        B, _, T = wav.shape
+        hop = (self.cond_codec if which == L.MODEL_COND else self.main_codec).hop_length
+        z = self._empty(B, self.main_codec.rep_dims, -(-T // hop))
+        s = self._enter()
+        L.check(self.lib.ldc_seanet_encode(self._ctx, which, wav.data_ptr(), B, T, z.data_ptr(), s))
+        self._exit()
+        return z
+
+    def decode_latents(self, which: int, z):
+        z = self._f32(z)
+        B, _, Lz = z.shape
+        hop = (self.cond_codec if which == L.MODEL_COND else self.main_codec).hop_length
+        wav = self._empty(B, 1, Lz * hop)
+        s = self._enter()
+        L.check(self.lib.ldc_seanet_decode(self._ctx, which, z.data_ptr(), B, Lz, wav.data_ptr(), s))
+        self._exit()
+        return wav
+
+    def rvq(self, z, n_q: int):
+        z = self._f32(z)
+        B, D, F = z.shape
+        codes = self._empty(n_q, B, F, dtype=self.torch.int64)
+        q = self._empty(B, D, F)
+        s = self._enter()
+        L.check(self.lib.ldc_rvq_encode(self._ctx, z.data_ptr(), B, F, n_q, codes.data_ptr(), q.data_ptr(), s))
+        self._exit()
+        return q, codes
+
+    def rvq_decode(self, codes):
+        codes = codes.to(self.device, self.torch.int64).contiguous()
+        n_q, B, F = codes.shape
+        q = self._empty(B, self.main_codec.rep_dims, F)
+        s = self._enter()
+        L.check(self.lib.ldc_rvq_decode(self._ctx, codes.data_ptr(), B, F, n_q, q.data_ptr(), s))
+        self._exit()
+        return q
+
+    def get_cond(self, wav, bandwidth: float = 0.0, return_codes: bool = False):
+        wav = self._f32(wav)
+        B, _, T = wav.shape
+        F = -(-T // self.cond_codec.hop_length)
+        n_q = self.cond_codec.n_q_for_bandwidth(bandwidth if bandwidth > 0 else None)
+        cond = self._empty(B, self.cond_codec.rep_dims, F)
+        codes = self._empty(n_q, B, F, dtype=self.torch.int64) if return_codes else None
+        s = self._enter()
+        L.check(self.lib.ldc_get_cond(self._ctx, wav.data_ptr(), B, T, float(bandwidth), cond.data_ptr(),
+                                      codes.data_ptr() if codes is not None else None, s))
+        self._exit()
+        return (cond, codes) if return_codes else cond
+
+    def cond_upsample(self, cond, normalise: int = 0):
+        cond = self._f32(cond)
+        B, Cc, F = cond.shape
+        f = int(np.prod(self.unet.upsampling_ratios))
+        img = self._empty(B, Cc, F * f)
+        s = self._enter()
+        L.check(self.lib.ldc_cond_upsample(self._ctx, cond.data_ptr(), B, F, normalise, img.data_ptr(), s))
+        self._exit()
+        return img
+
+    def unet_forward(self, x, t: int, cond):
+        x, cond = self._f32(x), self._f32(cond)
+        B, Cx, Lx = x.shape
+        eps = self._empty(B, Cx, Lx)
+        s = self._enter()
+        L.check(self.lib.ldc_unet_forward(self._ctx, x.data_ptr(), int(t), cond.data_ptr(), B, Lx, cond.shape[2],
+                                          eps.data_ptr(), s))
+        self._exit()
+        return eps
+
+    def debug_tap(self, name: str, shape):
+        out = self._empty(*shape)
+        s = self._enter()
+        L.check(self.lib.ldc_unet_debug_tap(self._ctx, name.encode(), out.data_ptr(), out.numel(), s))
+        self._exit()
+        return out
+
+    def p_sample(self, x, t: int, cond, noise=None):
+        x = self._f32(x).clone()
+        cond = self._f32(cond)
+        noise = self._f32(noise) if noise is not None else None
+        B, _, Lx = x.shape
+        s = self._enter()
+        L.check(self.lib.ldc_p_sample(self._ctx, x.data_ptr(), int(t), cond.data_ptr(),
+                                      noise.data_ptr() if noise is not None else None, B, Lx, cond.shape[2], s))
+        self._exit()
+        return x
+
+    def denoise(self, img, cond, n_steps: int, noise=None, inplace: bool = False):
+        img = self._f32(img)
+        if not inplace:
+            img = img.clone()
+        cond = self._f32(cond)
+        noise = self._f32(noise) if noise is not None else None
+        B, _, Lx = img.shape
+        s = self._enter()
+        L.check(self.lib.ldc_denoise(self._ctx, img.data_ptr(), cond.data_ptr(),
+                                     noise.data_ptr() if noise is not None else None, int(n_steps), B, Lx, cond.shape[2], s))
+        self._exit()
+        return img
+
+    def output_normalise(self, wav, per_item: bool = False):
+        wav = self._f32(wav).clone()
+        B = wav.shape[0]
+        s = self._enter()
+        L.check(self.lib.ldc_output_normalise(self._ctx, wav.data_ptr(), B, wav.numel() // B, int(per_item), s))
+        self._exit()
+        return wav
+
+    def decode(self, wav, n_steps: int, noise=None, per_item: bool = False, want_stages: bool = False):
+        """The per-batch body of synthesis() (sample.py:94-134) in one library call."""
+        wav = self._f32(wav)
+        B, _, T = wav.shape
+        F, Lz = T // self.cond_codec.hop_length, T // self.main_codec.hop_length
+        out = self._empty(B, 1, T)
+        lat = self._empty(B, self.main_codec.rep_dims, Lz) if want_stages else None
+        cond = self._empty(B, self.main_codec.rep_dims, F) if want_stages else None
+        n_q = self.cond_codec.n_q_for_bandwidth(None)
+        codes = self._empty(n_q, B, F, dtype=self.torch.int64) if want_stages else None
+        noise = self._f32(noise) if noise is not None else None
+        s = self._enter()
+        p = lambda t: t.data_ptr() if t is not None else None
+        L.check(self.lib.ldc_decode(self._ctx, wav.data_ptr(), B, T, int(n_steps), p(noise), int(per_item), out.data_ptr(),
+                                    p(lat), p(cond), p(codes), s))
+        self._exit()
+        if want_stages:
+            return {"wav": out, "latents": lat, "cond": cond, "codes": codes}
+        return out
+
+    # ---- accounting ------------------------------------------------------------------------------
+    def unet_step_cost(self, B: int, Lz: int):
+        fl, by = C.c_double(), C.c_double()
+        L.check(self.lib.ldc_unet_step_cost(self._ctx, B, Lz, C.byref(fl), C.byref(by)))
+        return fl.value, by.value
+
+    def profile(self, on: bool):
+        L.check(self.lib.ldc_profile_enable(self._ctx, int(on)))
+
+    def profile_read(self):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        L.check(self.lib.ldc_profile_read(self._ctx, C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
+    # ---- L1 primitives (parity tests) ------------------------------------------------------------
+    def sconv1d(self, x, w, b, stride=1, dilation=1, causal=True, pre_elu=False):
+        x = self._f32(x)
+        w = np.ascontiguousarray(w, np.float32); b = np.ascontiguousarray(b, np.float32)
+        B, Cin, Lx = x.shape
+        Cout, _, k = w.shape
+        Lout = -(-Lx // stride)
+        y = self._empty(B, Cout, Lout)
+        s = self._enter()
+        L.check(self.lib.ldc_sconv1d(self._ctx, x.data_ptr(), B, Cin, Lx, w.ctypes.data_as(C.c_void_p),
+                                     b.ctypes.data_as(C.c_void_p), Cout, k, stride, dilation, int(causal), int(pre_elu),
+                                     y.data_ptr(), s))
+        self._exit()
+        return y
+
+    def sconvtr1d(self, x, w, b, stride, causal):
+        x = self._f32(x)
+        w = np.ascontiguousarray(w, np.float32); b = np.ascontiguousarray(b, np.float32)
+        B, Cin, Lx = x.shape
+        _, Cout, k = w.shape
+        y = self._empty(B, Cout, Lx * stride)
+        s = self._enter()
+        L.check(self.lib.ldc_sconvtr1d(self._ctx, x.data_ptr(), B, Cin, Lx, w.ctypes.data_as(C.c_void_p),
+                                       b.ctypes.data_as(C.c_void_p), Cout, k, stride, int(causal), y.data_ptr(), s))
+        self._exit()
+        return y
+
+    def slstm(self, x, weights: Sequence[np.ndarray], layers: int):
+        x = self._f32(x)
+        B, H, T = x.shape
+        ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+        arr = (C.c_void_p * len(ws))(*[w.ctypes.data_as(C.c_void_p) for w in ws])
+        y = self._empty(B, H, T)
+        s = self._enter()
+        L.check(self.lib.ldc_slstm(self._ctx, x.data_ptr(), B, H, T, arr, layers, y.data_ptr(), s))
+        self._exit()
+        return y
+
+
+# --------------------------------------------------------------------------------------------------
+# reference-shaped facade
+# --------------------------------------------------------------------------------------------------
+class _Upsampler:
+    """Stands for `diff_model.upsampling_layers`: iterating yields one callable that applies the WHOLE
+    stack (the reference applies them in sequence, sample.py:127-128), so `for layer in
+    model.diff_model.upsampling_layers: img = layer(img)` gives the same tensor."""
+
+    def __init__(self, eng: Engine):
+        self._eng = eng
+
+    def __iter__(self):
+        yield lambda img: self._eng.cond_upsample(img, 0)
+
+    def __len__(self):
+        return 1
+
+
+class _DiffModel:
+    def __init__(self, eng: Engine):
+        self._eng = eng
+        self.upsampling_layers = _Upsampler(eng)
+        self.channels = eng.unet.inp_channels
+        self.self_condition = False
+
+    def __call__(self, x, time, x_cond=None):
+        t = int(time.reshape(-1)[0].item()) if hasattr(time, "reshape") else int(time)
+        if hasattr(time, "reshape") and bool((time != t).any()):
+            raise ValueError("per-item timesteps are not supported (the sampler never uses them)")
+        return self._eng.unet_forward(x, t, x_cond)
+
+
+class _Diffusion:
+    def __init__(self, eng: Engine):
+        self._eng = eng
+        self.seq_length = None
+        self.num_timesteps = eng.unet.timesteps
+
+    def p_sample(self, x, t: int, condition=None, noise=None):
+        return self._eng.p_sample(x, t, condition, noise), None
+
+    def halfway_sampling(self, img=None, t=None, condition=None, noise=None):
+        if tuple(img.shape) == tuple(condition.shape):       # ddpm_loss.py:376-378
+            img = self._eng.cond_upsample(img, 0)
+        return self._eng.denoise(img, condition, int(t), noise)
+
+
+class DiffAudioRep:
+    """Facade with the reference's attribute names over one side (main or cond) of an Engine."""
+
+    def __init__(self, eng: Engine, which: int):
+        self._eng, self._which = eng, which
+        cfg = eng.cond_codec if which == L.MODEL_COND else eng.main_codec
+        self.frame_rate = cfg.frame_rate
+        self.bandwidth = cfg.bandwidth
+        self.quantization = cfg.quantization
+        if which == L.MODEL_MAIN:
+            self.diff_model = _DiffModel(eng)
+            self.diffusion = _Diffusion(eng)
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def encoder(self, wav):
+        return self._eng.encode(self._which, wav)
+
+    def decoder(self, z):
+        return self._eng.decode_latents(self._which, z)
+
+    def quantizer(self, x, sample_rate=None, bandwidth=None, n_q=None):
+        cfg = self._eng.cond_codec
+        n = n_q if n_q is not None else cfg.n_q_for_bandwidth(bandwidth)
+        q, codes = self._eng.rvq(x, n)
+        torch = self._eng.torch
+        bw = torch.tensor(n * 0.5).to(q)
+        return QuantizedResult(q, codes, bw, penalty=torch.zeros((), device=q.device))
+
+    def get_cond(self, x):
+        if self._which != L.MODEL_COND:
+            return self.encoder(x)
+        return self._eng.get_cond(x)
