@@ -1,0 +1,151 @@
+"""Throughput bench of the LaDiffCodec decode path on MI355X.
+
+metric  : audio-seconds decoded per wall-second (BASELINE.json), 16 kHz, 3 kbps condition, 50-step DDPM
+workload: BASELINE.json configs[1] ("C2" in SURVEY.md section 8): LaDiffCodec diff_dims=256, enc_ratios 8 4,
+          batch = 32 x 2.4 s utterances per GPU, bf16 UNet on MFMA (codec stages exact fp32).
+step    : one pass of the whole hot path over one resident batch: cond encode -> RVQ -> upsample ->
+          N denoise steps (hipGraph replay) -> SEANet decode -> normalise  (ldc_decode).
+N > 1   : one process per GPU (torch.distributed.run), every rank decodes its own batch of
+          independent utterances (weak scaling, no data-path collective); RCCL only broadcasts the
+          checkpoint once and gathers the decoded waveforms at the end of every step.
+
+Prints ONE JSON line on rank 0.  Synthetic seeded weights and audio (no network for checkpoints/datasets).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from ladiffcodec_amd import lib as L, parallel, spec, synth  # noqa: E402
+from ladiffcodec_amd.spec import CodecConfig, UnetConfig  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(cc, mc, u, sd_cond, sd_main, n_steps, seconds, batch):
+    """The CPU oracle (a port of the reference's arithmetic, oracle/ldc_oracle.py) timed on this host."""
+    from oracle import ldc_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    T = int(seconds * 16000) // 640 * 640
+    wav = torch.from_numpy(synth.synthetic_wav(batch, T, seed=1234))
+    noise = torch.randn(n_steps, batch, 128, T // mc.hop_length, generator=torch.Generator().manual_seed(4321))
+    a, b = synth.to_torch(sd_cond), synth.to_torch(sd_main)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.decode_utterances(a, cc, b, mc, u, wav, n_steps, noise, per_item=True)
+    dt = time.perf_counter() - t0
+    return {"value": batch * T / 16000.0 / dt, "unit": "audio-s/wall-s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{batch} x {T / 16000.0:.1f} s utterance(s), {n_steps} DDPM steps, fp32, {dt:.1f} s of CPU time"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=2.4)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--diff-dims", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=1)
+    args = ap.parse_args()
+
+    rank, local_rank, world = parallel.init_process_group("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0)
+    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    u = UnetConfig(dim=args.diff_dims, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    T = int(args.seconds * 16000) // 640 * 640
+    N = args.denoise_steps
+
+    # ---- weights: rank 0 builds the synthetic checkpoints, RCCL broadcasts them (one flat buffer each) ----
+    main_layout = spec.codec_keys(mc) + spec.unet_keys(u, "diff_model") + [(f"diffusion.{b}", (u.timesteps,)) for b in spec.SCHEDULE_BUFFERS]
+    cond_layout = spec.codec_keys(cc)
+    sd_main = sd_cond = None
+    if rank == 0:
+        full = synth.ladiff_state_dict(mc, u, seed=1)
+        sd_main = {k: full[k] for k, _ in main_layout}      # the diffusion.model.* aliases are skipped (same tensors)
+        sd_cond = synth.codec_state_dict(cc, seed=0)
+    sd_main = parallel.broadcast_state_dict(sd_main, main_layout, device=dev)
+    sd_cond = parallel.broadcast_state_dict(sd_cond, cond_layout, device=dev)
+
+    from ladiffcodec_amd.model import Engine
+    eng = Engine(mc, u, cc, dtype=args.dtype, device=local_rank, noise_seed=4321 + rank)
+    eng.load_state_dict(L.MODEL_MAIN, sd_main)
+    eng.load_state_dict(L.MODEL_COND, sd_cond)
+    eng.finalize(strict=True)
+
+    B = args.batch
+    wav = torch.from_numpy(synth.synthetic_wav(B, T, seed=1234 + rank)).to(dev)   # resident in HBM before timing
+
+    def step():
+        out = eng.decode(wav, N, noise=None, per_item=True)
+        if world > 1:
+            parallel.gather_results(out, world)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+    assert bool(torch.isfinite(out).all()), "non-finite output"
+
+    audio_s = world * B * (T / 16000.0) * args.steps
+    result = {
+        "metric": "audio-sec decoded / wall-sec, 16kHz 3kbps 50-step DDPM",
+        "value": audio_s / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio)",
+        "config": {"workload": f"LaDiffCodec 3 kbps, diff_dims={args.diff_dims}, enc_ratios 8 4, {N}-step DDPM, "
+                               f"batch={B}x{T / 16000.0:.1f} s utterances per GPU", "global_batch": world * B,
+                   "latent_len": T // mc.hop_length, "denoise_steps": N, "parallelism": f"dp{world} (utterance-sharded, no data-path collective)"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel = the conv-GEMM family: per-launch hipEvents on the launch stream over one full
+        # eager decode of the same batch (profiling pass, separate from the timed region above)
+        eng.profile(True)
+        eng.decode(wav, N, noise=None, per_item=True)
+        ms, launches, flops = eng.profile_read()
+        eng.profile(False)
+        step_flops, step_bytes = eng.unet_step_cost(B, T // mc.hop_length)
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        result["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM Conv1d on MFMA)", "achieved": ach,
+                              "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                              "launches": launches, "avg_launch_us": 1000.0 * ms / max(1, launches),
+                              "unet_step_gflop": step_flops / 1e9, "unet_step_algorithmic_gb": step_bytes / 1e9}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cc, mc, u, sd_cond, sd_main, N, args.seconds, args.cpu_batch)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    eng.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

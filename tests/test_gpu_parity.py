@@ -1,0 +1,230 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against (a) the golden vectors
+made by running the reference (tests/golden/) and (b) the CPU oracle on fresh seeded inputs.
+
+Tolerances (relative to the max |reference|):
+  f32 engine (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32)    2e-4 per stage, 1e-3 after a chain
+  bf16 engine (bf16 storage + MFMA, fp32 accumulate/state)  6e-2 per UNet call, 0.2 after a chain
+  RVQ codes: bit-exact wherever the oracle's top-2 margin exceeds 1e-3 (all codec stages run fp32
+  in both engines precisely so that the codes do not depend on the UNet dtype).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ladiffcodec_amd import lib as L, synth  # noqa: E402
+from oracle import ldc_oracle as O  # noqa: E402
+from helpers import CASES, COND_CFG, T, cond_sd_np, load_golden, main_sd_np  # noqa: E402
+from gpu_common import engine, rel  # noqa: E402
+
+F32_TOL, BF16_TOL = 2e-4, 6e-2
+
+
+def cu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def tol_for(dtype, chain=False):
+    base = F32_TOL if dtype == "f32" else BF16_TOL
+    return base * (5 if chain else 1) if dtype == "f32" else (0.2 if chain else base)
+
+
+# ------------------------------------------------------------------------------------------- L1 primitives
+def test_sconv1d_against_reference_vectors():
+    g = load_golden("primitives")
+    e = engine("r84", "f32")
+    names = sorted({k.split(".")[0] for k in g if k.startswith("c_")})
+    ran = 0
+    for n in names:
+        k, s, d, causal = (int(v) for v in g[n + ".cfg"])
+        w = O.fold_weight_norm(T(g[n + ".g"]), T(g[n + ".v"])).numpy()
+        if g[n + ".x"].shape[-1] <= (k - 1) * d:
+            with pytest.raises(L.LdcError):      # inputs shorter than the reflect pad: refused loudly
+                e.sconv1d(cu(g[n + ".x"]), w, g[n + ".b"], stride=s, dilation=d, causal=bool(causal))
+            continue
+        y = e.sconv1d(cu(g[n + ".x"]), w, g[n + ".b"], stride=s, dilation=d, causal=bool(causal))
+        assert y.shape == g[n + ".y"].shape
+        assert rel(y.cpu().numpy(), g[n + ".y"]) < 1e-5, n
+        ran += 1
+    assert ran == 6
+
+
+def test_sconvtranspose1d_against_reference_vectors():
+    g = load_golden("primitives")
+    e = engine("r84", "f32")
+    for n in sorted({k.split(".")[0] for k in g if k.startswith("t_")}):
+        k, s, d, causal = (int(v) for v in g[n + ".cfg"])
+        w = O.fold_weight_norm(T(g[n + ".g"]), T(g[n + ".v"])).numpy() if (n + ".g") in g else g[n + ".w"]
+        y = e.sconvtr1d(cu(g[n + ".x"]), w, g[n + ".b"], s, bool(causal))
+        assert rel(y.cpu().numpy(), g[n + ".y"]) < 1e-5, n
+
+
+@pytest.mark.parametrize("H,Tn", [(16, 11), (64, 300), (128, 160), (512, 24)])
+def test_slstm_all_kernel_variants(H, Tn):
+    """H=64/128 take the register-resident kernel, others the L2-streaming one (seanet.hip)."""
+    g = torch.Generator().manual_seed(H)
+    b = 1.0 / np.sqrt(H)
+    ws, sd = [], {}
+    for layer in range(2):
+        for nm, shape in (("weight_ih_l", (4 * H, H)), ("weight_hh_l", (4 * H, H)), ("bias_ih_l", (4 * H,)), ("bias_hh_l", (4 * H,))):
+            w = (torch.rand(*shape, generator=g) * 2 - 1) * b
+            ws.append(w.numpy()); sd[f"p.lstm.{nm}{layer}"] = w
+    x = torch.randn(3, H, Tn, generator=g)
+    ref = O.lstm_skip(x, sd, "p", 2)
+    y = engine("r84", "f32").slstm(x.cuda(), ws, 2)
+    assert rel(y.cpu().numpy(), ref.numpy()) < 2e-5
+    if H == 16:
+        gold = load_golden("primitives")
+        gw = [gold[f"lstm.sd.lstm.{nm}{layer}"] for layer in range(2) for nm in ("weight_ih_l", "weight_hh_l", "bias_ih_l", "bias_hh_l")]
+        y = engine("r84", "f32").slstm(cu(gold["lstm.x"]), gw, 2)
+        assert rel(y.cpu().numpy(), gold["lstm.y"]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- codec (config C1)
+def test_codec_encode_rvq_decode_golden():
+    g = load_golden("codec_c1")
+    e = engine("r84", "f32")
+    wav = cu(g["wav"])
+    assert rel(e.encode(L.MODEL_COND, wav).cpu().numpy(), g["z"]) < 1e-4
+    _, _, margins = O.rvq_forward(synth.to_torch(cond_sd_np()), T(g["z"]), 6)
+    safe = margins.numpy() > 1e-3
+    q, codes = e.rvq(cu(g["z"]), 6)
+    assert codes.dtype == torch.int64 and tuple(codes.shape) == g["codes"].shape
+    assert np.array_equal(codes.cpu().numpy()[safe], g["codes"][safe])
+    assert np.array_equal(codes.cpu().numpy(), g["codes"])          # and in fact everywhere on this fixture
+    assert rel(q.cpu().numpy(), g["quantized"]) < 1e-6
+    cond, codes2 = e.get_cond(wav, return_codes=True)
+    assert np.array_equal(codes2.cpu().numpy()[safe], g["codes"][safe])
+    cond15, codes15 = e.get_cond(wav, bandwidth=1.5, return_codes=True)
+    assert codes15.shape[0] == 3 and np.array_equal(codes15.cpu().numpy(), g["codes_1p5"])
+    assert rel(cond15.cpu().numpy(), g["quantized_1p5"]) < 1e-4
+    assert rel(e.decode_latents(L.MODEL_COND, cu(g["quantized"])).cpu().numpy(), g["decoded"]) < 1e-4
+    assert rel(e.rvq_decode(cu(g["codes"])).cpu().numpy(), g["quantized"]) < 1e-6
+
+
+def test_rvq_ties_take_first_index():
+    """Duplicate code vectors: the reference's argmax returns the first maximum (core_vq.py:181)."""
+    e = engine("r84", "f32")
+    sd = synth.to_torch(cond_sd_np())
+    emb = sd["quantizer.vq.layers.0._codebook.embed"]
+    z = emb[[5, 900, 17]].t().reshape(1, 128, 3).contiguous()       # exactly on code vectors
+    _, codes = e.rvq(z.cuda(), 1)
+    assert codes.cpu().numpy().reshape(-1).tolist() == [5, 900, 17]
+
+
+# ------------------------------------------------------------------------------------------- UNet / diffusion
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["r84", "r8"])
+def test_unet_forward_and_taps(tag, dtype):
+    g = load_golden("ladiff_" + tag)
+    mc, u, _ = CASES[tag]
+    e = engine(tag, dtype)
+    tol = tol_for(dtype)
+    cond, x = cu(g["cond"]), cu(g["x"])
+    for t in (0, 37):
+        assert rel(e.unet_forward(x, t, cond).cpu().numpy(), g[f"eps_t{t}"]) < tol, t
+    taps = {}
+    O.unet_forward(synth.to_torch(main_sd_np(tag)), u, T(g["x"]), torch.full((2,), 37, dtype=torch.long), T(g["cond"]), taps=taps)
+    for name in ["cond_proc", "init", "down0", "down4", "mid", "up0", "up4"]:
+        assert rel(e.debug_tap(name, taps[name].shape).cpu().numpy(), taps[name].numpy()) < tol, name
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["r84", "r8"])
+def test_sampler_chain_and_stage_tensors(tag, dtype):
+    g = load_golden("ladiff_" + tag)
+    mc, u, _ = CASES[tag]
+    e = engine(tag, dtype)
+    cond, x = cu(g["cond"]), cu(g["x"])
+    n = int(g["meta"][2])
+    noises = cu(g["noises"])
+    assert rel(e.cond_upsample(cond, 0).cpu().numpy(), g["img_up"]) < 1e-5
+    assert rel(e.cond_upsample(cond, 1).cpu().numpy(), g["img0"]) < 1e-5
+    assert rel(e.p_sample(x, 5, cond, noises[n - 1]).cpu().numpy(), g["p_sample_t5"]) < tol_for(dtype)
+    lat = e.denoise(cu(g["img0"]), cond, n, noises)                   # first call: eager step + graph capture
+    assert rel(lat.cpu().numpy(), g["latents"]) < tol_for(dtype, chain=True)
+    lat2 = e.denoise(cu(g["img0"]), cond, n, noises)                  # second call: may re-capture (new x buffer)
+    assert rel(lat2.cpu().numpy(), lat.cpu().numpy()) < (1e-6 if dtype == "f32" else 2e-2)
+    assert rel(e.decode_latents(L.MODEL_MAIN, cu(g["latents"])).cpu().numpy(), g["wav_raw"]) < 1e-4
+    assert rel(e.output_normalise(cu(g["wav_raw"])).cpu().numpy(), g["wav_out"]) < 1e-5
+    out = e.decode(cu(g["wav"]), n, noises, per_item=False, want_stages=True)
+    assert rel(out["cond"].cpu().numpy(), g["cond"]) < 1e-4
+    assert rel(out["latents"].cpu().numpy(), g["latents"]) < tol_for(dtype, chain=True)
+    assert rel(out["wav"].cpu().numpy(), g["wav_out"]) < (5e-3 if dtype == "f32" else 0.5)
+
+
+def test_graph_replay_equals_eager_many_steps():
+    """hipGraph replay (n>=3) vs per-step eager calls through ldc_p_sample, same injected noise."""
+    tag = "r84"
+    g = load_golden("ladiff_" + tag)
+    e = engine(tag, "f32")
+    cond = cu(g["cond"])
+    n = 9
+    noises = torch.randn(n, *g["x"].shape, generator=torch.Generator().manual_seed(3)).cuda()
+    x = cu(g["img0"]).clone()
+    ref = x.clone()
+    for j, t in enumerate(reversed(range(n))):
+        ref = e.p_sample(ref, t, cond, noises[j])
+    got = e.denoise(x, cond, n, noises)
+    assert rel(got.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
+def test_philox_noise_is_standard_normal_and_seeded():
+    tag = "r84"
+    g = load_golden("ladiff_" + tag)
+    e = engine(tag, "f32")
+    cond = cu(g["cond"])
+    x0 = cu(g["img0"])
+    a = e.denoise(x0, cond, 6, None)
+    b = e.denoise(x0, cond, 6, None)
+    assert torch.equal(a, b)                       # same seed, same step indices -> same draws
+    assert torch.isfinite(a).all()
+    # one step from zeros with eps-independent part removed: x_new - mean = sigma * z
+    x = torch.zeros_like(x0)
+    y1 = e.p_sample(x, 500, cond, None)
+    y0 = e.p_sample(x, 500, cond, torch.zeros_like(x))
+    sched = synth.cosine_schedule_buffers(1000)
+    z = ((y1 - y0) / float(np.exp(0.5 * sched["posterior_log_variance_clipped"][500]))).cpu().numpy().ravel()
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    assert abs(((z ** 4).mean()) - 3.0) < 0.15
+
+
+# ------------------------------------------------------------------------------------------- full-size properties (BASELINE configs[1] shapes)
+def test_full_size_items_are_independent():
+    """C2 shapes at reduced width: decoding a batch equals decoding each utterance alone (per-item
+    normalisation) -- the property the data-parallel sharding relies on."""
+    tag = "r84"
+    mc, u, _ = CASES[tag]
+    e = engine(tag, "f32")
+    Tn = 38400
+    wav = torch.from_numpy(synth.synthetic_wav(3, Tn, seed=9)).cuda()
+    n = 3
+    noise = torch.randn(n, 3, 128, Tn // mc.hop_length, generator=torch.Generator().manual_seed(1)).cuda()
+    full = e.decode(wav, n, noise, per_item=True, want_stages=True)
+    for i in range(3):
+        one = e.decode(wav[i:i + 1], n, noise[:, i:i + 1].contiguous(), per_item=True, want_stages=True)
+        assert torch.equal(one["codes"], full["codes"][:, i:i + 1])
+        assert rel(one["latents"].cpu().numpy(), full["latents"][i:i + 1].cpu().numpy()) < 1e-5
+        assert rel(one["wav"].cpu().numpy(), full["wav"][i:i + 1].cpu().numpy()) < 1e-4
+    w = full["wav"].cpu().numpy()
+    assert np.allclose(np.abs(w).reshape(3, -1).max(1), 1.0, atol=1e-5)      # sample.py:134 leaves max|x| = 1
+
+
+def test_error_behaviour():
+    e = engine("r84", "f32")
+    g = load_golden("ladiff_r84")
+    with pytest.raises(L.LdcError):                      # L != F * prod(upsampling_ratios)
+        e.unet_forward(cu(g["x"])[:, :, :150].contiguous(), 3, cu(g["cond"]))
+    with pytest.raises(L.LdcError):                      # t outside the 1000-step schedule
+        e.unet_forward(cu(g["x"]), 1000, cu(g["cond"]))
+    from ladiffcodec_amd.model import Engine
+    mc, u, _ = CASES["r84"]
+    bad = Engine(mc, u, COND_CFG, dtype="f32")
+    sd = main_sd_np("r84")
+    sd.pop("diff_model.final_conv.bias"); sd.pop("diffusion.model.final_conv.bias")
+    bad.load_state_dict(L.MODEL_MAIN, sd)
+    bad.load_state_dict(L.MODEL_COND, cond_sd_np())
+    with pytest.raises(L.LdcError, match="final_conv.bias"):   # strict load names the missing key
+        bad.finalize(strict=True)
+    bad.close()
