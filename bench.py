@@ -29,20 +29,59 @@ from ladiffcodec_amd.spec import CodecConfig, UnetConfig  # noqa: E402
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(cc, mc, u, sd_cond, sd_main, n_steps, seconds, batch):
-    """The CPU oracle (a port of the reference's arithmetic, oracle/ldc_oracle.py) timed on this host."""
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    # cgroup CPU quota (containers): honour it, an oversubscribed OpenMP pool is pathologically slow
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(int(q[0]) / int(q[1]))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(cc, mc, u, sd_cond, sd_main, n_steps, seconds, batch, budget_s=20.0):
+    """The CPU oracle (a port of the reference's arithmetic, oracle/ldc_oracle.py) timed on this host, on a
+    bounded sample: front end (encode, RVQ, upsample) and decoder in full, as many of the N DDPM steps as
+    fit in ~budget_s (at least 2), the rest extrapolated from the measured per-step mean."""
     from oracle import ldc_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = host_threads()
+    torch.set_num_threads(cores)
     T = int(seconds * 16000) // 640 * 640
     wav = torch.from_numpy(synth.synthetic_wav(batch, T, seed=1234))
-    noise = torch.randn(n_steps, batch, 128, T // mc.hop_length, generator=torch.Generator().manual_seed(4321))
     a, b = synth.to_torch(sd_cond), synth.to_torch(sd_main)
-    t0 = time.perf_counter()
+    g = torch.Generator().manual_seed(4321)
     with torch.no_grad():
-        O.decode_utterances(a, cc, b, mc, u, wav, n_steps, noise, per_item=True)
-    dt = time.perf_counter() - t0
-    return {"value": batch * T / 16000.0 / dt, "unit": "audio-s/wall-s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{batch} x {T / 16000.0:.1f} s utterance(s), {n_steps} DDPM steps, fp32, {dt:.1f} s of CPU time"}
+        t0 = time.perf_counter()
+        cond, _, _, _ = O.get_cond(a, cc, wav)
+        img = O.start_image(b, u, cond, per_item=True)
+        t_front = time.perf_counter() - t0
+        step_times = []
+        t = n_steps - 1
+        while t >= 0 and (len(step_times) < 2 or sum(step_times) + step_times[-1] < budget_s):
+            noise = torch.randn(img.shape, generator=g)
+            t1 = time.perf_counter()
+            img = O.p_sample(b, u, img, t, cond, noise)
+            step_times.append(time.perf_counter() - t1)
+            t -= 1
+        t2 = time.perf_counter()
+        O.output_normalise(O.seanet_decode(b, mc, img), per_item=True)
+        t_back = time.perf_counter() - t2
+    timed = len(step_times)
+    per_step = sum(step_times[1:]) / max(1, timed - 1) if timed > 1 else step_times[0]
+    total = t_front + t_back + per_step * n_steps
+    return {"value": batch * T / 16000.0 / total, "unit": "audio-s/wall-s", "cores": cores, "kind": "port",
+            "sample": f"{batch} x {T / 16000.0:.1f} s utterance(s), fp32 oracle: front/back ends in full "
+                      f"({t_front + t_back:.2f} s), {timed} of {n_steps} DDPM steps timed ({per_step:.3f} s/step), "
+                      f"rest extrapolated"}
 
 
 def main():
@@ -84,11 +123,13 @@ def main():
     sd_main = parallel.broadcast_state_dict(sd_main, main_layout, device=dev)
     sd_cond = parallel.broadcast_state_dict(sd_cond, cond_layout, device=dev)
 
+    log(f"rank {rank}/{world}: checkpoints ready ({len(sd_main)} + {len(sd_cond)} tensors)")
     from ladiffcodec_amd.model import Engine
     eng = Engine(mc, u, cc, dtype=args.dtype, device=local_rank, noise_seed=4321 + rank)
     eng.load_state_dict(L.MODEL_MAIN, sd_main)
     eng.load_state_dict(L.MODEL_COND, sd_cond)
     eng.finalize(strict=True)
+    log("weights folded/packed/uploaded")
 
     B = args.batch
     wav = torch.from_numpy(synth.synthetic_wav(B, T, seed=1234 + rank)).to(dev)   # resident in HBM before timing
@@ -99,8 +140,10 @@ def main():
             parallel.gather_results(out, world)
         return out
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize(dev)
+        log(f"warmup {i} done")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
@@ -112,6 +155,7 @@ def main():
         torch.distributed.barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
     assert bool(torch.isfinite(out).all()), "non-finite output"
+    log(f"timed region: {elapsed:.3f} s for {args.steps} step(s)")
 
     audio_s = world * B * (T / 16000.0) * args.steps
     result = {
@@ -131,6 +175,7 @@ def main():
         eng.decode(wav, N, noise=None, per_item=True)
         ms, launches, flops = eng.profile_read()
         eng.profile(False)
+        log(f"profile pass: {launches} conv launches, {ms:.1f} ms")
         step_flops, step_bytes = eng.unet_step_cost(B, T // mc.hop_length)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
