@@ -22,6 +22,7 @@
 //   is irrelevant; only the C/D layout (col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)) matters.
 #include "ldc_kernels.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -294,6 +295,224 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
   }
 }
 
+// bias (+ residual) (+ activation) and store of a wave's TM x TN accumulators (plain conv, row-major [M][n])
+template <typename T, int TM, int TN, bool RES, bool ACT>
+__device__ __forceinline__ void epilogue_plain(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + j * 32;
+    const bool col_ok = col < a.n;
+    const float bv = (a.bias && col_ok) ? a.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = mrow0 + i * 32;
+      float rv[16];
+      if (RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          rv[r] = (col_ok && m < M) ? load_in<T>(a.residual, (size_t)m * a.n + col) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] + bv;
+        if (RES) v += rv[r];
+        if (ACT) v = act_apply(v, a.post_act);
+        if (col_ok && m < M) store_out<T>(a.y, (size_t)m * a.y_ld + col, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2 fast path: same tiling, but the HBM/L2 -> LDS copies are LDS-DMA (`global_load_lds_dwordx4`,
+// no VGPR round trip) into a 2-stage LDS ring, issued one pipeline unit ahead of the MFMAs that
+// consume them, so the copy of unit u+1 overlaps the matrix work of unit u.  LDS-DMA writes
+// lane-linear (wave base + lane*16 B), so rows cannot be padded; bank conflicts are avoided with an
+// XOR swizzle of the 16-byte slot index, slot' = slot ^ ((row >> 2) & 3), applied on the per-lane
+// SOURCE address and again on the ds_read address (rows distinct mod 16 -> 16 distinct bank slots).
+// Eligible: zero padding, no prologue activation, plain (non-transposed) conv -- every UNet conv.
+// ------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// one 16-byte-per-lane LDS-DMA: lane l's 16 bytes at `gsrc` land at LDS byte address lds_addr + 16*l.
+// M0 carries the (wave-uniform) LDS address; it is saved/restored around the instruction because hipcc
+// does not model M0 inside an asm statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
+struct ConvV2Geom {
+  int a_rows;       // LDS rows reserved for the input window (multiple of 16 * waves); zero row follows
+  int b_rows;       // LDS rows of the weight slab per unit (multiple of 16 * waves)
+  int stage_bytes;
+  int ngroups;      // tap groups per channel chunk
+};
+
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gemm_v2_kernel(const ConvKArgs a, const ConvV2Geom gm) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN;
+  constexpr int BKE = kRowBytes / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int M = a.B * a.L_rows;
+  const int total_in_rows = a.B * a.L_in;
+  const int leff = a.L_in << a.ups;
+
+  int R_lo, R_hi;
+  {
+    const int m_last = min(m0 + BM, M) - 1;
+    int b = m0 / a.L_rows, l = m0 - b * a.L_rows;
+    int u = l * a.stride - a.pad_left;
+    u = max(0, min(u, leff - 1));
+    R_lo = b * a.L_in + (u >> a.ups);
+    b = m_last / a.L_rows;
+    l = m_last - b * a.L_rows;
+    u = l * a.stride + (a.taps - 1) * a.dil - a.pad_left;
+    u = max(0, min(u, leff - 1));
+    R_hi = min(b * a.L_in + (u >> a.ups), total_in_rows - 1);
+  }
+  const int nrows = min(R_hi - R_lo + 1, gm.a_rows);
+  const int zero_row = gm.a_rows;
+  if (tid < 32) {
+    reinterpret_cast<unsigned*>(smem + (size_t)zero_row * kRowBytes)[tid & 15] = 0u;
+    reinterpret_cast<unsigned*>(smem + gm.stage_bytes + (size_t)zero_row * kRowBytes)[tid & 15] = 0u;
+  }
+
+  int row_b[TM], row_l[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + (wm * TM + i) * 32 + (lane & 31);
+    if (m < M) {
+      row_b[i] = m / a.L_rows;
+      row_l[i] = m - row_b[i] * a.L_rows;
+    } else {
+      row_b[i] = -1;
+      row_l[i] = 0;
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nchunks = (a.C1 + a.C2) / BKE;
+  const int nunits = nchunks * gm.ngroups;
+  const int nA = gm.a_rows / (16 * NW), nB = gm.b_rows / (16 * NW);
+  const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+
+  auto load_unit = [&](int u, int st) {
+    const int c = u / gm.ngroups, g = u - c * gm.ngroups;
+    const char* src;
+    int ld, coff;
+    if (c * BKE < a.C1) {
+      src = a.x1; ld = a.C1; coff = c * BKE;
+    } else {
+      src = a.x2; ld = a.C2; coff = c * BKE - a.C1;
+    }
+    // input window: LDS slot p = row*4 + slot'
+    for (int i = 0; i < nA; ++i) {
+      const int pbase = (i * NW + wave) * 64;
+      const int p = pbase + lane;
+      int r = p >> 2;
+      const int s = (p & 3) ^ ((r >> 2) & 3);
+      if (r >= nrows) r = 0;
+      const char* g_addr = src + ((size_t)(R_lo + r) * ld + coff) * sizeof(T) + s * 16;
+      lds_dma16(g_addr, lds_base + (unsigned)(st * gm.stage_bytes + pbase * 16));
+    }
+    // weight slab of tap group g
+    const int tg0 = g * a.tg;
+    const int ntg = min(a.tg, a.taps - tg0);
+    const char* wsrc = a.w + ((size_t)(c * a.taps + tg0) * a.n_pad + n0) * kRowBytes;
+    for (int i = 0; i < nB; ++i) {
+      const int pbase = (i * NW + wave) * 64;
+      const int p = pbase + lane;
+      const int rb = p >> 2;
+      const int s = (p & 3) ^ ((rb >> 2) & 3);
+      int t = rb / BN;
+      const int j = rb - t * BN;
+      if (t >= ntg) t = 0;
+      const char* g_addr = wsrc + ((size_t)t * a.n_pad + j) * kRowBytes + s * 16;
+      lds_dma16(g_addr, lds_base + (unsigned)(st * gm.stage_bytes + (gm.a_rows + 2) * kRowBytes + pbase * 16));
+    }
+  };
+
+  load_unit(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int kh = lane >> 5;
+  for (int u = 0; u < nunits; ++u) {
+    const int st = u & 1;
+    if (u + 1 < nunits) load_unit(u + 1, st ^ 1);
+    const int g = u % gm.ngroups;
+    const int tg0 = g * a.tg;
+    const int ntg = min(a.tg, a.taps - tg0);
+    const char* sA = smem + (size_t)st * gm.stage_bytes;
+    const char* sB = sA + (size_t)(gm.a_rows + 2) * kRowBytes;
+    for (int t = 0; t < ntg; ++t) {
+      const int toff = (tg0 + t) * a.dil;
+      int arow[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int row = zero_row;
+        if (row_b[i] >= 0) {
+          const int gr = gather_row(a, row_b[i], row_l[i], toff);
+          if (gr >= 0) row = gr - R_lo;
+        }
+        arow[i] = row;
+      }
+      const int brow0 = t * BN + wn * TN * 32 + (lane & 31);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 af[TM], bfr[TN];
+        const int slot = ks * 2 + kh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const uint4*>(sA + arow[i] * kRowBytes + ((slot ^ ((arow[i] >> 2) & 3)) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int rb = brow0 + j * 32;
+          bfr[j] = *reinterpret_cast<const uint4*>(sB + rb * kRowBytes + ((slot ^ ((rb >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mfma_step<T>(acc[i][j], af[i], bfr[j]);
+      }
+    }
+    // the LDS-DMA of unit u+1 was issued through inline asm (invisible to hipcc's waitcnt pass, which would
+    // otherwise drain it before the first ds_read above): wait for it here, then release stage st
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const int mrow0 = m0 + wm * TM * 32 + 4 * (lane >> 5);
+  const int col0 = n0 + wn * TN * 32 + (lane & 31);
+  if (a.residual) {
+    if (a.post_act == ACT_NONE) epilogue_plain<T, TM, TN, true, false>(a, acc, mrow0, col0, M);
+    else epilogue_plain<T, TM, TN, true, true>(a, acc, mrow0, col0, M);
+  } else {
+    if (a.post_act == ACT_NONE) epilogue_plain<T, TM, TN, false, false>(a, acc, mrow0, col0, M);
+    else epilogue_plain<T, TM, TN, false, true>(a, acc, mrow0, col0, M);
+  }
+}
+
 int conv_pick_bn(int n) {
   if (n % 128 == 0) return 128;
   if (n % 64 == 0) return 64;
@@ -367,6 +586,23 @@ static hipError_t launch_cfg(const ConvKArgs& a, int M, size_t lds, hipStream_t 
   return hipGetLastError();
 }
 
+template <typename T, int WM, int WN, int TM, int TN>
+static hipError_t launch_cfg_v2(const ConvKArgs& a, const ConvV2Geom& gm, int M, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  dim3 grid((M + BM - 1) / BM, a.n_pad / BN);
+  auto kern = conv_gemm_v2_kernel<T, WM, WN, TM, TN>;
+  static bool lds_opt_in = false;
+  if (!lds_opt_in) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    lds_opt_in = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), 2 * (size_t)gm.stage_bytes, s, a, gm);
+  return hipGetLastError();
+}
+
+static int g_conv_force_v1 = -1;
+
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   ConvKArgs a;
   a.x1 = (const char*)c.x1; a.x2 = (const char*)c.x2; a.w = (const char*)ly.w; a.bias = ly.bias;
@@ -395,6 +631,27 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   }
   a.win_rows = std::min(span, c.B * c.L_in) + 1;
   const int bn = ly.bn;
+  if (g_conv_force_v1 < 0) g_conv_force_v1 = getenv("LDC_CONV_V1") ? 1 : 0;
+  if (!g_conv_force_v1 && ly.pad_mode == PAD_ZERO && ly.pre_act == ACT_NONE && ly.tr_stride == 0) {
+    ConvV2Geom gm;
+    const int quantum = 16 * 4;   // rows per LDS-DMA sweep of the 4 waves
+    gm.a_rows = (span + quantum - 1) / quantum * quantum;
+    a.tg = std::max(1, std::min(ly.taps, (32 * 1024) / (bn * kRowBytes)));
+    gm.ngroups = (ly.taps + a.tg - 1) / a.tg;
+    gm.b_rows = (a.tg * bn + quantum - 1) / quantum * quantum;
+    gm.stage_bytes = (gm.a_rows + 2 + gm.b_rows) * kRowBytes;
+    if (2 * (size_t)gm.stage_bytes <= 160 * 1024) {
+      if (ly.dt == DT_F32) {
+        if (bn == 128) return launch_cfg_v2<float, 2, 2, 2, 2>(a, gm, M, s);
+        if (bn == 64) return launch_cfg_v2<float, 2, 2, 2, 1>(a, gm, M, s);
+        return launch_cfg_v2<float, 4, 1, 1, 1>(a, gm, M, s);
+      } else {
+        if (bn == 128) return launch_cfg_v2<__bf16, 2, 2, 2, 2>(a, gm, M, s);
+        if (bn == 64) return launch_cfg_v2<__bf16, 2, 2, 2, 1>(a, gm, M, s);
+        return launch_cfg_v2<__bf16, 4, 1, 1, 1>(a, gm, M, s);
+      }
+    }
+  }
   a.tg = std::max(1, std::min(ly.taps, (40 * 1024) / (bn * kPitch)));
   const size_t lds = (size_t)(a.win_rows + 1) * kPitch + (size_t)a.tg * bn * kPitch;
   if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -1,0 +1,32 @@
+"""Summarise a rocprofv3 rocpd database (the default output of `rocprofv3 --kernel-trace --stats`) as a
+per-kernel table: calls, total / average / min / max duration.  Usage: python tools/prof_summary.py DB [> profiles/x.md]"""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("ldc::", "")
+    name = re.sub(r"\(.*\)$", "", name)
+    return name[:90]
+
+
+def main(path):
+    con = sqlite3.connect(path)
+    rows = con.execute("select name, grid_x*1.0/workgroup_x, duration, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size from kernels").fetchall()
+    agg = {}
+    for name, blocks, dur, lds, v, a, s, scr in rows:
+        k = short(name)
+        e = agg.setdefault(k, [0, 0, 1 << 62, 0, lds, v, a, s, scr])
+        e[0] += 1; e[1] += dur; e[2] = min(e[2], dur); e[3] = max(e[3], dur)
+    total = sum(e[1] for e in agg.values())
+    print(f"| kernel | calls | total ms | % | avg us | min us | max us | VGPR | AGPR | SGPR | scratch |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    for k, e in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"| `{k}` | {e[0]} | {e[1] / 1e6:.2f} | {100 * e[1] / total:.1f} | {e[1] / e[0] / 1e3:.1f} | {e[2] / 1e3:.1f} | {e[3] / 1e3:.1f} | {e[5]} | {e[6]} | {e[7]} | {e[8]} |")
+    print(f"\ntotal kernel time: {total / 1e6:.2f} ms over {sum(e[0] for e in agg.values())} dispatches")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
