@@ -153,6 +153,10 @@ int ldc_unet_step_cost(ldc_ctx* ctx, int B, int L, double* flops, double* bytes)
 /* Timing of the dominant kernel class, measured with hipEvents on the launch stream when enabled.
  * ldc_profile_enable(ctx, 1) makes ldc_denoise bracket every conv-GEMM launch (eager, no graph). */
 int ldc_profile_enable(ldc_ctx* ctx, int on);
+/* Tuning aid: times `iters` launches of one conv-GEMM (random weights/inputs) of the given shape with
+ * hipEvents on the context's stream; dtype LDC_F32 | LDC_BF16; ups = 1 folds nearest x2 upsampling. */
+int ldc_conv_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups,
+                        int iters, double* ms_per_launch);
 int ldc_profile_read(ldc_ctx* ctx, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
 
 #ifdef __cplusplus

@@ -1,0 +1,160 @@
+// conv_device.h -- device-side pieces shared by the two conv-GEMM kernels (conv_gemm.hip: generic,
+// conv_fast.hip: LDS-DMA pipelined fast path).
+#pragma once
+#include "ldc_kernels.h"
+
+namespace ldc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int kRowBytes = 64;   // bytes of K (channels) per LDS row per chunk: 32 bf16 or 16 f32
+
+struct ConvKArgs {
+  const char* x1;
+  const char* x2;
+  const char* w;
+  const float* bias;
+  char* y;
+  const char* residual;
+  int C1, C2;          // channels of the two inputs
+  int n, n_pad;
+  int B, L_in, L_rows, L_final, y_ld;
+  int taps, stride, dil, pad_left, ups, pad_mode, pre_act, post_act;
+  int tr_stride, tr_cout, tr_trim_left;
+  int win_rows;        // generic kernel: LDS window capacity (rows); the zero row lives at index win_rows
+  int tg;              // taps staged per weight slab
+  int reflect_back, reflect_fwd;
+};
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                                  // round to nearest even
+  return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case ACT_SILU: return v / (1.0f + __expf(-v));
+    case ACT_ELU: return v > 0.0f ? v : (expm1f(v));
+    case ACT_TANH: return tanhf(v);
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    default: return v;
+  }
+}
+
+// One 64-byte-per-row K step of a 32x32 output tile.  Both operands use the same (lane>>5, element) -> k
+// mapping, so the K order inside a chunk is irrelevant; only the C/D layout matters
+// (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+template <typename T>
+__device__ __forceinline__ void mfma_step(f32x16& acc, const uint4& a, const uint4& b);
+template <>
+__device__ __forceinline__ void mfma_step<float>(f32x16& acc, const uint4& a, const uint4& b) {
+  const float* fa = reinterpret_cast<const float*>(&a);
+  const float* fb = reinterpret_cast<const float*>(&b);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mfma_step<__bf16>(f32x16& acc, const uint4& a, const uint4& b) {
+  bf16x8 va, vb;
+  __builtin_memcpy(&va, &a, 16);
+  __builtin_memcpy(&vb, &b, 16);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_out(char* y, size_t idx, float v);
+template <>
+__device__ __forceinline__ void store_out<float>(char* y, size_t idx, float v) { reinterpret_cast<float*>(y)[idx] = v; }
+template <>
+__device__ __forceinline__ void store_out<__bf16>(char* y, size_t idx, float v) {
+  reinterpret_cast<unsigned short*>(y)[idx] = f32_to_bf16(v);
+}
+template <typename T>
+__device__ __forceinline__ float load_in(const char* p, size_t idx);
+template <>
+__device__ __forceinline__ float load_in<float>(const char* p, size_t idx) { return reinterpret_cast<const float*>(p)[idx]; }
+template <>
+__device__ __forceinline__ float load_in<__bf16>(const char* p, size_t idx) {
+  return bf16_to_f32(reinterpret_cast<const unsigned short*>(p)[idx]);
+}
+
+// flat input row reached from GEMM row (b, l) with tap offset `toff` (= tap*dil); -1 when it is padding
+__device__ __forceinline__ int gather_row(const ConvKArgs& a, int b, int l, int toff) {
+  int u = l * a.stride + toff - a.pad_left;
+  const int leff = a.L_in << a.ups;
+  if (a.pad_mode == PAD_REFLECT) {
+    if (u < 0) u = -u;
+    if (u >= leff) u = 2 * (leff - 1) - u;
+  }
+  if (u < 0 || u >= leff) return -1;
+  return b * a.L_in + (u >> a.ups);
+}
+
+// [R_lo, R_hi]: flat input rows a BM-row tile starting at m0 touches (zero-pad convs; monotone in m and tap)
+__device__ __forceinline__ void tile_window(const ConvKArgs& a, int m0, int BM, int M, int& R_lo, int& R_hi) {
+  const int leff = a.L_in << a.ups;
+  const int m_last = min(m0 + BM, M) - 1;
+  int b = m0 / a.L_rows, l = m0 - b * a.L_rows;
+  int u = l * a.stride - a.pad_left;
+  u = max(0, min(u, leff - 1));
+  R_lo = b * a.L_in + (u >> a.ups) - a.reflect_back;
+  b = m_last / a.L_rows;
+  l = m_last - b * a.L_rows;
+  u = l * a.stride + (a.taps - 1) * a.dil - a.pad_left;
+  u = max(0, min(u, leff - 1));
+  R_hi = b * a.L_in + (u >> a.ups) + a.reflect_fwd;
+  R_lo = max(R_lo, 0);
+  R_hi = min(R_hi, a.B * a.L_in - 1);
+}
+
+// bias (+ residual) (+ activation) and store of a wave's TM x TN accumulators (plain conv, row-major [M][n])
+template <typename T, int TM, int TN, bool RES, bool ACT>
+__device__ __forceinline__ void epilogue_plain(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + j * 32;
+    const bool col_ok = col < a.n;
+    const float bv = (a.bias && col_ok) ? a.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = mrow0 + i * 32;
+      float rv[16];
+      if (RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          rv[r] = (col_ok && m < M) ? load_in<T>(a.residual, (size_t)m * a.n + col) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] + bv;
+        if (RES) v += rv[r];
+        if (ACT) v = act_apply(v, a.post_act);
+        if (col_ok && m < M) store_out<T>(a.y, (size_t)m * a.y_ld + col, v);
+      }
+    }
+  }
+}
+
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void epilogue_dispatch(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M) {
+  if (a.residual) {
+    if (a.post_act == ACT_NONE) epilogue_plain<T, TM, TN, true, false>(a, acc, mrow0, col0, M);
+    else epilogue_plain<T, TM, TN, true, true>(a, acc, mrow0, col0, M);
+  } else {
+    if (a.post_act == ACT_NONE) epilogue_plain<T, TM, TN, false, false>(a, acc, mrow0, col0, M);
+    else epilogue_plain<T, TM, TN, false, true>(a, acc, mrow0, col0, M);
+  }
+}
+
+// conv_fast.hip
+bool conv_fast_eligible(const ConvLayer& ly);
+hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, hipStream_t s, bool* launched);
+
+}  // namespace ldc

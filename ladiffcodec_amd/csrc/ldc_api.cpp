@@ -1799,3 +1799,48 @@ extern "C" int ldc_profile_read(ldc_ctx* c, double* conv_ms_total, int64_t* conv
   if (conv_flops_total) *conv_flops_total = c->prof_flops;
   return LDC_OK;
 }
+
+extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride,
+                                   int ups, int iters, double* ms_per_launch) {
+  if (!c || !ms_per_launch || iters < 1) return fail(LDC_E_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  const int dt = dtype == LDC_BF16 ? DT_BF16 : DT_F32;
+  const int cin = cin1 + cin2;
+  std::vector<float> w((size_t)cout * cin * k), bias(cout, 0.1f);
+  unsigned seed = 12345u;
+  for (auto& v : w) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f; }
+  DevMem keep;
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  ConvLayer ly;
+  ConvSpec sp;
+  sp.dt = dt; sp.cin1 = cin1; sp.cin2 = cin2; sp.cout = cout; sp.k = k; sp.stride = stride; sp.ups = ups;
+  sp.pad_left = (k == 4 && stride == 2) ? 1 : (k - 1) / 2;
+  int rc = make_conv(c, sp, w.data(), bias.data(), &ly);
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  LDCCHK(rc);
+  const int L_out = ups ? 2 * L : (stride == 2 ? (L + 2 * sp.pad_left - k) / 2 + 1 : L);
+  const size_t es = dt_size(dt);
+  void *x1 = nullptr, *x2 = nullptr, *y = nullptr;
+  LDCCHK(keep.alloc(&x1, (size_t)B * L * cin1 * es));
+  if (cin2) LDCCHK(keep.alloc(&x2, (size_t)B * L * cin2 * es));
+  LDCCHK(keep.alloc(&y, (size_t)B * L_out * cout * es));
+  HIPCHK(hipMemset(x1, 0x3c, (size_t)B * L * cin1 * es));     // 0x3c3c.. is a small normal number in bf16 and f32
+  if (cin2) HIPCHK(hipMemset(x2, 0x3c, (size_t)B * L * cin2 * es));
+  ConvCall cc;
+  cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.y_ld = cout;
+  hipStream_t s = c->own_stream;
+  for (int i = 0; i < 3; ++i) HIPCHK(launch_conv(ly, cc, s));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) HIPCHK(launch_conv(ly, cc, s));
+  HIPCHK(hipEventRecord(e1, s));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / iters;
+  return LDC_OK;
+}

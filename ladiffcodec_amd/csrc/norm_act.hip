@@ -166,9 +166,71 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x, void* y, c
   }
 }
 
+// Fast variant: grid (row chunks, B); a thread keeps ONE 8-channel column, so the per-channel affine
+// (mean, rstd, gamma, beta, timestep scale/shift folded into a*x+b) is computed once and the row loop is
+// pure streaming.  Needs C/8 to divide 256.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void* y, const void* residual, int L, int C,
+                                                            int groups, int rows_per_block, const float* stats,
+                                                            const float* gamma, const float* beta, const float* ss_table,
+                                                            int ss_stride, const int* t_ptr, int act) {
+  const int vpr = C / 8;
+  const int b = blockIdx.y;
+  const int v = threadIdx.x % vpr, rph = threadIdx.x / vpr, nph = 256 / vpr;
+  const int cpg = C / groups;
+  const float inv_n = 1.0f / ((float)L * (float)cpg);
+  const float* ss = nullptr;
+  if (ss_table) ss = ss_table + (size_t)(t_ptr ? *t_ptr : 0) * ss_stride;
+  float ca[8], cb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = v * 8 + i;
+    const int g = c / cpg;
+    const float mean = stats[((size_t)b * groups + g) * 2] * inv_n;
+    const float var = fmaxf(stats[((size_t)b * groups + g) * 2 + 1] * inv_n - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + 1e-5f);
+    float a1 = rstd * gamma[c];
+    float b1 = beta[c] - mean * a1;
+    if (ss) {
+      const float sc = ss[c] + 1.0f;
+      a1 *= sc;
+      b1 = b1 * sc + ss[C + c];
+    }
+    ca[i] = a1;
+    cb[i] = b1;
+  }
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(L, r0 + rows_per_block);
+  for (int r = r0 + rph; r < r1; r += nph) {
+    const size_t off = ((size_t)b * L + r) * C + v * 8;
+    float f[8], o[8];
+    Vec8<T>::load(x, off, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = act_f(fmaf(f[i], ca[i], cb[i]), act);
+    if (residual) {
+      float rr[8];
+      Vec8<T>::load(residual, off, rr);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] += rr[i];
+    }
+    Vec8<T>::store(y, off, o);
+  }
+}
+
 hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual, int B, int L, int C, int groups,
                            const float* stats, const float* gamma, const float* beta, const float* ss_table,
                            int ss_stride, const int* t_ptr, int act, hipStream_t s) {
+  const int vpr = C / 8;
+  if (C % 8 == 0 && vpr <= 256 && 256 % vpr == 0) {
+    int rpb = (int)std::max<size_t>(256 / vpr, (32 * 1024) / ((size_t)C * dt_size(dt)));
+    dim3 grid((L + rpb - 1) / rpb, B);
+    if (dt == DT_F32)
+      hipLaunchKernelGGL(gn_apply_cols_kernel<float>, grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats, gamma,
+                         beta, ss_table, ss_stride, t_ptr, act);
+    else
+      hipLaunchKernelGGL(gn_apply_cols_kernel<__bf16>, grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
+                         gamma, beta, ss_table, ss_stride, t_ptr, act);
+    return hipGetLastError();
+  }
   const size_t total = (size_t)B * L * (C / 8);
   int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 8);
   if (blocks < 1) blocks = 1;
