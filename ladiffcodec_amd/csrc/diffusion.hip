@@ -184,7 +184,7 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, unsigned step, uin
 template <typename T>
 __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const void* eps_cl, const float* noise,
                                                               int64_t noise_step_stride, void* x_cl, int C, int L,
-                                                              StepTables tb, const int* st, uint64_t seed) {
+                                                              StepTables tb, const int* st, uint64_t seed, uint64_t elem_base) {
   __shared__ float tile[32][33];
   const int t = st[0], j = st[1];
   const float recip = tb.sqrt_recip_alphas_cumprod[t], recipm1 = tb.sqrt_recipm1_alphas_cumprod[t];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const vo
       x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
       float v = c1 * x0 + c2 * xv;
       if (t > 0) {
-        const float z = noise ? noise[(size_t)j * noise_step_stride + idx] : philox_normal(seed, (unsigned)j, idx);
+        const float z = noise ? noise[(size_t)j * noise_step_stride + idx] : philox_normal(seed, (unsigned)j, elem_base + idx);
         v += sigma * z;
       }
       x[idx] = v;
@@ -231,14 +231,14 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const vo
 
 hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const float* noise, int64_t noise_step_stride,
                                   void* x_cl, int B, int C, int L, StepTables tb, const int* st, uint64_t seed,
-                                  hipStream_t s) {
+                                  uint64_t elem_base, hipStream_t s) {
   dim3 grid((L + 31) / 32, (C + 31) / 32, B);
   if (dt == DT_F32)
     hipLaunchKernelGGL(p_sample_update_kernel<float>, grid, dim3(256), 0, s, x, eps_cl, noise, noise_step_stride, x_cl, C, L,
-                       tb, st, seed);
+                       tb, st, seed, elem_base);
   else
     hipLaunchKernelGGL(p_sample_update_kernel<__bf16>, grid, dim3(256), 0, s, x, eps_cl, noise, noise_step_stride, x_cl, C,
-                       L, tb, st, seed);
+                       L, tb, st, seed, elem_base);
   return hipGetLastError();
 }
 

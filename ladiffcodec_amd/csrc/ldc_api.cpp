@@ -168,8 +168,8 @@ struct UnetW {
   double weight_elems = 0;
 };
 
-struct Plan {   // one UNet step for fixed (B, L, F)
-  int B = 0, L = 0, F = 0;
+struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells the two halves of a batch apart
+  int B = 0, L = 0, F = 0, slot = 0;
   void* arena_base = nullptr;
   size_t arena_bytes = 0;
   void* x_cl = nullptr;         // [B*L][channels]
@@ -184,11 +184,22 @@ struct Plan {   // one UNet step for fixed (B, L, F)
   struct Tap { void* p; int C; int L; };
   std::map<std::string, Tap> taps;
   double flops = 0, act_bytes = 0;
-  // hipGraph of {unet step, p_sample_update, step_advance}
-  hipGraphExec_t graph = nullptr;
-  const float* graph_noise = nullptr;
-  float* graph_x = nullptr;
-  hipStream_t graph_stream = nullptr;
+};
+
+// A batch is decoded as (up to) two independent halves on two streams: utterances do not interact inside
+// the UNet, so the halves' kernels overlap and fill each other's tails and launch gaps.
+struct Halves {
+  int n = 0;
+  Plan* p[2] = {nullptr, nullptr};
+  int b0[2] = {0, 0};          // first item of each half
+};
+
+struct StepGraph {   // hipGraph of {unet step (both halves), p_sample_update, step_advance}
+  int B = 0, L = 0, F = 0;
+  const float* noise = nullptr;
+  float* x = nullptr;
+  hipStream_t stream = nullptr;
+  hipGraphExec_t exec = nullptr;
 };
 
 struct ldc_ctx {
@@ -203,6 +214,11 @@ struct ldc_ctx {
   StepTables sched{};
   int* step_state = nullptr;    // device int[2]: t, j
   std::vector<std::unique_ptr<Plan>> plans;
+  std::vector<StepGraph> graphs;
+  Halves last_halves;
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int split_batch = 1;
   std::vector<void*> plan_mem;
   // scratch arena for codec stages and boundary buffers
   char* scratch = nullptr;
@@ -805,6 +821,10 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->device = device;
   c->dt = cfg->compute_dtype == LDC_BF16 ? DT_BF16 : DT_F32;
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  c->split_batch = getenv("LDC_NO_SPLIT") ? 0 : 1;
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, 2 * sizeof(int)));
   c->step_state = (int*)p;
@@ -813,8 +833,9 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
 }
 
 static void drop_plans(ldc_ctx* c) {
-  for (auto& pl : c->plans)
-    if (pl->graph) (void)hipGraphExecDestroy(pl->graph);
+  for (auto& g : c->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  c->graphs.clear();
   c->plans.clear();
   for (void* p : c->plan_mem) (void)hipFree(p);
   c->plan_mem.clear();
@@ -829,6 +850,9 @@ extern "C" int ldc_destroy(ldc_ctx* c) {
   if (c->outnorm_ws) (void)hipFree(c->outnorm_ws);
   if (c->step_state) (void)hipFree(c->step_state);
   for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return LDC_OK;
@@ -1390,9 +1414,9 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   return LDC_OK;
 }
 
-static int get_plan(ldc_ctx* c, int B, int L, int F, hipStream_t s, Plan** out) {
+static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Plan** out) {
   for (auto& p : c->plans)
-    if (p->B == B && p->L == L && p->F == F) {
+    if (p->B == B && p->L == L && p->F == F && p->slot == slot) {
       *out = p.get();
       return LDC_OK;
     }
@@ -1409,9 +1433,26 @@ static int get_plan(ldc_ctx* c, int B, int L, int F, hipStream_t s, Plan** out) 
   LDCCHK(build_plan(c, pl.get(), real, B, L, F));
   pl->arena_base = base;
   pl->arena_bytes = real.cap;
+  pl->slot = slot;
   *out = pl.get();
   c->plans.push_back(std::move(pl));
   (void)s;
+  return LDC_OK;
+}
+
+static int get_halves(ldc_ctx* c, int B, int L, int F, hipStream_t s, Halves* h) {
+  *h = Halves();
+  if (c->split_batch && B >= 2) {
+    h->n = 2;
+    h->b0[0] = 0;
+    h->b0[1] = B / 2;
+    LDCCHK(get_plan(c, B / 2, L, F, 0, s, &h->p[0]));
+    LDCCHK(get_plan(c, B - B / 2, L, F, 1, s, &h->p[1]));
+  } else {
+    h->n = 1;
+    LDCCHK(get_plan(c, B, L, F, 0, s, &h->p[0]));
+  }
+  c->last_halves = *h;
   return LDC_OK;
 }
 
@@ -1435,9 +1476,23 @@ static int run_ops(ldc_ctx* c, Plan* pl, const std::vector<std::function<hipErro
   return LDC_OK;
 }
 
-static int load_cond(ldc_ctx* c, Plan* pl, const float* cond, hipStream_t s) {
-  HIPCHK(launch_to_cl(DT_F32, cond, pl->cond_in_cl, pl->B, c->unet.cond_channels, pl->F, nullptr, 0, 0.f, s));
-  return run_ops(c, pl, pl->cond_ops, false, s);
+static int load_cond(ldc_ctx* c, const Halves& h, const float* cond, hipStream_t s) {
+  for (int k = 0; k < h.n; ++k) {
+    Plan* pl = h.p[k];
+    const float* src = cond + (size_t)h.b0[k] * c->unet.cond_channels * pl->F;
+    HIPCHK(launch_to_cl(DT_F32, src, pl->cond_in_cl, pl->B, c->unet.cond_channels, pl->F, nullptr, 0, 0.f, s));
+    LDCCHK(run_ops(c, pl, pl->cond_ops, false, s));
+  }
+  return LDC_OK;
+}
+
+static int load_x(ldc_ctx* c, const Halves& h, const float* x, hipStream_t s) {
+  for (int k = 0; k < h.n; ++k) {
+    Plan* pl = h.p[k];
+    HIPCHK(launch_to_cl(c->dt, x + (size_t)h.b0[k] * c->unet.channels * pl->L, pl->x_cl, pl->B, c->unet.channels, pl->L, nullptr,
+                        0, 0.f, s));
+  }
+  return LDC_OK;
 }
 
 static int check_unet_args(ldc_ctx* c, int B, int L, int F) {
@@ -1454,34 +1509,62 @@ extern "C" int ldc_unet_forward(ldc_ctx* c, const float* x, int t, const float* 
   if (t < 0 || t >= c->unet.timesteps) return fail(LDC_E_INVALID, "t out of range");
   LDCCHK(check_unet_args(c, B, L, F));
   hipStream_t s = pick_stream(c, stream);
-  Plan* pl = nullptr;
-  LDCCHK(get_plan(c, B, L, F, s, &pl));
-  LDCCHK(load_cond(c, pl, cond, s));
-  HIPCHK(launch_to_cl(c->dt, x, pl->x_cl, B, c->unet.channels, L, nullptr, 0, 0.f, s));
+  Halves h;
+  LDCCHK(get_halves(c, B, L, F, s, &h));
+  LDCCHK(load_cond(c, h, cond, s));
+  LDCCHK(load_x(c, h, x, s));
   HIPCHK(launch_step_set(c->step_state, t, 0, s));
-  LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
-  HIPCHK(launch_from_cl(c->dt, pl->eps_cl, eps_out, B, c->unet.channels, L, nullptr, 0, 0.f, s));
+  for (int k = 0; k < h.n; ++k) {
+    Plan* pl = h.p[k];
+    LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
+    HIPCHK(launch_from_cl(c->dt, pl->eps_cl, eps_out + (size_t)h.b0[k] * c->unet.channels * L, pl->B, c->unet.channels, L, nullptr,
+                          0, 0.f, s));
+  }
   return finish_stream(c, stream);
 }
 
 extern "C" int ldc_unet_debug_tap(ldc_ctx* c, const char* name, float* out, int64_t capacity, void* stream) {
   LDCCHK(check_ready(c, LDC_MODEL_MAIN));
   if (!name || !out) return fail(LDC_E_INVALID, "null argument");
-  if (c->plans.empty()) return fail(LDC_E_STATE, "no UNet call has been made yet");
-  Plan* pl = c->plans.back().get();
-  auto it = pl->taps.find(name);
-  if (it == pl->taps.end()) return fail(LDC_E_INVALID, "unknown tap '%s'", name);
-  const int64_t need = (int64_t)pl->B * it->second.C * it->second.L;
+  const Halves& h = c->last_halves;
+  if (h.n == 0) return fail(LDC_E_STATE, "no UNet call has been made yet");
+  int64_t need = 0;
+  for (int k = 0; k < h.n; ++k) {
+    auto it = h.p[k]->taps.find(name);
+    if (it == h.p[k]->taps.end()) return fail(LDC_E_INVALID, "unknown tap '%s'", name);
+    need += (int64_t)h.p[k]->B * it->second.C * it->second.L;
+  }
   if (capacity < need) return fail(LDC_E_INVALID, "tap '%s' needs %lld elements", name, (long long)need);
   hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_from_cl(c->dt, it->second.p, out, pl->B, it->second.C, it->second.L, nullptr, 0, 0.f, s));
+  for (int k = 0; k < h.n; ++k) {
+    const Plan::Tap& tp = h.p[k]->taps.find(name)->second;
+    HIPCHK(launch_from_cl(c->dt, tp.p, out + (size_t)h.b0[k] * tp.C * tp.L, h.p[k]->B, tp.C, tp.L, nullptr, 0, 0.f, s));
+  }
   return finish_stream(c, stream);
 }
 
-static int one_step(ldc_ctx* c, Plan* pl, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
+static int half_step(ldc_ctx* c, const Halves& h, int k, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
+  Plan* pl = h.p[k];
+  const size_t off = (size_t)h.b0[k] * c->unet.channels * pl->L;
   LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
-  HIPCHK(launch_p_sample_update(c->dt, x, pl->eps_cl, noise, noise_stride, pl->x_cl, pl->B, c->unet.channels, pl->L, c->sched,
-                                c->step_state, c->cfg.noise_seed, s));
+  HIPCHK(launch_p_sample_update(c->dt, x + off, pl->eps_cl, noise ? noise + off : nullptr, noise_stride, pl->x_cl, pl->B,
+                                c->unet.channels, pl->L, c->sched, c->step_state, c->cfg.noise_seed, (uint64_t)off, s));
+  return LDC_OK;
+}
+
+// one reverse-diffusion step for the whole batch; two halves fork onto the auxiliary stream and join again
+// (valid eagerly and under stream capture: the event edges become graph dependencies)
+static int one_step(ldc_ctx* c, const Halves& h, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
+  if (h.n == 2 && !c->profile) {
+    HIPCHK(hipEventRecord(c->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    LDCCHK(half_step(c, h, 0, x, noise, noise_stride, s));
+    LDCCHK(half_step(c, h, 1, x, noise, noise_stride, c->aux_stream));
+    HIPCHK(hipEventRecord(c->ev_join, c->aux_stream));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+  } else {
+    for (int k = 0; k < h.n; ++k) LDCCHK(half_step(c, h, k, x, noise, noise_stride, s));
+  }
   HIPCHK(launch_step_advance(c->step_state, s));
   return LDC_OK;
 }
@@ -1493,41 +1576,50 @@ extern "C" int ldc_p_sample(ldc_ctx* c, float* x, int t, const float* cond, cons
   if (t < 0 || t >= c->unet.timesteps) return fail(LDC_E_INVALID, "t out of range");
   LDCCHK(check_unet_args(c, B, L, F));
   hipStream_t s = pick_stream(c, stream);
-  Plan* pl = nullptr;
-  LDCCHK(get_plan(c, B, L, F, s, &pl));
-  LDCCHK(load_cond(c, pl, cond, s));
-  HIPCHK(launch_to_cl(c->dt, x, pl->x_cl, B, c->unet.channels, L, nullptr, 0, 0.f, s));
+  Halves h;
+  LDCCHK(get_halves(c, B, L, F, s, &h));
+  LDCCHK(load_cond(c, h, cond, s));
+  LDCCHK(load_x(c, h, x, s));
   HIPCHK(launch_step_set(c->step_state, t, 0, s));
-  LDCCHK(one_step(c, pl, x, noise, 0, s));
+  LDCCHK(one_step(c, h, x, noise, 0, s));
   return finish_stream(c, stream);
 }
 
-// the denoise loop on a prepared plan (cond already processed, x_cl already set)
-static int denoise_loop(ldc_ctx* c, Plan* pl, float* x, const float* noise, int n_steps, hipStream_t s) {
-  const int64_t stride = (int64_t)pl->B * c->unet.channels * pl->L;
+// the denoise loop on prepared plans (cond already processed, x_cl already set)
+static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const float* noise, int n_steps, hipStream_t s) {
+  const int L = h.p[0]->L, F = h.p[0]->F;
+  const int64_t stride = (int64_t)B * c->unet.channels * L;
   HIPCHK(launch_step_set(c->step_state, n_steps - 1, 0, s));
   if (c->profile || n_steps < 3) {
-    for (int i = 0; i < n_steps; ++i) LDCCHK(one_step(c, pl, x, noise, stride, s));
+    for (int i = 0; i < n_steps; ++i) LDCCHK(one_step(c, h, x, noise, stride, s));
     return LDC_OK;
   }
+  StepGraph* sg = nullptr;
+  for (auto& g : c->graphs)
+    if (g.B == B && g.L == L && g.F == F) sg = &g;
+  if (!sg) {
+    c->graphs.push_back(StepGraph());
+    sg = &c->graphs.back();
+    sg->B = B; sg->L = L; sg->F = F;
+  }
   int done = 0;
-  if (!pl->graph || pl->graph_noise != noise || pl->graph_x != x || pl->graph_stream != s) {
-    if (pl->graph) { (void)hipGraphExecDestroy(pl->graph); pl->graph = nullptr; }
+  if (!sg->exec || sg->noise != noise || sg->x != x || sg->stream != s) {
+    if (sg->exec) { (void)hipGraphExecDestroy(sg->exec); sg->exec = nullptr; }
     // first step eagerly: loads code objects / sets function attributes outside of the capture
-    LDCCHK(one_step(c, pl, x, noise, stride, s));
+    LDCCHK(one_step(c, h, x, noise, stride, s));
     done = 1;
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-    int r = one_step(c, pl, x, noise, stride, s);
+    int r = one_step(c, h, x, noise, stride, s);
     hipError_t e = hipStreamEndCapture(s, &g);
     if (r != LDC_OK) { if (g) (void)hipGraphDestroy(g); return r; }
     if (e != hipSuccess) return fail(LDC_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-    e = hipGraphInstantiate(&pl->graph, g, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(&sg->exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { pl->graph = nullptr; return fail(LDC_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
-    pl->graph_noise = noise; pl->graph_x = x; pl->graph_stream = s;
+    if (e != hipSuccess) { sg->exec = nullptr; return fail(LDC_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    sg->noise = noise; sg->x = x; sg->stream = s;
   }
-  for (int i = done; i < n_steps; ++i) HIPCHK(hipGraphLaunch(pl->graph, s));
+  for (int i = done; i < n_steps; ++i) HIPCHK(hipGraphLaunch(sg->exec, s));
   return LDC_OK;
 }
 
@@ -1538,11 +1630,11 @@ extern "C" int ldc_denoise(ldc_ctx* c, float* img, const float* cond, const floa
   if (n_steps < 1 || n_steps > c->unet.timesteps) return fail(LDC_E_INVALID, "n_steps must be in [1,%d]", c->unet.timesteps);
   LDCCHK(check_unet_args(c, B, L, F));
   hipStream_t s = pick_stream(c, stream);
-  Plan* pl = nullptr;
-  LDCCHK(get_plan(c, B, L, F, s, &pl));
-  LDCCHK(load_cond(c, pl, cond, s));
-  HIPCHK(launch_to_cl(c->dt, img, pl->x_cl, B, c->unet.channels, L, nullptr, 0, 0.f, s));
-  LDCCHK(denoise_loop(c, pl, img, noise, n_steps, s));
+  Halves h;
+  LDCCHK(get_halves(c, B, L, F, s, &h));
+  LDCCHK(load_cond(c, h, cond, s));
+  LDCCHK(load_x(c, h, img, s));
+  LDCCHK(denoise_loop(c, h, B, img, noise, n_steps, s));
   return finish_stream(c, stream);
 }
 
@@ -1580,8 +1672,8 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
   LDCCHK(check_unet_args(c, B, L, F));
   LDCCHK(ensure_outnorm(c, B));
   hipStream_t s = pick_stream(c, stream);
-  Plan* pl = nullptr;
-  LDCCHK(get_plan(c, B, L, F, s, &pl));
+  Halves h;
+  LDCCHK(get_halves(c, B, L, F, s, &h));
   LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
     float* qr = nullptr;
     int Fq = 0;
@@ -1599,10 +1691,13 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
       HIPCHK(launch_maxabs(DT_F32, up, B, (int64_t)L * D, per_item ? 1 : 0, mx, s));
       HIPCHK(launch_from_cl(DT_F32, up, x, B, D, L, mx, per_item ? 1 : 0, 1e-8f, s));
       // process_cond for the UNet (rows are already channels-last fp32)
-      HIPCHK(hipMemcpyAsync(pl->cond_in_cl, qr, (size_t)B * F * D * 4, hipMemcpyDeviceToDevice, s));
-      LDCCHK(run_ops(c, pl, pl->cond_ops, false, s));
-      HIPCHK(launch_to_cl(c->dt, x, pl->x_cl, B, D, L, nullptr, 0, 0.f, s));
-      LDCCHK(denoise_loop(c, pl, x, noise, n_steps, s));
+      for (int k = 0; k < h.n; ++k) {
+        Plan* pl = h.p[k];
+        HIPCHK(hipMemcpyAsync(pl->cond_in_cl, qr + (size_t)h.b0[k] * F * D, (size_t)pl->B * F * D * 4, hipMemcpyDeviceToDevice, s));
+        LDCCHK(run_ops(c, pl, pl->cond_ops, false, s));
+      }
+      LDCCHK(load_x(c, h, x, s));
+      LDCCHK(denoise_loop(c, h, B, x, noise, n_steps, s));
     }
     // decoder (quirk Q3: no x18 un-scaling on this path, sample.py:131)
     SeaRun R{c, &ar, s, dry, B};

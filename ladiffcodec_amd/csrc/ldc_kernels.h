@@ -110,7 +110,7 @@ struct StepTables {            // device pointers, fp32 [T]
 // also writes x_cl [B][L][C] dt (the next step's UNet input).  Reads t, j from st.
 hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const float* noise, int64_t noise_step_stride,
                                   void* x_cl, int B, int C, int L, StepTables tb, const int* st, uint64_t seed,
-                                  hipStream_t s);
+                                  uint64_t elem_base, hipStream_t s);
 // x /= (maxabs[b or 0] + eps) in place on a raw element stream (n_per_item elements per item)
 hipError_t launch_scale_by_maxabs(int dt, void* x, int B, int64_t n_per_item, const float* maxabs, int per_item,
                                   float eps, hipStream_t s);

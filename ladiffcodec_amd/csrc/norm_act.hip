@@ -200,19 +200,33 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
     cb[i] = b1;
   }
   const int r0 = blockIdx.x * rows_per_block, r1 = min(L, r0 + rows_per_block);
-  for (int r = r0 + rph; r < r1; r += nph) {
-    const size_t off = ((size_t)b * L + r) * C + v * 8;
-    float f[8], o[8];
-    Vec8<T>::load(x, off, f);
+  // 4 rows per trip: all loads of a trip are issued before the first use (latency paid once per trip)
+  constexpr int U = 4;
+  for (int rb = r0 + rph; rb < r1; rb += nph * U) {
+    float f[U][8], rr[U][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = act_f(fmaf(f[i], ca[i], cb[i]), act);
-    if (residual) {
-      float rr[8];
-      Vec8<T>::load(residual, off, rr);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] += rr[i];
+    for (int q = 0; q < U; ++q) {
+      const int r = rb + q * nph;
+      if (r < r1) {
+        const size_t off = ((size_t)b * L + r) * C + v * 8;
+        Vec8<T>::load(x, off, f[q]);
+        if (residual) Vec8<T>::load(residual, off, rr[q]);
+      }
     }
-    Vec8<T>::store(y, off, o);
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int r = rb + q * nph;
+      if (r < r1) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = act_f(fmaf(f[q][i], ca[i], cb[i]), act);
+        if (residual) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += rr[q][i];
+        }
+        Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
+      }
+    }
   }
 }
 
