@@ -25,6 +25,8 @@ struct ConvKArgs {
   int win_rows;        // generic kernel: LDS window capacity (rows); the zero row lives at index win_rows
   int tg;              // taps staged per weight slab
   int reflect_back, reflect_fwd;
+  float* gn_sum;       // fused GroupNorm statistics target [B][gn_groups][2] (pre-zeroed) or null
+  int gn_groups, gn_cpg;
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -142,8 +144,60 @@ __device__ __forceinline__ void epilogue_plain(const ConvKArgs& a, f32x16 (&acc)
   }
 }
 
+// Fused GroupNorm statistics (unet.py:142-147 normalises the conv output): every wave adds the sum and the sum
+// of squares of (acc + bias) per (item, group) to gn_sum[b][g][2].  A lane owns one column per 32-wide sub-tile,
+// i.e. one group; lanes of a group are reduced with xor-shuffles (channels per group: a power of two >= 4 that
+// divides or is a multiple of 32), then one lane per group issues the two atomics.  Rows of several items can
+// meet in one tile, hence the (wave-uniform) loop over the items the tile touches.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_gn_stats(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int m0,
+                                                  int BM, int M) {
+  const int lane = threadIdx.x & 63;
+  const int b_first = m0 / a.L_rows;
+  const int b_last = (min(m0 + BM, M) - 1) / a.L_rows;
+  const int cpg = a.gn_cpg;
+  const int seg = min(cpg, 32);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + j * 32;
+    const bool col_ok = col < a.n;
+    const float bv = (a.bias && col_ok) ? a.bias[col] : 0.0f;
+    const int g = col_ok ? col / cpg : 0;
+    for (int bb = b_first; bb <= b_last; ++bb) {
+      const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (col_ok && m >= lo && m < hi) {
+            const float v = acc[i][j][r] + bv;
+            s += v;
+            ss += v * v;
+          }
+        }
+      s += __shfl_xor(s, 32);
+      ss += __shfl_xor(ss, 32);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        if (o < seg) {
+          s += __shfl_xor(s, o);
+          ss += __shfl_xor(ss, o);
+        }
+      }
+      if (col_ok && lane < 32 && (lane & (seg - 1)) == 0) {
+        atomicAdd(&a.gn_sum[((size_t)bb * a.gn_groups + g) * 2], s);
+        atomicAdd(&a.gn_sum[((size_t)bb * a.gn_groups + g) * 2 + 1], ss);
+      }
+    }
+  }
+}
+
 template <typename T, int TM, int TN>
-__device__ __forceinline__ void epilogue_dispatch(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M) {
+__device__ __forceinline__ void epilogue_dispatch(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M,
+                                                  int m0 = 0, int BM = 0) {
+  if (a.gn_sum) epilogue_gn_stats<TM, TN>(a, acc, mrow0, col0, m0, BM, M);
   if (a.residual) {
     if (a.post_act == ACT_NONE) epilogue_plain<T, TM, TN, true, false>(a, acc, mrow0, col0, M);
     else epilogue_plain<T, TM, TN, true, true>(a, acc, mrow0, col0, M);

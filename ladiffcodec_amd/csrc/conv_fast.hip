@@ -264,7 +264,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fast_kernel(const ConvKArgs 
     }
   }
 
-  epilogue_dispatch<T, TM, TN>(a, acc, m0 + wm * TM * 32 + 4 * (lane >> 5), n0 + wn * TN * 32 + (lane & 31), M);
+  epilogue_dispatch<T, TM, TN>(a, acc, m0 + wm * TM * 32 + 4 * (lane >> 5), n0 + wn * TN * 32 + (lane & 31), M, m0, BM);
 }
 
 bool conv_fast_eligible(const ConvLayer& ly) {

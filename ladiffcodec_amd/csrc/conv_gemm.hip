@@ -192,7 +192,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
   const int mrow0 = m0 + wm * TM * 32 + 4 * (lane >> 5);
   const int col0 = n0 + wn * TN * 32 + (lane & 31);
   if (!a.tr_stride) {
-    epilogue_dispatch<T, TM, TN>(a, acc, mrow0, col0, M);
+    epilogue_dispatch<T, TM, TN>(a, acc, mrow0, col0, M, m0, BM);
     return;
   }
   // transposed conv: GEMM column = phase*Cout + co ; row q -> output position q*stride + phase - trim_left
@@ -305,6 +305,13 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   a.pad_mode = ly.pad_mode; a.pre_act = ly.pre_act; a.post_act = ly.post_act;
   a.tr_stride = ly.tr_stride; a.tr_cout = ly.tr_cout; a.tr_trim_left = ly.tr_trim_left;
   a.tg = 1; a.win_rows = 0;
+  a.gn_sum = nullptr; a.gn_groups = 0; a.gn_cpg = 1;
+  if (c.gn_sum && c.gn_groups > 0 && !ly.tr_stride) {
+    const int cpg = ly.n / c.gn_groups;
+    const bool pow2 = cpg >= 4 && (cpg & (cpg - 1)) == 0;
+    if (ly.n % c.gn_groups || !pow2) return hipErrorInvalidValue;   // the planner only asks for supported widths
+    a.gn_sum = c.gn_sum; a.gn_groups = c.gn_groups; a.gn_cpg = cpg;
+  }
   const int BM = 128;
   const int M = c.B * c.L_rows;
   if (M <= 0) return hipSuccess;

@@ -219,6 +219,7 @@ struct ldc_ctx {
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int split_batch = 1;
+  int fuse_gn_stats = 1;
   std::vector<void*> plan_mem;
   // scratch arena for codec stages and boundary buffers
   char* scratch = nullptr;
@@ -825,6 +826,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   c->split_batch = getenv("LDC_NO_SPLIT") ? 0 : 1;
+  c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, 2 * sizeof(int)));
   c->step_state = (int*)p;
@@ -1246,9 +1248,11 @@ struct PlanBuilder {
     pl->step_flops.push_back(flops);
     pl->flops += flops;
   }
-  void conv(const ConvLayer& ly, const void* x1, const void* x2, void* y, const void* residual, int L_in, int L_out) {
+  void conv(const ConvLayer& ly, const void* x1, const void* x2, void* y, const void* residual, int L_in, int L_out,
+            float* gn_sum = nullptr) {
     ConvCall cc;
     cc.B = B; cc.L_in = L_in; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.residual = residual; cc.y_ld = ly.n;
+    cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
     const ConvLayer* lp = &ly;
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out);
   }
@@ -1267,15 +1271,17 @@ struct PlanBuilder {
     float* st1 = next_stats();
     float* st2 = next_stats();
     const int* tptr = c->step_state;
-    conv(r.c1, x1, x2, a, nullptr, L, L);
+    const int cpg = r.cout / g;
+    const bool fuse_stats = c->fuse_gn_stats && cpg >= 4 && (cpg & (cpg - 1)) == 0;
+    conv(r.c1, x1, x2, a, nullptr, L, L, fuse_stats ? st1 : nullptr);
     const ResnetW* rp = &r;
-    add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
+    if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
     add([=](hipStream_t s) {
       return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, u->ss_table + rp->ss_off,
                              u->ss_stride, tptr, ACT_SILU, s);
     });
-    conv(r.c2, b, nullptr, d, nullptr, L, L);
-    add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
+    conv(r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
+    if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
     const void* res = x1;
     if (r.has_res) {
       void* rr = act(rows, r.cout);

@@ -178,7 +178,9 @@ def test_philox_noise_is_standard_normal_and_seeded():
     x0 = cu(g["img0"])
     a = e.denoise(x0, cond, 6, None)
     b = e.denoise(x0, cond, 6, None)
-    assert torch.equal(a, b)                       # same seed, same step indices -> same draws
+    # same seed, same step indices -> same draws (fp32 atomics in the GroupNorm / attention reductions make the
+    # two runs agree to rounding, not bit for bit)
+    assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
     assert torch.isfinite(a).all()
     # one step from zeros with eps-independent part removed: x_new - mean = sigma * z
     x = torch.zeros_like(x0)
