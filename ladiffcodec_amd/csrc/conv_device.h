@@ -207,6 +207,69 @@ __device__ __forceinline__ void epilogue_dispatch(const ConvKArgs& a, f32x16 (&a
   }
 }
 
+// Store path of the fast kernel: the direct form above issues 16*TM*TN two-byte stores per lane (64 per lane for
+// a 64x64 wave tile; measured ~375 cycles per store instruction, ~10 us per workgroup -- longer than the whole
+// MFMA loop of a 256-channel k=3 conv).  Here each wave transposes its tile through LDS (ring stages are free
+// once the K loop has drained) and writes whole rows: 16 bytes per lane, 8 rows x 128 B per store instruction.
+template <typename T, int TM, int TN, bool RES, bool ACT>
+__device__ __forceinline__ void epilogue_rows(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
+                                              int col_wave0, int M) {
+  constexpr int RB = TN * 32 * (int)sizeof(T);      // bytes per tile row
+  constexpr int PITCH = RB + 16;
+  constexpr int LPR = RB / 16;                      // lanes per row in the read-back
+  constexpr int RPS = 64 / LPR;                     // rows per sweep
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col_wave0 + j * 32 + (lane & 31);
+    const bool col_ok = col < a.n;
+    const float bv = (a.bias && col_ok) ? a.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float rv[16];
+      if (RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m_wave0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          rv[r] = (col_ok && m < M) ? load_in<T>(a.residual, (size_t)m * a.n + col) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[i][j][r] + bv;
+        if (RES) v += rv[r];
+        if (ACT) v = act_apply(v, a.post_act);
+        store_out<T>(wave_lds, (size_t)(row * PITCH) / sizeof(T) + j * 32 + (lane & 31), v);
+      }
+    }
+  }
+  // same wave wrote and reads: LDS executes a wave's operations in order
+  const int rsub = lane / LPR, chunk = lane % LPR;
+  const int col = col_wave0 + chunk * (16 / (int)sizeof(T));
+#pragma unroll
+  for (int sw = 0; sw < TM * 32 / RPS; ++sw) {
+    const int row = sw * RPS + rsub;
+    const int m = m_wave0 + row;
+    const uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * PITCH + chunk * 16);
+    if (m < M && col < a.n) *reinterpret_cast<uint4*>(a.y + ((size_t)m * a.y_ld + col) * sizeof(T)) = v;
+  }
+}
+
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void epilogue_rows_dispatch(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
+                                                       int col_wave0, int M, int m0, int BM) {
+  const int lane = threadIdx.x & 63;
+  if (a.gn_sum) epilogue_gn_stats<TM, TN>(a, acc, m_wave0 + 4 * (lane >> 5), col_wave0 + (lane & 31), m0, BM, M);
+  if (a.residual) {
+    if (a.post_act == ACT_NONE) epilogue_rows<T, TM, TN, true, false>(a, acc, wave_lds, m_wave0, col_wave0, M);
+    else epilogue_rows<T, TM, TN, true, true>(a, acc, wave_lds, m_wave0, col_wave0, M);
+  } else {
+    if (a.post_act == ACT_NONE) epilogue_rows<T, TM, TN, false, false>(a, acc, wave_lds, m_wave0, col_wave0, M);
+    else epilogue_rows<T, TM, TN, false, true>(a, acc, wave_lds, m_wave0, col_wave0, M);
+  }
+}
+
 // conv_fast.hip
 bool conv_fast_eligible(const ConvLayer& ly);
 hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, hipStream_t s, bool* launched);

@@ -57,6 +57,7 @@ struct FastGeom {
   int stage_bytes;
   int ngroups;       // tap groups per chunk group (k=7: 2)
   int debug;         // tuning aid (LDC_CONV_DEBUG): 1 = skip the copies after the prologue, 2 = skip the math
+  unsigned long long* stamps;   // tuning aid: per workgroup {start, prologue done, loop done, end} s_memtime
 };
 
 
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fast_kernel(const ConvKArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int M = a.B * a.L_rows;
+  unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+  if (gm.stamps) t_start = __builtin_amdgcn_s_memtime();
   // XCD-aware tile order: workgroup h runs on XCD h % 8 (observed dispatch rule, used for speed only), so give
   // every XCD a contiguous run of tiles, N-tile fastest: workgroups sharing an input window hit the same L2.
   int m0, n0;
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fast_kernel(const ConvKArgs 
   for (int p = 0; p < S - 1; ++p)
     if (p < nunits) load_unit(p);
   int cu_g = 0;   // consumer cursor: tap group of the unit being multiplied
+  if (gm.stamps) t_pro = __builtin_amdgcn_s_memtime();
   for (int u0 = 0; u0 < nunits; u0 += S) {
 #pragma unroll
     for (int ss = 0; ss < S; ++ss) {
@@ -264,8 +268,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fast_kernel(const ConvKArgs 
     }
   }
 
-  epilogue_dispatch<T, TM, TN>(a, acc, m0 + wm * TM * 32 + 4 * (lane >> 5), n0 + wn * TN * 32 + (lane & 31), M, m0, BM);
+  if (gm.stamps) t_loop = __builtin_amdgcn_s_memtime();
+  __syncthreads();   // every wave has consumed the last ring stage: LDS is free for the output transpose
+  {
+    constexpr int WREG = TM * 32 * (TN * 32 * (int)sizeof(T) + 16);
+    epilogue_rows_dispatch<T, TM, TN>(a, acc, smem + (size_t)wave * WREG, m0 + wm * TM * 32, n0 + wn * TN * 32, M, m0, BM);
+  }
+  if (gm.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* o = gm.stamps + (size_t)blockIdx.x * 4;
+      o[0] = t_start; o[1] = t_pro; o[2] = t_loop; o[3] = t_end;
+    }
+  }
 }
+
+unsigned long long* g_conv_stamps = nullptr;   // set by ldc_conv_microbench when LDC_CONV_STAMPS is on
 
 bool conv_fast_eligible(const ConvLayer& ly) {
   return ly.pad_mode == PAD_ZERO && ly.pre_act == ACT_NONE && ly.tr_stride == 0 && ly.taps <= 8;
@@ -282,7 +301,8 @@ static hipError_t launch_fast_cfg(const ConvKArgs& a, const FastGeom& gm, int M,
     if (e != hipSuccess) return e;
     lds_opt_in = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), (size_t)S * gm.stage_bytes, s, a, gm);
+  const size_t epi_bytes = (size_t)WM * WN * TM * 32 * (TN * 32 * sizeof(T) + 16);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), std::max((size_t)S * gm.stage_bytes, epi_bytes), s, a, gm);
   return hipGetLastError();
 }
 
@@ -335,6 +355,7 @@ hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a_in, int M, i
     static int dbg = -1;
     if (dbg < 0) dbg = getenv("LDC_CONV_DEBUG") ? atoi(getenv("LDC_CONV_DEBUG")) : 0;
     gm.debug = dbg;
+    gm.stamps = g_conv_stamps;
   }
   a.tg = TG;
   *launched = true;

@@ -1901,6 +1901,8 @@ extern "C" int ldc_profile_read(ldc_ctx* c, double* conv_ms_total, int64_t* conv
   return LDC_OK;
 }
 
+namespace ldc { extern unsigned long long* g_conv_stamps; }
+
 extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride,
                                    int ups, int iters, double* ms_per_launch) {
   if (!c || !ms_per_launch || iters < 1) return fail(LDC_E_INVALID, "bad arguments");
@@ -1943,5 +1945,25 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *ms_per_launch = ms / iters;
+  if (getenv("LDC_CONV_STAMPS")) {
+    const int nblk = 1 << 16;
+    void* st = nullptr;
+    LDCCHK(keep.alloc(&st, (size_t)nblk * 4 * 8));
+    HIPCHK(hipMemset(st, 0, (size_t)nblk * 4 * 8));
+    ldc::g_conv_stamps = (unsigned long long*)st;
+    hipError_t le = launch_conv(ly, cc, s);
+    ldc::g_conv_stamps = nullptr;
+    HIPCHK(le);
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h((size_t)nblk * 4);
+    HIPCHK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+    double pro = 0, loop = 0, epi = 0; int n = 0; unsigned long long tmin = ~0ull, tmax = 0;
+    for (int b = 0; b < nblk; ++b) {
+      if (!h[4 * b + 3]) continue;
+      pro += (double)(h[4 * b + 1] - h[4 * b]); loop += (double)(h[4 * b + 2] - h[4 * b + 1]); epi += (double)(h[4 * b + 3] - h[4 * b + 2]);
+      tmin = std::min(tmin, h[4 * b]); tmax = std::max(tmax, h[4 * b + 3]); ++n;
+    }
+    if (n) fprintf(stderr, "  stamps (100 MHz ticks): blocks=%d prologue=%.1f loop=%.1f epilogue=%.1f  kernel span=%.1f\n", n, pro / n, loop / n, epi / n, (double)(tmax - tmin));
+  }
   return LDC_OK;
 }
