@@ -188,10 +188,11 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
 
 // A batch is decoded as (up to) two independent halves on two streams: utterances do not interact inside
 // the UNet, so the halves' kernels overlap and fill each other's tails and launch gaps.
-struct Halves {
+static constexpr int kMaxParts = 4;
+struct Halves {                // (the name dates from the two-way split; n parts, n <= kMaxParts)
   int n = 0;
-  Plan* p[2] = {nullptr, nullptr};
-  int b0[2] = {0, 0};          // first item of each half
+  Plan* p[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
+  int b0[kMaxParts] = {0, 0, 0, 0};   // first item of each part
 };
 
 struct StepGraph {   // hipGraph of {unet step (both halves), p_sample_update, step_advance}
@@ -216,9 +217,9 @@ struct ldc_ctx {
   std::vector<std::unique_ptr<Plan>> plans;
   std::vector<StepGraph> graphs;
   Halves last_halves;
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int split_batch = 1;
+  hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
+  int split_batch = 2;
   int fuse_gn_stats = 1;
   std::vector<void*> plan_mem;
   // scratch arena for codec stages and boundary buffers
@@ -822,10 +823,12 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->device = device;
   c->dt = cfg->compute_dtype == LDC_BF16 ? DT_BF16 : DT_F32;
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  c->split_batch = getenv("LDC_NO_SPLIT") ? 0 : 1;
+  for (int k = 1; k < kMaxParts; ++k) {
+    HIPCHK(hipStreamCreateWithFlags(&c->aux_stream[k], hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+  }
+  c->split_batch = getenv("LDC_NO_SPLIT") ? 1 : (getenv("LDC_SPLIT") ? std::max(1, std::min(kMaxParts, atoi(getenv("LDC_SPLIT")))) : 2);
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, 2 * sizeof(int)));
@@ -853,8 +856,10 @@ extern "C" int ldc_destroy(ldc_ctx* c) {
   if (c->step_state) (void)hipFree(c->step_state);
   for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+  for (int k = 1; k < kMaxParts; ++k) {
+    if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
+    if (c->aux_stream[k]) (void)hipStreamDestroy(c->aux_stream[k]);
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return LDC_OK;
@@ -1448,15 +1453,11 @@ static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Pl
 
 static int get_halves(ldc_ctx* c, int B, int L, int F, hipStream_t s, Halves* h) {
   *h = Halves();
-  if (c->split_batch && B >= 2) {
-    h->n = 2;
-    h->b0[0] = 0;
-    h->b0[1] = B / 2;
-    LDCCHK(get_plan(c, B / 2, L, F, 0, s, &h->p[0]));
-    LDCCHK(get_plan(c, B - B / 2, L, F, 1, s, &h->p[1]));
-  } else {
-    h->n = 1;
-    LDCCHK(get_plan(c, B, L, F, 0, s, &h->p[0]));
+  h->n = std::max(1, std::min(c->split_batch, B));
+  for (int k = 0; k < h->n; ++k) {
+    const int lo = (int)((long long)B * k / h->n), hi = (int)((long long)B * (k + 1) / h->n);
+    h->b0[k] = lo;
+    LDCCHK(get_plan(c, hi - lo, L, F, k, s, &h->p[k]));
   }
   c->last_halves = *h;
   return LDC_OK;
@@ -1561,13 +1562,15 @@ static int half_step(ldc_ctx* c, const Halves& h, int k, float* x, const float* 
 // one reverse-diffusion step for the whole batch; two halves fork onto the auxiliary stream and join again
 // (valid eagerly and under stream capture: the event edges become graph dependencies)
 static int one_step(ldc_ctx* c, const Halves& h, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
-  if (h.n == 2 && !c->profile) {
+  if (h.n >= 2 && !c->profile) {
     HIPCHK(hipEventRecord(c->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    for (int k = 1; k < h.n; ++k) HIPCHK(hipStreamWaitEvent(c->aux_stream[k], c->ev_fork, 0));
     LDCCHK(half_step(c, h, 0, x, noise, noise_stride, s));
-    LDCCHK(half_step(c, h, 1, x, noise, noise_stride, c->aux_stream));
-    HIPCHK(hipEventRecord(c->ev_join, c->aux_stream));
-    HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    for (int k = 1; k < h.n; ++k) {
+      LDCCHK(half_step(c, h, k, x, noise, noise_stride, c->aux_stream[k]));
+      HIPCHK(hipEventRecord(c->ev_join[k], c->aux_stream[k]));
+      HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
+    }
   } else {
     for (int k = 0; k < h.n; ++k) LDCCHK(half_step(c, h, k, x, noise, noise_stride, s));
   }

@@ -166,25 +166,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x, void* y, c
   }
 }
 
-// Fast variant: grid (row chunks, B); a thread keeps ONE 8-channel column, so the per-channel affine
-// (mean, rstd, gamma, beta, timestep scale/shift folded into a*x+b) is computed once and the row loop is
-// pure streaming.  Needs C/8 to divide 256.
+// Fast variant: grid (row chunks, B).  The per-channel affine of this item (mean, rstd, gamma, beta and the
+// timestep scale/shift folded into a*x+b) is built once per workgroup in LDS; a thread then keeps ONE 8-channel
+// column and streams U rows with all loads in flight before the first use.  Needs C/8 to divide 256, C <= 2048.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void* y, const void* residual, int L, int C,
                                                             int groups, int rows_per_block, const float* stats,
                                                             const float* gamma, const float* beta, const float* ss_table,
                                                             int ss_stride, const int* t_ptr, int act) {
+  __shared__ __attribute__((aligned(16))) float s_a[2048];
+  __shared__ __attribute__((aligned(16))) float s_b[2048];
+  constexpr int U = 8;
   const int vpr = C / 8;
   const int b = blockIdx.y;
   const int v = threadIdx.x % vpr, rph = threadIdx.x / vpr, nph = 256 / vpr;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(L, r0 + rows_per_block);   // rows_per_block == nph * U
+  const int rb = r0 + rph;
+  // 1. the activation rows do not depend on the statistics: get them moving first
+  float f[U][8], rr[U][8];
+#pragma unroll
+  for (int q = 0; q < U; ++q) {
+    const int r = rb + q * nph;
+    if (r < r1) {
+      const size_t off = ((size_t)b * L + r) * C + v * 8;
+      Vec8<T>::load(x, off, f[q]);
+      if (residual) Vec8<T>::load(residual, off, rr[q]);
+    }
+  }
+  // 2. per-channel affine of this item, once per workgroup
   const int cpg = C / groups;
   const float inv_n = 1.0f / ((float)L * (float)cpg);
   const float* ss = nullptr;
   if (ss_table) ss = ss_table + (size_t)(t_ptr ? *t_ptr : 0) * ss_stride;
-  float ca[8], cb[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = v * 8 + i;
+  for (int c = threadIdx.x; c < C; c += 256) {
     const int g = c / cpg;
     const float mean = stats[((size_t)b * groups + g) * 2] * inv_n;
     const float var = fmaxf(stats[((size_t)b * groups + g) * 2 + 1] * inv_n - mean * mean, 0.0f);
@@ -196,36 +210,30 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
       a1 *= sc;
       b1 = b1 * sc + ss[C + c];
     }
-    ca[i] = a1;
-    cb[i] = b1;
+    s_a[c] = a1;
+    s_b[c] = b1;
   }
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(L, r0 + rows_per_block);
-  // 4 rows per trip: all loads of a trip are issued before the first use (latency paid once per trip)
-  constexpr int U = 4;
-  for (int rb = r0 + rph; rb < r1; rb += nph * U) {
-    float f[U][8], rr[U][8];
+  __syncthreads();
+  float ca[8], cb[8];
+  {
+    const float4 a0 = *reinterpret_cast<const float4*>(&s_a[v * 8]), a1 = *reinterpret_cast<const float4*>(&s_a[v * 8 + 4]);
+    const float4 b0 = *reinterpret_cast<const float4*>(&s_b[v * 8]), b1 = *reinterpret_cast<const float4*>(&s_b[v * 8 + 4]);
+    ca[0] = a0.x; ca[1] = a0.y; ca[2] = a0.z; ca[3] = a0.w; ca[4] = a1.x; ca[5] = a1.y; ca[6] = a1.z; ca[7] = a1.w;
+    cb[0] = b0.x; cb[1] = b0.y; cb[2] = b0.z; cb[3] = b0.w; cb[4] = b1.x; cb[5] = b1.y; cb[6] = b1.z; cb[7] = b1.w;
+  }
+  // 3. apply and store
 #pragma unroll
-    for (int q = 0; q < U; ++q) {
-      const int r = rb + q * nph;
-      if (r < r1) {
-        const size_t off = ((size_t)b * L + r) * C + v * 8;
-        Vec8<T>::load(x, off, f[q]);
-        if (residual) Vec8<T>::load(residual, off, rr[q]);
+  for (int q = 0; q < U; ++q) {
+    const int r = rb + q * nph;
+    if (r < r1) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = act_f(fmaf(f[q][i], ca[i], cb[i]), act);
+      if (residual) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += rr[q][i];
       }
-    }
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-      const int r = rb + q * nph;
-      if (r < r1) {
-        float o[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = act_f(fmaf(f[q][i], ca[i], cb[i]), act);
-        if (residual) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] += rr[q][i];
-        }
-        Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
-      }
+      Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
     }
   }
 }
@@ -234,8 +242,8 @@ hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual,
                            const float* stats, const float* gamma, const float* beta, const float* ss_table,
                            int ss_stride, const int* t_ptr, int act, hipStream_t s) {
   const int vpr = C / 8;
-  if (C % 8 == 0 && vpr <= 256 && 256 % vpr == 0) {
-    int rpb = (int)std::max<size_t>(256 / vpr, (32 * 1024) / ((size_t)C * dt_size(dt)));
+  if (C % 8 == 0 && vpr <= 256 && 256 % vpr == 0 && C <= 2048) {
+    const int rpb = (256 / vpr) * 8;   // one 8-row trip per thread
     dim3 grid((L + rpb - 1) / rpb, B);
     if (dt == DT_F32)
       hipLaunchKernelGGL(gn_apply_cols_kernel<float>, grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats, gamma,

@@ -1,0 +1,179 @@
+"""`python -m srcs.sample` -- the synthesis CLI of the reference (srcs/sample.py:50-203) on the MI355X engine.
+
+Same flags, defaults and output naming as the reference.  What differs, by design:
+  * files are decoded in BATCHES of equal trimmed length (the reference walks them one by one,
+    sample.py:73); every utterance is normalised on its own, which is what the reference computes for
+    a mono file (its "batch" is the channel axis of one file, sample.py:85,129,133-134);
+  * `midway_t` (a literal 100 at sample.py:69) is a flag, `--midway_t`, default 100;
+  * under `torch.distributed.run` the file list is sharded over the ranks (one process per GPU).
+Flags that are inert in the reference stay accepted and inert (`--sampling_timesteps`,
+`--cond_enc_ratios`: quirk Q1, the cond codec is always built with ratios [8,5,4,2]).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+# (flag, kwargs) in the reference's order -- srcs/sample.py:141-198
+_FLAGS: List[Tuple[str, dict]] = [
+    ("--data_folder_path", dict(type=str, default="/data/hy17/librispeech/librispeech")),
+    ("--n_spks", dict(type=int, default=500)),
+    ("--seq_len_in_sec", dict(type=float, default=1.8)),
+    ("--sample_rate", dict(type=int, default=16000)),
+    ("--model_path", dict(type=str, default="")),
+    ("--qtzer_path", dict(type=str, default="")),
+    ("--note", dict(type=str, default="")),
+    ("--rep_dims", dict(type=int, default=128)),
+    ("--emb_dims", dict(type=int, default=128)),
+    ("--quantization", dict(dest="quantization", action="store_true")),
+    ("--bandwidth", dict(type=float, default=3.0)),
+    ("--n_filters", dict(type=int, default=32)),
+    ("--lstm", dict(type=int, default=2)),
+    ("--n_residual_layers", dict(type=int, default=1)),
+    ("--enc_ratios", dict(nargs="+", type=int, default=[8])),
+    ("--final_activation", dict(type=str, default=None)),
+    ("--run_diff", dict(dest="run_diff", action="store_true")),
+    ("--run_vae", dict(dest="run_vae", action="store_true")),
+    ("--train_time_diff", dict(dest="train_time_diff", action="store_true")),
+    ("--diff_dims", dict(type=int, default=256)),
+    ("--qtz_condition", dict(dest="qtz_condition", action="store_true")),
+    ("--self_condition", dict(dest="self_condition", action="store_true")),
+    ("--seq_length", dict(type=int, default=16000)),
+    ("--model_type", dict(type=str, default="unet")),
+    ("--scaling_frame", dict(dest="scaling_frame", action="store_true")),
+    ("--scaling_feature", dict(dest="scaling_feature", action="store_true")),
+    ("--scaling_global", dict(dest="scaling_global", action="store_true")),
+    ("--scaling_dim", dict(dest="scaling_dim", action="store_true")),
+    ("--sampling_timesteps", dict(type=int, default=1000)),
+    ("--use_film", dict(dest="use_film", action="store_true")),
+    ("--model_for_cond", dict(type=str, default="")),
+    ("--upsampling_ratios", dict(nargs="+", type=int, default=[5, 4, 2])),
+    ("--cond_enc_ratios", dict(nargs="+", type=int, default=[8, 5, 4, 2])),
+    ("--cond_bandwidth", dict(type=float, default=3.0)),
+    ("--cond_global", dict(type=float, default=3.0)),
+    ("--unet_scale_cond", dict(dest="unet_scale_cond", action="store_true")),
+    ("--unet_scale_x", dict(dest="unet_scale_x", action="store_true")),
+    ("--input_dir", dict(type=str, default="")),
+    ("--output_dir", dict(type=str, default="outputs/")),
+]
+# additions of this implementation
+_EXTRA: List[Tuple[str, dict]] = [
+    ("--midway_t", dict(type=int, default=100, help="reverse-diffusion steps (literal 100 in the reference)")),
+    ("--dtype", dict(type=str, default="bf16", choices=["bf16", "f32"], help="UNet compute dtype on the GPU")),
+    ("--batch_size", dict(type=int, default=32, help="utterances decoded per engine call")),
+]
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Encodec_baseline")
+    for flag, kw in _FLAGS + _EXTRA:
+        p.add_argument(flag, **kw)
+    return p
+
+
+def _unsupported(a) -> None:
+    bad = [n for n in ("train_time_diff", "self_condition", "qtz_condition", "use_film", "run_vae", "unet_scale_x") if getattr(a, n)]
+    if bad:
+        raise SystemExit(f"flags {bad} select paths outside the decode path this implementation covers (SURVEY.md section 8)")
+    if a.model_type != "unet":
+        raise SystemExit("only --model_type unet is supported")
+    if not a.model_for_cond:
+        raise SystemExit("--model_for_cond is required: halfway sampling starts from the quantised condition (sample.py:125-130)")
+    if a.final_activation is not None:
+        raise SystemExit("--final_activation is not supported")
+
+
+def read_wav_16k(path: str) -> np.ndarray:
+    """-> float32 [channels, T] at 16 kHz (torchaudio.load + functional.resample in the reference, sample.py:83-84)."""
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+    sr, x = wavfile.read(path)
+    if x.dtype.kind == "i":
+        x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
+    elif x.dtype.kind == "u":
+        x = (x.astype(np.float32) - 128.0) / 128.0
+    x = x.astype(np.float32)
+    x = x[None, :] if x.ndim == 1 else x.T
+    if sr != 16000:
+        g = int(np.gcd(int(sr), 16000))
+        x = resample_poly(x, 16000 // g, int(sr) // g, axis=1).astype(np.float32)
+    return x
+
+
+def output_path(wav_file: str, input_dir: str, output_dir: str) -> str:
+    """sample.py:75-81,136: save_path = output_dir + wav_file[len(input_dir):][:-4]; file = save_path + '.wav'."""
+    local_path = wav_file[len(input_dir):][:-4]
+    save_path = output_dir + local_path
+    return os.path.join(output_dir, f"{save_path}.wav")
+
+
+def synthesis(inp_args) -> List[str]:
+    import torch
+    from scipy.io import wavfile
+
+    from . import checkpoint, lib as L, parallel
+    from .model import Engine
+    from .spec import CodecConfig, UnetConfig
+
+    _unsupported(inp_args)
+    rank, local_rank, world = parallel.init_process_group("nccl")
+    main_codec = CodecConfig(rep_dims=inp_args.rep_dims, n_filters=inp_args.n_filters,
+                             n_residual_layers=inp_args.n_residual_layers, lstm=inp_args.lstm,
+                             enc_ratios=tuple(inp_args.enc_ratios), quantization=False)
+    cond_codec = CodecConfig(rep_dims=inp_args.rep_dims, n_filters=inp_args.n_filters,
+                             n_residual_layers=inp_args.n_residual_layers, lstm=inp_args.lstm,
+                             enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=inp_args.cond_bandwidth)   # quirk Q1
+    unet = UnetConfig(dim=inp_args.diff_dims, inp_channels=inp_args.rep_dims, upsampling_ratios=tuple(inp_args.upsampling_ratios),
+                      unet_scale_cond=inp_args.unet_scale_cond, unet_scale_x=inp_args.unet_scale_x)
+    eng = Engine(main_codec, unet, cond_codec, dtype=inp_args.dtype, device=local_rank)
+    eng.load_state_dict(L.MODEL_MAIN, checkpoint.read_amlt(inp_args.model_path))       # load_model(model, path, strict=True)
+    eng.load_state_dict(L.MODEL_COND, checkpoint.read_amlt(inp_args.model_for_cond))
+    eng.finalize(strict=True)
+
+    files = sorted(glob.glob(os.path.join(inp_args.input_dir, "**/*.wav"), recursive=True))
+    items: List[Tuple[str, int, np.ndarray]] = []      # (file, channel, samples)
+    for f in files:
+        wav = read_wav_16k(f)
+        length = wav.shape[-1] // 640 * 640                                              # sample.py:87-88
+        if length == 0:
+            continue
+        for ch in range(wav.shape[0]):
+            items.append((f, ch, wav[ch, :length]))
+    mine = parallel.shard_utterances([len(it[2]) for it in items], rank, world)
+    by_len: Dict[int, List[int]] = {}
+    for i in mine:
+        by_len.setdefault(len(items[i][2]), []).append(i)
+    decoded: Dict[int, np.ndarray] = {}
+    for length, idxs in sorted(by_len.items(), reverse=True):
+        for s in range(0, len(idxs), inp_args.batch_size):
+            chunk = idxs[s:s + inp_args.batch_size]
+            batch = torch.from_numpy(np.stack([items[i][2] for i in chunk])[:, None, :])
+            out = eng.decode(batch.cuda(local_rank), inp_args.midway_t, noise=None, per_item=True)
+            out = out.cpu().numpy()
+            for k, i in enumerate(chunk):
+                decoded[i] = out[k, 0]
+    written = []
+    per_file: Dict[str, List[Tuple[int, np.ndarray]]] = {}
+    for i, y in decoded.items():
+        per_file.setdefault(items[i][0], []).append((items[i][1], y))
+    for f, chans in per_file.items():
+        path = output_path(f, inp_args.input_dir, inp_args.output_dir)
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        chans.sort()
+        data = np.stack([y for _, y in chans], axis=1)
+        wavfile.write(path, 16000, data[:, 0] if data.shape[1] == 1 else data)
+        written.append(path)
+    eng.close()
+    return written
+
+
+def main(argv=None):
+    synthesis(build_parser().parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()

@@ -230,3 +230,33 @@ def test_error_behaviour():
     with pytest.raises(L.LdcError, match="final_conv.bias"):   # strict load names the missing key
         bad.finalize(strict=True)
     bad.close()
+
+
+def test_cli_synthesis_end_to_end(tmp_path):
+    """`python -m srcs.sample`-equivalent run: .amlt checkpoints (one DDP-prefixed), wav files in a tree,
+    batching by length; with --midway_t 1 the sampler draws no noise (t = 0), so the written audio must equal
+    the oracle's decode of the same file."""
+    from scipy.io import wavfile
+    from ladiffcodec_amd import sample as cli
+    mc, u, seed = CASES["r84"]
+    synth.save_amlt(main_sd_np("r84"), str(tmp_path / "ladiff.amlt"), ddp_prefix=True)
+    synth.save_amlt(cond_sd_np(), str(tmp_path / "codec.amlt"))
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    (ind / "spk1").mkdir(parents=True)
+    wavs = {"spk1/a.wav": synth.synthetic_wav(1, 5120 + 100, seed=1)[0, 0], "spk1/b.wav": synth.synthetic_wav(1, 5120, seed=2)[0, 0],
+            "c.wav": synth.synthetic_wav(1, 3840, seed=3)[0, 0]}
+    for name, x in wavs.items():
+        wavfile.write(str(ind / name), 16000, (x * 0.5).astype(np.float32))
+    args = cli.build_parser().parse_args([
+        "--model_for_cond", str(tmp_path / "codec.amlt"), "--model_path", str(tmp_path / "ladiff.amlt"), "--run_diff",
+        "--scaling_global", "--cond_bandwidth", "3", "--unet_scale_cond", "--enc_ratios", "8", "4", "--upsampling_ratios", "5", "2",
+        "--diff_dims", "32", "--input_dir", str(ind) + "/", "--output_dir", str(outd) + "/", "--midway_t", "1", "--dtype", "f32"])
+    written = cli.synthesis(args)
+    assert len(written) == 3
+    sd_c, sd_m = synth.to_torch(cond_sd_np()), synth.to_torch(main_sd_np("r84"))
+    for name, x in wavs.items():
+        sr, y = wavfile.read(str(outd / name))
+        n = len(x) // 640 * 640
+        assert sr == 16000 and y.shape == (n,) and y.dtype == np.float32
+        ref = O.decode_utterances(sd_c, COND_CFG, sd_m, mc, u, T((x[:n] * 0.5).astype(np.float32)).reshape(1, 1, n), 1, None)
+        assert rel(y, ref["wav"].numpy().reshape(-1)) < 5e-3, name
