@@ -155,6 +155,8 @@ int ldc_unet_step_cost(ldc_ctx* ctx, int B, int L, double* flops, double* bytes)
 int ldc_profile_enable(ldc_ctx* ctx, int on);
 /* Tuning aid: times `iters` launches of one conv-GEMM (random weights/inputs) of the given shape with
  * hipEvents on the context's stream; dtype LDC_F32 | LDC_BF16; ups = 1 folds nearest x2 upsampling. */
+/* Tuning aid: times the GroupNorm-apply kernel on [B,L,C] (random data, fixed statistics). */
+int ldc_gn_microbench(ldc_ctx* ctx, int dtype, int B, int L, int C, int with_residual, int iters, double* ms_per_launch);
 int ldc_conv_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups,
                         int iters, double* ms_per_launch);
 int ldc_profile_read(ldc_ctx* ctx, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);

@@ -2,6 +2,7 @@
 // conv_fast.hip: LDS-DMA pipelined fast path).
 #pragma once
 #include "ldc_kernels.h"
+#include "ldc_math.h"
 
 namespace ldc {
 
@@ -39,9 +40,9 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
-    case ACT_SILU: return v / (1.0f + __expf(-v));
-    case ACT_ELU: return v > 0.0f ? v : (expm1f(v));
-    case ACT_TANH: return tanhf(v);
+    case ACT_SILU: return fast_silu(v);
+    case ACT_ELU: return fast_elu(v);
+    case ACT_TANH: return fast_tanh(v);
     case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     default: return v;
   }
@@ -270,7 +271,8 @@ __device__ __forceinline__ void epilogue_rows_dispatch(const ConvKArgs& a, f32x1
   }
 }
 
-// conv_fast.hip
+// conv_fast_{bf16,f32}.hip
+extern unsigned long long* g_conv_stamps;   // tuning aid, set by ldc_conv_microbench when LDC_CONV_STAMPS is on
 bool conv_fast_eligible(const ConvLayer& ly);
 hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, hipStream_t s, bool* launched);
 

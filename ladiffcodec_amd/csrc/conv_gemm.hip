@@ -38,7 +38,7 @@ template <>
 __device__ __forceinline__ uint4 elu16<float>(uint4 v) {
   float* f = reinterpret_cast<float*>(&v);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) f[i] = f[i] > 0.0f ? f[i] : expm1f(f[i]);
+  for (int i = 0; i < 4; ++i) f[i] = fast_elu(f[i]);
   return v;
 }
 template <>
@@ -48,8 +48,8 @@ __device__ __forceinline__ uint4 elu16<__bf16>(uint4 v) {
   for (int i = 0; i < 4; ++i) {
     float lo = bf16_to_f32((unsigned short)(u[i] & 0xffffu));
     float hi = bf16_to_f32((unsigned short)(u[i] >> 16));
-    lo = lo > 0.0f ? lo : expm1f(lo);
-    hi = hi > 0.0f ? hi : expm1f(hi);
+    lo = fast_elu(lo);
+    hi = fast_elu(hi);
     u[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
   }
   return v;

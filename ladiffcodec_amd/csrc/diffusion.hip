@@ -250,6 +250,14 @@ __global__ void step_set_kernel(int* st, int t, int j) {
   st[0] = t;
   st[1] = j;
 }
+__global__ __launch_bounds__(256) void step_begin_kernel(const float* table, int stride, const int* st, float* cur) {
+  const float* row = table + (size_t)st[0] * stride;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < stride; i += gridDim.x * 256) cur[i] = row[i];
+}
+hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, hipStream_t s) {
+  hipLaunchKernelGGL(step_begin_kernel, dim3(std::max(1, std::min(64, (stride + 255) / 256))), dim3(256), 0, s, table, stride, st, cur);
+  return hipGetLastError();
+}
 hipError_t launch_step_advance(int* st, hipStream_t s) {
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, st);
   return hipGetLastError();

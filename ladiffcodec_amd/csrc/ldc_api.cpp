@@ -163,6 +163,7 @@ struct UnetW {
   std::vector<ConvLayer> upsamplers;
   std::vector<int> up_ratios;
   float* ss_table = nullptr;    // [T][ss_stride] fp32
+  float* cur_ss = nullptr;      // [ss_stride]: the row of the step being executed (launch_step_begin)
   int ss_stride = 0;
   int timesteps = 1000;
   double weight_elems = 0;
@@ -757,6 +758,8 @@ static int build_time_table(ldc_ctx* c, WeightReader& wr) {
   LDCCHK(tmp.alloc(&p, (size_t)T * td * 4)); d_h2 = (float*)p;
   LDCCHK(c->wmem.alloc(&p, (size_t)T * u.ss_stride * 4));
   u.ss_table = (float*)p;
+  LDCCHK(c->wmem.alloc(&p, (size_t)u.ss_stride * 4));
+  u.cur_ss = (float*)p;
   hipStream_t s = c->own_stream;
   ConvLayer l1, l2;
   ConvSpec sp;
@@ -1275,15 +1278,14 @@ struct PlanBuilder {
     void* out = act(rows, r.cout);
     float* st1 = next_stats();
     float* st2 = next_stats();
-    const int* tptr = c->step_state;
     const int cpg = r.cout / g;
     const bool fuse_stats = c->fuse_gn_stats && cpg >= 4 && (cpg & (cpg - 1)) == 0;
     conv(r.c1, x1, x2, a, nullptr, L, L, fuse_stats ? st1 : nullptr);
     const ResnetW* rp = &r;
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
     add([=](hipStream_t s) {
-      return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, u->ss_table + rp->ss_off,
-                             u->ss_stride, tptr, ACT_SILU, s);
+      return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, u->cur_ss + rp->ss_off,
+                             0, nullptr, ACT_SILU, s);
     });
     conv(r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
@@ -1521,6 +1523,7 @@ extern "C" int ldc_unet_forward(ldc_ctx* c, const float* x, int t, const float* 
   LDCCHK(load_cond(c, h, cond, s));
   LDCCHK(load_x(c, h, x, s));
   HIPCHK(launch_step_set(c->step_state, t, 0, s));
+  HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, c->step_state, c->unet.cur_ss, s));
   for (int k = 0; k < h.n; ++k) {
     Plan* pl = h.p[k];
     LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
@@ -1562,6 +1565,7 @@ static int half_step(ldc_ctx* c, const Halves& h, int k, float* x, const float* 
 // one reverse-diffusion step for the whole batch; two halves fork onto the auxiliary stream and join again
 // (valid eagerly and under stream capture: the event edges become graph dependencies)
 static int one_step(ldc_ctx* c, const Halves& h, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
+  HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, c->step_state, c->unet.cur_ss, s));
   if (h.n >= 2 && !c->profile) {
     HIPCHK(hipEventRecord(c->ev_fork, s));
     for (int k = 1; k < h.n; ++k) HIPCHK(hipStreamWaitEvent(c->aux_stream[k], c->ev_fork, 0));
@@ -1968,5 +1972,36 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     }
     if (n) fprintf(stderr, "  stamps (100 MHz ticks): blocks=%d prologue=%.1f loop=%.1f epilogue=%.1f  kernel span=%.1f\n", n, pro / n, loop / n, epi / n, (double)(tmax - tmin));
   }
+  return LDC_OK;
+}
+
+extern "C" int ldc_gn_microbench(ldc_ctx* c, int dtype, int B, int L, int C, int with_residual, int iters, double* ms_per_launch) {
+  if (!c || !ms_per_launch || iters < 1) return fail(LDC_E_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  const int dt = dtype == LDC_BF16 ? DT_BF16 : DT_F32;
+  const size_t es = dt_size(dt), n = (size_t)B * L * C;
+  DevMem keep;
+  void *x = nullptr, *y = nullptr, *r = nullptr, *st = nullptr, *gb = nullptr;
+  LDCCHK(keep.alloc(&x, n * es)); LDCCHK(keep.alloc(&y, n * es)); LDCCHK(keep.alloc(&r, n * es));
+  LDCCHK(keep.alloc(&st, (size_t)B * 8 * 2 * 4)); LDCCHK(keep.alloc(&gb, (size_t)4 * C * 4));
+  HIPCHK(hipMemset(x, 0x3c, n * es)); HIPCHK(hipMemset(r, 0x3c, n * es));
+  std::vector<float> hs((size_t)B * 16, 1.0f), hg((size_t)4 * C, 0.5f);
+  for (size_t i = 0; i < hs.size(); i += 2) { hs[i] = 10.f; hs[i + 1] = 1e4f; }
+  HIPCHK(hipMemcpy(st, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(gb, hg.data(), hg.size() * 4, hipMemcpyHostToDevice));
+  float* g = (float*)gb;
+  hipStream_t s = c->own_stream;
+  auto go = [&]() { return launch_gn_apply(dt, x, y, with_residual ? r : nullptr, B, L, C, 8, (float*)st, g, g + C, g + 2 * C, 0, nullptr, ACT_SILU, s); };
+  for (int i = 0; i < 3; ++i) HIPCHK(go());
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) HIPCHK(go());
+  HIPCHK(hipEventRecord(e1, s));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / iters;
   return LDC_OK;
 }

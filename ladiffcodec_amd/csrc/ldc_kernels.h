@@ -115,6 +115,9 @@ hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const fl
 hipError_t launch_scale_by_maxabs(int dt, void* x, int B, int64_t n_per_item, const float* maxabs, int per_item,
                                   float eps, hipStream_t s);
 hipError_t launch_step_advance(int* st, hipStream_t s);      // t -= 1, j += 1
+// cur[0..stride) = table[st[0]][0..stride): the current timestep's scale/shift row, so that consumers need no
+// dependent load through the step counter
+hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, hipStream_t s);
 hipError_t launch_step_set(int* st, int t, int j, hipStream_t s);
 // output normalisation (sample.py:133-134); ws: double [B][2] + float [B] zeroed by the launcher
 hipError_t launch_output_normalise(float* x, int B, int64_t n_per_item, int per_item, void* ws, hipStream_t s);

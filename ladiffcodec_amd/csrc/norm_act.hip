@@ -5,7 +5,10 @@
 // channel LayerNorm (:82-91) used by PreNorm (:93-101) and LinearAttention.to_out (:203-206), and
 // the tanh before final_conv (:467).  All are HBM-bound streaming kernels over channels-last rows:
 // algorithmic bytes = (reads + writes) * rows * C * sizeof(dtype).
+#include <stdlib.h>
+
 #include "ldc_kernels.h"
+#include "ldc_math.h"
 
 namespace ldc {
 
@@ -54,9 +57,9 @@ struct Vec8<__bf16> {
 
 __device__ __forceinline__ float act_f(float v, int act) {
   switch (act) {
-    case ACT_SILU: return v / (1.0f + __expf(-v));
-    case ACT_ELU: return v > 0.0f ? v : expm1f(v);
-    case ACT_TANH: return tanhf(v);
+    case ACT_SILU: return fast_silu(v);
+    case ACT_ELU: return fast_elu(v);
+    case ACT_TANH: return fast_tanh(v);
     case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     default: return v;
   }
@@ -169,11 +172,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x, void* y, c
 // Fast variant: grid (row chunks, B).  The per-channel affine of this item (mean, rstd, gamma, beta and the
 // timestep scale/shift folded into a*x+b) is built once per workgroup in LDS; a thread then keeps ONE 8-channel
 // column and streams U rows with all loads in flight before the first use.  Needs C/8 to divide 256, C <= 2048.
-template <typename T>
+template <typename T, int ACT>   // ACT >= 0: compile-time activation; -1: runtime `act`
 __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void* y, const void* residual, int L, int C,
                                                             int groups, int rows_per_block, const float* stats,
                                                             const float* gamma, const float* beta, const float* ss_table,
-                                                            int ss_stride, const int* t_ptr, int act) {
+                                                            int ss_stride, const int* t_ptr, int act, int dbg) {
   __shared__ __attribute__((aligned(16))) float s_a[2048];
   __shared__ __attribute__((aligned(16))) float s_b[2048];
   constexpr int U = 8;
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
   const float* ss = nullptr;
   if (ss_table) ss = ss_table + (size_t)(t_ptr ? *t_ptr : 0) * ss_stride;
   for (int c = threadIdx.x; c < C; c += 256) {
+    if (dbg & 1) { s_a[c] = 1.0f; s_b[c] = 0.5f; continue; }
     const int g = c / cpg;
     const float mean = stats[((size_t)b * groups + g) * 2] * inv_n;
     const float var = fmaxf(stats[((size_t)b * groups + g) * 2 + 1] * inv_n - mean * mean, 0.0f);
@@ -228,12 +232,16 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
     if (r < r1) {
       float o[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = act_f(fmaf(f[q][i], ca[i], cb[i]), act);
+      for (int i = 0; i < 8; ++i) {
+        const float lin = fmaf(f[q][i], ca[i], cb[i]);
+        o[i] = (dbg & 2) ? lin : (ACT == ACT_SILU ? fast_silu(lin) : act_f(lin, act));
+      }
       if (residual) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] += rr[q][i];
       }
-      Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
+      if (!(dbg & 4)) Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
+      else if (o[0] == 12345.678f) Vec8<T>::store(y, 0, o);
     }
   }
 }
@@ -244,13 +252,21 @@ hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual,
   const int vpr = C / 8;
   if (C % 8 == 0 && vpr <= 256 && 256 % vpr == 0 && C <= 2048) {
     const int rpb = (256 / vpr) * 8;   // one 8-row trip per thread
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("LDC_GN_DEBUG") ? atoi(getenv("LDC_GN_DEBUG")) : 0;
     dim3 grid((L + rpb - 1) / rpb, B);
-    if (dt == DT_F32)
-      hipLaunchKernelGGL(gn_apply_cols_kernel<float>, grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats, gamma,
-                         beta, ss_table, ss_stride, t_ptr, act);
+    if (dt == DT_F32 && act == ACT_SILU)
+      hipLaunchKernelGGL((gn_apply_cols_kernel<float, ACT_SILU>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
+                         gamma, beta, ss_table, ss_stride, t_ptr, act, dbg);
+    else if (dt == DT_F32)
+      hipLaunchKernelGGL((gn_apply_cols_kernel<float, -1>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
+                         gamma, beta, ss_table, ss_stride, t_ptr, act, dbg);
+    else if (act == ACT_SILU)
+      hipLaunchKernelGGL((gn_apply_cols_kernel<__bf16, ACT_SILU>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
+                         gamma, beta, ss_table, ss_stride, t_ptr, act, dbg);
     else
-      hipLaunchKernelGGL(gn_apply_cols_kernel<__bf16>, grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
-                         gamma, beta, ss_table, ss_stride, t_ptr, act);
+      hipLaunchKernelGGL((gn_apply_cols_kernel<__bf16, -1>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
+                         gamma, beta, ss_table, ss_stride, t_ptr, act, dbg);
     return hipGetLastError();
   }
   const size_t total = (size_t)B * L * (C / 8);

@@ -244,7 +244,7 @@ def test_cli_synthesis_end_to_end(tmp_path):
     ind, outd = tmp_path / "in", tmp_path / "out"
     (ind / "spk1").mkdir(parents=True)
     wavs = {"spk1/a.wav": synth.synthetic_wav(1, 5120 + 100, seed=1)[0, 0], "spk1/b.wav": synth.synthetic_wav(1, 5120, seed=2)[0, 0],
-            "c.wav": synth.synthetic_wav(1, 3840, seed=3)[0, 0]}
+            "c.wav": synth.synthetic_wav(1, 2560, seed=3)[0, 0]}   # lengths: multiples of lcm(640, 32*16) so that L survives 4 halvings
     for name, x in wavs.items():
         wavfile.write(str(ind / name), 16000, (x * 0.5).astype(np.float32))
     args = cli.build_parser().parse_args([
