@@ -158,25 +158,31 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const void* qkv, void*
   }
 }
 
+size_t linattn_ws_floats_per_item(int heads, int dim_head) { return linattn_ws_per_item(heads, dim_head); }
+
+// kmax_fused: the caller zeroed `ws` before the qkv conv and that conv's epilogue already produced the column
+// maxima (conv_device.h epilogue_colmax)
 hipError_t launch_linattn(int dt, const void* qkv, void* out, float* ws, int B, int L, int heads, int dim_head,
-                          hipStream_t s) {
+                          bool kmax_fused, hipStream_t s) {
   if (dim_head != 32 || heads * dim_head > 256 || 256 % (heads * dim_head) || 256 % heads) return hipErrorInvalidValue;
   const int HD = heads * dim_head;
   const size_t wss = linattn_ws_per_item(heads, dim_head);
-  hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * wss * sizeof(float), s);
-  if (e != hipSuccess) return e;
+  if (!kmax_fused) {
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * wss * sizeof(float), s);
+    if (e != hipSuccess) return e;
+  }
   const int rpb = 128;
   const int chunks = (L + rpb - 1) / rpb;
   const float scale = 1.0f / sqrtf((float)dim_head);
   const size_t lds_out = (size_t)heads * (dim_head * dim_head + 8) * sizeof(float);
   const int rows_out = 256 / heads;
   if (dt == DT_F32) {
-    hipLaunchKernelGGL(linattn_kmax_kernel<float>, dim3(chunks, B), dim3(256), 0, s, qkv, ws, L, HD, rpb, wss);
+    if (!kmax_fused) hipLaunchKernelGGL(linattn_kmax_kernel<float>, dim3(chunks, B), dim3(256), 0, s, qkv, ws, L, HD, rpb, wss);
     hipLaunchKernelGGL((linattn_ctx_kernel<float, 32>), dim3(chunks, B * heads), dim3(256), 0, s, qkv, ws, L, heads, rpb, wss);
     hipLaunchKernelGGL((linattn_out_kernel<float, 32>), dim3((L + rows_out - 1) / rows_out, B), dim3(256), lds_out, s, qkv,
                        out, ws, L, heads, wss, scale);
   } else {
-    hipLaunchKernelGGL(linattn_kmax_kernel<__bf16>, dim3(chunks, B), dim3(256), 0, s, qkv, ws, L, HD, rpb, wss);
+    if (!kmax_fused) hipLaunchKernelGGL(linattn_kmax_kernel<__bf16>, dim3(chunks, B), dim3(256), 0, s, qkv, ws, L, HD, rpb, wss);
     hipLaunchKernelGGL((linattn_ctx_kernel<__bf16, 32>), dim3(chunks, B * heads), dim3(256), 0, s, qkv, ws, L, heads, rpb, wss);
     hipLaunchKernelGGL((linattn_out_kernel<__bf16, 32>), dim3((L + rows_out - 1) / rows_out, B), dim3(256), lds_out, s,
                        qkv, out, ws, L, heads, wss, scale);

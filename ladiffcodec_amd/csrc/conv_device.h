@@ -28,6 +28,8 @@ struct ConvKArgs {
   int reflect_back, reflect_fwd;
   float* gn_sum;       // fused GroupNorm statistics target [B][gn_groups][2] (pre-zeroed) or null
   int gn_groups, gn_cpg;
+  unsigned* colmax;    // fused column max over positions (LinearAttention k softmax): ordered-uint keys, pre-zeroed
+  int colmax_lo, colmax_hi, colmax_stride;   // columns [lo, hi) -> colmax[b * stride + col - lo]
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -145,6 +147,46 @@ __device__ __forceinline__ void epilogue_plain(const ConvKArgs& a, f32x16 (&acc)
   }
 }
 
+// order-preserving float -> uint key: atomicMax(unsigned) from a zeroed buffer implements a float max
+__device__ __forceinline__ unsigned float_order_key(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// Fused column max per item of the stored (dtype-rounded) conv output, columns [colmax_lo, colmax_hi): the
+// max over positions that LinearAttention's k.softmax(dim=-1) needs (unet.py:214), so that no extra pass over
+// the qkv tensor is required for it.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void epilogue_colmax(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int m0, int BM,
+                                                int M) {
+  const int lane = threadIdx.x & 63;
+  const int b_first = m0 / a.L_rows;
+  const int b_last = (min(m0 + BM, M) - 1) / a.L_rows;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + j * 32;
+    const bool in = col >= a.colmax_lo && col < a.colmax_hi;     // uniform over the 32 lanes of a sub-tile
+    const float bv = (a.bias && col < a.n) ? a.bias[col] : 0.0f;
+    for (int bb = b_first; bb <= b_last; ++bb) {
+      const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (m >= lo && m < hi) {
+            float v = acc[i][j][r] + bv;
+            if (sizeof(T) == 2) v = bf16_to_f32(f32_to_bf16(v));
+            mx = fmaxf(mx, v);
+          }
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (in && lane < 32 && mx > -INFINITY) atomicMax(a.colmax + (size_t)bb * a.colmax_stride + (col - a.colmax_lo), float_order_key(mx));
+    }
+  }
+}
+
 // Fused GroupNorm statistics (unet.py:142-147 normalises the conv output): every wave adds the sum and the sum
 // of squares of (acc + bias) per (item, group) to gn_sum[b][g][2].  A lane owns one column per 32-wide sub-tile,
 // i.e. one group; lanes of a group are reduced with xor-shuffles (channels per group: a power of two >= 4 that
@@ -199,6 +241,7 @@ template <typename T, int TM, int TN>
 __device__ __forceinline__ void epilogue_dispatch(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M,
                                                   int m0 = 0, int BM = 0) {
   if (a.gn_sum) epilogue_gn_stats<TM, TN>(a, acc, mrow0, col0, m0, BM, M);
+  if (a.colmax) epilogue_colmax<T, TM, TN>(a, acc, mrow0, col0, m0, BM, M);
   if (a.residual) {
     if (a.post_act == ACT_NONE) epilogue_plain<T, TM, TN, true, false>(a, acc, mrow0, col0, M);
     else epilogue_plain<T, TM, TN, true, true>(a, acc, mrow0, col0, M);
@@ -262,6 +305,7 @@ __device__ __forceinline__ void epilogue_rows_dispatch(const ConvKArgs& a, f32x1
                                                        int col_wave0, int M, int m0, int BM) {
   const int lane = threadIdx.x & 63;
   if (a.gn_sum) epilogue_gn_stats<TM, TN>(a, acc, m_wave0 + 4 * (lane >> 5), col_wave0 + (lane & 31), m0, BM, M);
+  if (a.colmax) epilogue_colmax<T, TM, TN>(a, acc, m_wave0 + 4 * (lane >> 5), col_wave0 + (lane & 31), m0, BM, M);
   if (a.residual) {
     if (a.post_act == ACT_NONE) epilogue_rows<T, TM, TN, true, false>(a, acc, wave_lds, m_wave0, col_wave0, M);
     else epilogue_rows<T, TM, TN, true, true>(a, acc, wave_lds, m_wave0, col_wave0, M);

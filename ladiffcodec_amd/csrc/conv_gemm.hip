@@ -306,6 +306,8 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   a.tr_stride = ly.tr_stride; a.tr_cout = ly.tr_cout; a.tr_trim_left = ly.tr_trim_left;
   a.tg = 1; a.win_rows = 0;
   a.gn_sum = nullptr; a.gn_groups = 0; a.gn_cpg = 1;
+  a.colmax = c.colmax; a.colmax_lo = c.colmax_lo; a.colmax_hi = c.colmax_hi; a.colmax_stride = c.colmax_stride;
+  if (ly.tr_stride) a.colmax = nullptr;
   if (c.gn_sum && c.gn_groups > 0 && !ly.tr_stride) {
     const int cpg = ly.n / c.gn_groups;
     const bool pow2 = cpg >= 4 && (cpg & (cpg - 1)) == 0;

@@ -181,6 +181,8 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
   std::vector<std::function<hipError_t(hipStream_t)>> cond_ops;   // process_cond (once per denoise)
   std::vector<std::function<hipError_t(hipStream_t)>> step_ops;   // Unet1D.forward after process_cond
   std::vector<int> step_is_conv;                                   // 1 where step_ops[i] is a conv-GEMM launch
+  std::vector<int> step_where;                                     // 0 main stream, 1 side stream, 2 fork, 3 join
+  std::vector<hipEvent_t> marker_events;                           // one event per fork/join marker (no re-use inside a capture)
   std::vector<double> step_flops;
   struct Tap { void* p; int C; int L; };
   std::map<std::string, Tap> taps;
@@ -221,6 +223,10 @@ struct ldc_ctx {
   hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int split_batch = 2;
+  hipStream_t side_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_side_fork[kMaxParts] = {nullptr, nullptr, nullptr, nullptr}, ev_side_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
+  int side_streams = 0;
+  int fuse_kmax = 1;
   int fuse_gn_stats = 1;
   std::vector<void*> plan_mem;
   // scratch arena for codec stages and boundary buffers
@@ -831,8 +837,18 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->aux_stream[k], hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
   }
+  for (int k = 0; k < kMaxParts; ++k) {
+    HIPCHK(hipStreamCreateWithFlags(&c->side_stream[k], hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_side_fork[k], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_side_join[k], hipEventDisableTiming));
+  }
+  // res_conv on a side stream (off the conv->norm->conv chain).  Only without the batch split: a fork inside an
+  // already forked stream (or cross edges between sibling streams) crashes stream capture on ROCm 7.2, and the
+  // two-way batch split is worth more (+9 % vs +3 %).
+  c->side_streams = (getenv("LDC_SIDE") && c->split_batch == 1) ? 1 : 0;
   c->split_batch = getenv("LDC_NO_SPLIT") ? 1 : (getenv("LDC_SPLIT") ? std::max(1, std::min(kMaxParts, atoi(getenv("LDC_SPLIT")))) : 2);
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
+  c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, 2 * sizeof(int)));
   c->step_state = (int*)p;
@@ -844,6 +860,8 @@ static void drop_plans(ldc_ctx* c) {
   for (auto& g : c->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   c->graphs.clear();
+  for (auto& pl : c->plans)
+    for (hipEvent_t e : pl->marker_events) (void)hipEventDestroy(e);
   c->plans.clear();
   for (void* p : c->plan_mem) (void)hipFree(p);
   c->plan_mem.clear();
@@ -862,6 +880,11 @@ extern "C" int ldc_destroy(ldc_ctx* c) {
   for (int k = 1; k < kMaxParts; ++k) {
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
     if (c->aux_stream[k]) (void)hipStreamDestroy(c->aux_stream[k]);
+  }
+  for (int k = 0; k < kMaxParts; ++k) {
+    if (c->ev_side_fork[k]) (void)hipEventDestroy(c->ev_side_fork[k]);
+    if (c->ev_side_join[k]) (void)hipEventDestroy(c->ev_side_join[k]);
+    if (c->side_stream[k]) (void)hipStreamDestroy(c->side_stream[k]);
   }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -1250,17 +1273,26 @@ struct PlanBuilder {
     pl->act_bytes += (double)rows * C * es;
     return ar->alloc((size_t)rows * C * es);
   }
+  int where = 0;   // stream selector for the ops being added (0 main, 1 side)
+  void mark(int kind) {   // 2 = fork (side waits for main), 3 = join (main waits for side)
+    pl->step_ops.push_back([](hipStream_t) { return hipSuccess; });
+    pl->step_is_conv.push_back(0);
+    pl->step_where.push_back(kind);
+    pl->step_flops.push_back(0);
+  }
   void add(std::function<hipError_t(hipStream_t)> f, bool is_conv = false, double flops = 0) {
     pl->step_ops.push_back(std::move(f));
+    pl->step_where.push_back(where);
     pl->step_is_conv.push_back(is_conv ? 1 : 0);
     pl->step_flops.push_back(flops);
     pl->flops += flops;
   }
   void conv(const ConvLayer& ly, const void* x1, const void* x2, void* y, const void* residual, int L_in, int L_out,
-            float* gn_sum = nullptr) {
+            float* gn_sum = nullptr, unsigned* colmax = nullptr, int cm_lo = 0, int cm_hi = 0, int cm_stride = 0) {
     ConvCall cc;
     cc.B = B; cc.L_in = L_in; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.residual = residual; cc.y_ld = ly.n;
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
+    cc.colmax = colmax; cc.colmax_lo = cm_lo; cc.colmax_hi = cm_hi; cc.colmax_stride = cm_stride;
     const ConvLayer* lp = &ly;
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out);
   }
@@ -1280,6 +1312,16 @@ struct PlanBuilder {
     float* st2 = next_stats();
     const int cpg = r.cout / g;
     const bool fuse_stats = c->fuse_gn_stats && cpg >= 4 && (cpg & (cpg - 1)) == 0;
+    // the 1x1 res_conv only feeds the final add: it runs on the side stream, off the conv->norm->conv chain
+    const void* res = x1;
+    if (r.has_res) {
+      void* rr = act(rows, r.cout);
+      mark(2);
+      where = 1;
+      conv(r.res, x1, x2, rr, nullptr, L, L);
+      where = 0;
+      res = rr;
+    }
     conv(r.c1, x1, x2, a, nullptr, L, L, fuse_stats ? st1 : nullptr);
     const ResnetW* rp = &r;
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
@@ -1289,12 +1331,7 @@ struct PlanBuilder {
     });
     conv(r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
-    const void* res = x1;
-    if (r.has_res) {
-      void* rr = act(rows, r.cout);
-      conv(r.res, x1, x2, rr, nullptr, L, L);
-      res = rr;
-    }
+    if (r.has_res) mark(3);
     add([=](hipStream_t s) {
       return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s);
     });
@@ -1311,13 +1348,21 @@ struct PlanBuilder {
     const LinAttnW* ap = &a;
     float* ws = linattn_ws;
     add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s); });
-    conv(a.qkv, xn, nullptr, qkv, nullptr, L, L);
     if (linear) {
-      add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, s); });
+      const size_t wss = linattn_ws_floats_per_item(H, Dh);
+      if (c->fuse_kmax) {
+        add([=](hipStream_t s) { return hipMemsetAsync(ws, 0, (size_t)Bn * wss * sizeof(float), s); });
+        conv(a.qkv, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
+        add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, true, s); });
+      } else {
+        conv(a.qkv, xn, nullptr, qkv, nullptr, L, L);
+        add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, false, s); });
+      }
       void* t = act(rows, a.dim);
       conv(a.out, o, nullptr, t, nullptr, L, L);
       add([=](hipStream_t s) { return launch_ln_rows(dt, t, out, x, ap->out_g, rows, ap->dim, s); });
     } else {
+      conv(a.qkv, xn, nullptr, qkv, nullptr, L, L);
       add([=](hipStream_t s) { return launch_attn_full(dt, qkv, o, Bn, L, H, Dh, s); });
       conv(a.out, o, nullptr, out, x, L, L);   // + x in the epilogue
     }
@@ -1328,7 +1373,7 @@ struct PlanBuilder {
 static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const UnetW& u = c->unet;
   pl->B = B; pl->L = L; pl->F = F;
-  pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_flops.clear(); pl->taps.clear();
+  pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_where.clear(); pl->step_flops.clear(); pl->taps.clear();
   pl->flops = 0; pl->act_bytes = 0;
   const int dt = c->dt;
   const size_t es = dt_size(dt);
@@ -1467,15 +1512,46 @@ static int get_halves(ldc_ctx* c, int B, int L, int F, hipStream_t s, Halves* h)
 
 static int run_ops(ldc_ctx* c, Plan* pl, const std::vector<std::function<hipError_t(hipStream_t)>>& ops, bool is_step,
                    hipStream_t s) {
+  const bool use_side = is_step && !c->profile && c->side_streams;
+  hipStream_t side = c->side_stream[pl->slot];
+  if (use_side && pl->marker_events.empty()) {
+    size_t nm = 0;
+    for (int w : pl->step_where) nm += (w >= 2);
+    for (size_t k = 0; k < nm; ++k) {
+      hipEvent_t e = nullptr;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      pl->marker_events.push_back(e);
+    }
+  }
+  size_t marker = 0;
   for (size_t i = 0; i < ops.size(); ++i) {
     const bool prof = c->profile && is_step && pl->step_is_conv[i];
+    const int where = is_step ? pl->step_where[i] : 0;
+    if (where == 2) {
+      if (use_side) {
+        hipEvent_t e = pl->marker_events[marker];
+        HIPCHK(hipEventRecord(e, s));
+        HIPCHK(hipStreamWaitEvent(side, e, 0));
+      }
+      ++marker;
+      continue;
+    }
+    if (where == 3) {
+      if (use_side) {
+        hipEvent_t e = pl->marker_events[marker];
+        HIPCHK(hipEventRecord(e, side));
+        HIPCHK(hipStreamWaitEvent(s, e, 0));
+      }
+      ++marker;
+      continue;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {
       HIPCHK(hipEventCreate(&e0));
       HIPCHK(hipEventCreate(&e1));
       HIPCHK(hipEventRecord(e0, s));
     }
-    HIPCHK(ops[i](s));
+    HIPCHK(ops[i]((use_side && where == 1) ? side : s));
     if (prof) {
       HIPCHK(hipEventRecord(e1, s));
       c->prof_events.push_back({e0, e1});
@@ -1569,6 +1645,7 @@ static int one_step(ldc_ctx* c, const Halves& h, float* x, const float* noise, i
   if (h.n >= 2 && !c->profile) {
     HIPCHK(hipEventRecord(c->ev_fork, s));
     for (int k = 1; k < h.n; ++k) HIPCHK(hipStreamWaitEvent(c->aux_stream[k], c->ev_fork, 0));
+
     LDCCHK(half_step(c, h, 0, x, noise, noise_stride, s));
     for (int k = 1; k < h.n; ++k) {
       LDCCHK(half_step(c, h, k, x, noise, noise_stride, c->aux_stream[k]));

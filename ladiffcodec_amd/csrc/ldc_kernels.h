@@ -51,6 +51,8 @@ struct ConvCall {
   int y_ld = 0;               // channels per output row
   float* gn_sum = nullptr;    // optional fused GroupNorm statistics: [B][groups][2] (sum, sumsq), pre-zeroed
   int gn_groups = 0;
+  unsigned* colmax = nullptr; // optional fused per-item column max, columns [colmax_lo, colmax_hi), pre-zeroed keys
+  int colmax_lo = 0, colmax_hi = 0, colmax_stride = 0;
 };
 
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
@@ -82,7 +84,8 @@ hipError_t launch_act(int dt, const void* x, void* y, int64_t n, int act, hipStr
 // ------------------------------------------------------------------------------------------------
 // qkv [B*L][3*H*D] (q | k | v, head-major).  ctx_ws: fp32 [B][H][D][D].
 hipError_t launch_linattn(int dt, const void* qkv, void* out, float* ctx_ws, int B, int L, int heads, int dim_head,
-                          hipStream_t s);
+                          bool kmax_fused, hipStream_t s);
+size_t linattn_ws_floats_per_item(int heads, int dim_head);
 hipError_t launch_attn_full(int dt, const void* qkv, void* out, int B, int L, int heads, int dim_head, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
