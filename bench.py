@@ -136,22 +136,21 @@ def main():
 
     def step():
         out = eng.decode(wav, N, noise=None, per_item=True)
-        if world > 1:
-            parallel.gather_results(out, world)
+        parallel.gather_results(out, world)      # RCCL all_gather of the decoded waveforms (no-op without a process group)
         return out
 
     for i in range(args.warmup):
         step()
         torch.cuda.synchronize(dev)
         log(f"warmup {i} done")
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
     assert bool(torch.isfinite(out).all()), "non-finite output"
@@ -176,19 +175,35 @@ def main():
         ms, launches, flops = eng.profile_read()
         eng.profile(False)
         log(f"profile pass: {launches} conv launches, {ms:.1f} ms")
-        step_flops, step_bytes = eng.unet_step_cost(B, T // mc.hop_length)
+        # the engine decodes the batch as two halves (two streams): account the launches as they are issued
+        parts = [B // 2, B - B // 2] if B >= 2 else [B]
+        step_flops = step_bytes = 0.0
+        for pb in parts:
+            f_, b_ = eng.unet_step_cost(pb, T // mc.hop_length)
+            step_flops += f_
+            step_bytes += b_
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        result["roofline"] = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM Conv1d on MFMA)", "achieved": ach,
-                              "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+        if os.path.exists(tpath) and args.dtype == "bf16" and B == 32 and N == 50:
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+        convs_per_step = launches / max(1, N)
+        result["roofline"] = {"bound": "mfma", "kernel": "conv_fast_kernel / conv_gemm_kernel (implicit-GEMM Conv1d on MFMA)",
+                              "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                              "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                              "algorithmic_bytes_per_launch": step_bytes / max(1.0, convs_per_step),
+                              "algorithmic_flops_per_launch": flops / max(1, launches),
                               "launches": launches, "avg_launch_us": 1000.0 * ms / max(1, launches),
-                              "unet_step_gflop": step_flops / 1e9, "unet_step_algorithmic_gb": step_bytes / 1e9}
+                              "unet_step_gflop": step_flops / 1e9, "unet_step_conv_algorithmic_gb": step_bytes / 1e9}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cc, mc, u, sd_cond, sd_main, N, args.seconds, args.cpu_batch)
     if rank == 0:
         print(json.dumps(result), flush=True)
     eng.close()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -186,7 +186,7 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
   std::vector<double> step_flops;
   struct Tap { void* p; int C; int L; };
   std::map<std::string, Tap> taps;
-  double flops = 0, act_bytes = 0;
+  double flops = 0, act_bytes = 0, conv_bytes = 0;   // conv_bytes: inputs + outputs + packed weights of every conv-GEMM
 };
 
 // A batch is decoded as (up to) two independent halves on two streams: utterances do not interact inside
@@ -1294,6 +1294,7 @@ struct PlanBuilder {
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
     cc.colmax = colmax; cc.colmax_lo = cm_lo; cc.colmax_hi = cm_hi; cc.colmax_stride = cm_stride;
     const ConvLayer* lp = &ly;
+    pl->conv_bytes += ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n) * es + (double)conv_packed_weight_bytes(ly);
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out);
   }
   float* next_stats() {
@@ -1374,7 +1375,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const UnetW& u = c->unet;
   pl->B = B; pl->L = L; pl->F = F;
   pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_where.clear(); pl->step_flops.clear(); pl->taps.clear();
-  pl->flops = 0; pl->act_bytes = 0;
+  pl->flops = 0; pl->act_bytes = 0; pl->conv_bytes = 0;
   const int dt = c->dt;
   const size_t es = dt_size(dt);
   const int Cc = u.cond_channels, Cx = u.channels;
@@ -1944,11 +1945,9 @@ extern "C" int ldc_unet_step_cost(ldc_ctx* c, int B, int L, double* flops, doubl
   if (flops) *flops = tmp.flops;
   // algorithmic bytes with perfect intra-block fusion: every conv-boundary activation
   // read + written once, the weights once per step
-  if (bytes) {
-    double conv_act = 0;
-    (void)conv_act;
-    *bytes = c->unet.weight_elems * dt_size(c->dt) + tmp.act_bytes;
-  }
+  // algorithmic bytes of the conv-GEMM launches of one step: every conv reads its input(s) and packed weights once
+  // and writes its output once
+  if (bytes) *bytes = tmp.conv_bytes;
   return LDC_OK;
 }
 

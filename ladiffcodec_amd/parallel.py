@@ -26,7 +26,9 @@ def dist_env() -> Tuple[int, int, int]:
 def init_process_group(backend: str):
     import torch.distributed as dist
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    # under torch.distributed.run ("RANK" is set) the group is created even for a single rank, so that the same
+    # broadcast / gather code runs at N = 1 and at N = 8
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -54,7 +56,7 @@ def broadcast_state_dict(sd: Optional["OrderedDict[str, np.ndarray]"], layout: L
     only `src` needs `sd`.  One flat fp32 broadcast."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         assert sd is not None
         return sd
     total = sum(int(np.prod(s)) if len(s) else 1 for _, s in layout)
@@ -79,7 +81,7 @@ def gather_results(local, world: int):
     """all_gather of equally-shaped per-rank result tensors -> list indexed by rank."""
     import torch
     import torch.distributed as dist
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return [local]
     outs = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(outs, local)
@@ -89,7 +91,7 @@ def gather_results(local, world: int):
 def max_over_ranks(value: float, device=None) -> float:
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -89,9 +89,13 @@ print("ok", rank, lo, hi)
 def test_two_rank_gloo_broadcast_and_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    import socket
+    with socket.socket() as sk:          # a free port: back-to-back runs must not collide on a fixed one
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29517", str(script), ROOT], env=env, capture_output=True, text=True,
+                        "127.0.0.1", "--master-port", port, str(script), ROOT], env=env, capture_output=True, text=True,
                        timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "ok 0 0 4" in r.stdout and "ok 1 4 7" in r.stdout
