@@ -114,11 +114,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
       uint4 v[A_MAX];
 #pragma unroll
       for (int q = 0; q < A_MAX; ++q) {
-        const int idx = base + q * NT + tid;
-        if (idx < nrows * 4) {
-          const int r = idx >> 2, p = idx & 3;
-          v[q] = *reinterpret_cast<const uint4*>(src + ((size_t)(R_lo + r) * ld + coff + p * EPV) * sizeof(T));
-        }
+        const int idx = min(base + q * NT + tid, nrows * 4 - 1);   // clamped: unconditional load keeps v[] in registers
+        const int r = idx >> 2, p = idx & 3;
+        v[q] = *reinterpret_cast<const uint4*>(src + ((size_t)(R_lo + r) * ld + coff + p * EPV) * sizeof(T));
       }
 #pragma unroll
       for (int q = 0; q < A_MAX; ++q) {
@@ -141,12 +139,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
           uint4 v[B_MAX];
 #pragma unroll
           for (int q = 0; q < B_MAX; ++q) {
-            const int idx = base + q * NT + tid;
-            if (idx < total) {
-              const int t = idx / (BN * 4);
-              const int rem = idx - t * (BN * 4);
-              v[q] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)t * a.n_pad + n0 + (rem >> 2)) * kRowBytes + (rem & 3) * 16);
-            }
+            const int idx = min(base + q * NT + tid, total - 1);
+            const int t = idx / (BN * 4);
+            const int rem = idx - t * (BN * 4);
+            v[q] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)t * a.n_pad + n0 + (rem >> 2)) * kRowBytes + (rem & 3) * 16);
           }
 #pragma unroll
           for (int q = 0; q < B_MAX; ++q) {

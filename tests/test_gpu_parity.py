@@ -260,3 +260,34 @@ def test_cli_synthesis_end_to_end(tmp_path):
         assert sr == 16000 and y.shape == (n,) and y.dtype == np.float32
         ref = O.decode_utterances(sd_c, COND_CFG, sd_m, mc, u, T((x[:n] * 0.5).astype(np.float32)).reshape(1, 1, n), 1, None)
         assert rel(y, ref["wav"].numpy().reshape(-1)) < 5e-3, name
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_width_unet_step_against_oracle(dtype):
+    """BASELINE configs[1] widths (diff_dims=256: 256/512/1024 channels, all-128-wide tiles, 2-chunk 1x1 units,
+    64x64 small-grid tiles), short latent so that the CPU oracle finishes in seconds."""
+    from ladiffcodec_amd.model import Engine
+    from ladiffcodec_amd.spec import CodecConfig, UnetConfig
+    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    u = UnetConfig(dim=256, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    sd = synth.ladiff_state_dict(mc, u, seed=5)
+    e = Engine(mc, u, COND_CFG, dtype=dtype)
+    e.load_state_dict(L.MODEL_MAIN, {k: v for k, v in sd.items() if not k.startswith("diffusion.model.")})
+    e.load_state_dict(L.MODEL_COND, cond_sd_np())
+    e.finalize(strict=True)
+    g = torch.Generator().manual_seed(17)
+    B, Lz, F = 3, 320, 32
+    x = torch.randn(B, 128, Lz, generator=g) * 0.7
+    cond = torch.randn(B, 128, F, generator=g)
+    t = 23
+    ref = O.unet_forward(synth.to_torch(sd), u, x, torch.full((B,), t, dtype=torch.long), cond)
+    got = e.unet_forward(x.cuda(), t, cond.cuda()).cpu()
+    assert rel(got.numpy(), ref.numpy()) < (2e-4 if dtype == "f32" else 6e-2)
+    # two sampler steps with injected noise through the captured-graph path (n >= 3 steps)
+    n = 3
+    noise = torch.randn(n, B, 128, Lz, generator=g)
+    img = torch.randn(B, 128, Lz, generator=g).clamp(-1, 1) * 0.5
+    want = O.halfway_sampling(synth.to_torch(sd), u, img, cond, n, noise)
+    have = e.denoise(img.cuda(), cond.cuda(), n, noise.cuda()).cpu()
+    assert rel(have.numpy(), want.numpy()) < (1e-3 if dtype == "f32" else 0.2)
+    e.close()
