@@ -109,6 +109,7 @@ struct DevMem {
 struct LstmLayer {
   ConvLayer in_proj;          // k1 GEMM H -> 4H with bias b_ih + b_hh
   float* w_hh = nullptr;      // layout depends on H (see launch_lstm_layer)
+  float* w_rm = nullptr;      // row-major copy for the cooperative kernel (H = 256 / 512)
 };
 
 struct SeaOp {
@@ -410,6 +411,7 @@ static int build_lstm(ldc_ctx* c, WeightReader& wr, const std::string& p, int H,
       for (int row = 0; row < 4 * H; ++row)
         for (int k = 0; k < H; ++k) km[((size_t)(k / 4) * 4 * H + row) * 4 + (k % 4)] = whh->data[(size_t)row * H + k];
       LDCCHK(c->wmem.upload(&L.w_hh, km));
+      if (lstm_coop_eligible(H)) LDCCHK(c->wmem.upload(&L.w_rm, whh->data));
     }
     out->push_back(L);
   }
@@ -1032,12 +1034,16 @@ static int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in
         for (size_t n = 0; n < op.lstm.size(); ++n) {
           void* pre = R.ar->alloc((size_t)R.B * L * 4 * H * 4);
           void* o = R.ar->alloc((size_t)R.B * L * H * 4);
+          static const bool no_coop = getenv("LDC_LSTM_STREAM") != nullptr;
+          const bool coop = op.lstm[n].w_rm && !no_coop;
+          void* lws = coop ? R.ar->alloc(lstm_coop_ws_bytes(H)) : nullptr;
           if (!R.dry) {
             ConvCall cc;
             cc.B = R.B; cc.L_in = L; cc.L_rows = L; cc.x1 = in; cc.y = pre; cc.y_ld = 4 * H;
             HIPCHK(launch_conv(op.lstm[n].in_proj, cc, R.s));
             const bool lastl = n + 1 == op.lstm.size();
-            HIPCHK(launch_lstm_layer(DT_F32, pre, op.lstm[n].w_hh, o, lastl ? x : nullptr, R.B, L, H, R.s));
+            if (coop) HIPCHK(launch_lstm_coop(DT_F32, pre, op.lstm[n].w_rm, o, lastl ? x : nullptr, R.B, L, H, lws, R.s));
+            else HIPCHK(launch_lstm_layer(DT_F32, pre, op.lstm[n].w_hh, o, lastl ? x : nullptr, R.B, L, H, R.s));
           }
           in = o;
           y = o;
@@ -1268,6 +1274,7 @@ struct PlanBuilder {
   float* stats_pool = nullptr;   // [n_gn][B][groups][2]
   int stats_used = 0;
   float* linattn_ws = nullptr;
+  int linattn_used = 0;
 
   void* act(int rows, int C) {
     pl->act_bytes += (double)rows * C * es;
@@ -1347,12 +1354,13 @@ struct PlanBuilder {
     void* o = act(rows, hid);
     void* out = act(rows, a.dim);
     const LinAttnW* ap = &a;
-    float* ws = linattn_ws;
+    // one workspace per LinearAttention layer when the k column-max is fused: all of them are zeroed by the
+    // step's single memset (they sit behind the GroupNorm statistics)
+    float* ws = (linear && c->fuse_kmax) ? linattn_ws + (size_t)(linattn_used++) * B * linattn_ws_floats_per_item(H, Dh) : linattn_ws;
     add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s); });
     if (linear) {
       const size_t wss = linattn_ws_floats_per_item(H, Dh);
       if (c->fuse_kmax) {
-        add([=](hipStream_t s) { return hipMemsetAsync(ws, 0, (size_t)Bn * wss * sizeof(float), s); });
         conv(a.qkv, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
         add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, true, s); });
       } else {
@@ -1381,9 +1389,12 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const int Cc = u.cond_channels, Cx = u.channels;
   PlanBuilder pb{c, pl, &ar, B, es};
   const int n_gn = 2 * (int)(2 * u.downs.size() + 2 + 2 * u.ups.size() + 1);
-  pb.stats_pool = (float*)ar.alloc((size_t)n_gn * B * u.groups * 2 * 4);
-  const size_t stats_bytes = (size_t)n_gn * B * u.groups * 2 * 4;
-  pb.linattn_ws = (float*)ar.alloc((size_t)B * (2 * u.heads * u.dim_head + u.heads * u.dim_head * u.dim_head) * 4);
+  const size_t gn_bytes = (size_t)n_gn * B * u.groups * 2 * 4;
+  const size_t n_lin = c->fuse_kmax ? u.downs.size() + u.ups.size() : 1;
+  const size_t lin_bytes = n_lin * B * linattn_ws_floats_per_item(u.heads, u.dim_head) * 4;
+  pb.stats_pool = (float*)ar.alloc(gn_bytes + lin_bytes);
+  pb.linattn_ws = pb.stats_pool + gn_bytes / 4;
+  const size_t stats_bytes = gn_bytes + (c->fuse_kmax ? lin_bytes : 0);
   pl->maxabs = (float*)ar.alloc((size_t)B * 4);
   pl->x_cl = ar.alloc((size_t)B * L * Cx * es);
   pl->eps_cl = ar.alloc((size_t)B * L * Cx * es);

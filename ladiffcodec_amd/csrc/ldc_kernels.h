@@ -136,6 +136,12 @@ hipError_t launch_conv_cin1(int dt, const float* x, void* y, const float* w, con
 // fp32, out [B][T][H]; if skip != null: out = h + skip (SLSTM skip, lstm.py:25-26).
 hipError_t launch_lstm_layer(int dt, const void* pre, const float* w_hh, void* out, const void* skip, int B, int T,
                              int H, hipStream_t s);
+// Cooperative weight-stationary variant for H = 256 / 512 (H/4 workgroups exchange h through `ws`); w_rm is the
+// row-major [4H][H] matrix.
+bool lstm_coop_eligible(int H);
+size_t lstm_coop_ws_bytes(int H);
+hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* out, const void* skip, int B, int T, int H,
+                            void* ws, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // rvq.hip

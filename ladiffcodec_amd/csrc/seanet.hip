@@ -160,6 +160,161 @@ __global__ __launch_bounds__(1024) void lstm_stream_kernel(const void* pre, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight-stationary cooperative recurrence for wide layers (H = 256 / 512, the cond codec's SLSTM).
+// H/4 workgroups; workgroup j owns hidden units [4j, 4j+4) = 16 gate rows whose W_hh slices stay in
+// registers as the B operand of the exact-fp32 MFMA (16x16x4), K = H split over the 4 waves.  Per step:
+// every workgroup reads h_{t-1} of all (<= 32) items (the MFMA M dimension) from a double-buffered exchange
+// buffer, reduces the 4 waves' partials through LDS, applies the gates for its 4 units, publishes its slice
+// of h_t with write-through (sc1) stores and arrives on one of 8 counters.  Visibility follows the
+// placement-independent protocol: drained agent-scope stores -> relaxed arrive; relaxed poll -> agent acquire.
+// Every spin is bounded; a timeout poisons the output with NaN instead of hanging.
+// ---------------------------------------------------------------------------------------------
+constexpr int LSTM_COOP_SHARDS = 8;
+constexpr int LSTM_COOP_SHARD_STRIDE = 16;   // unsigneds: one 64-byte line per counter
+size_t lstm_coop_ws_bytes(int H) { return (size_t)2 * 32 * H * sizeof(float) + 256 * sizeof(unsigned); }
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <typename T, int H>
+__global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const float* w_hh, void* out, const void* skip,
+                                                        int B, int T_len, float* hbuf, unsigned* sync) {
+  constexpr int KW = H / 4;      // k range of one wave
+  constexpr int NI = KW / 16;    // float4 k-groups per lane
+  __shared__ float part[4][2][16][16];
+  __shared__ int s_dead;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = blockIdx.x, nb = gridDim.x;
+  const int n = lane & 15, q = lane >> 4;
+  const int MT = (B + 15) / 16;
+  // B operand: lane (n, q) holds W[row(n)][w*KW + 16*jj + 4*q + e]; the k order inside a wave is permuted
+  // identically for A and B, which the dot product does not see
+  f32x4 breg[NI];
+  {
+    const size_t row = (size_t)(n >> 2) * H + 4 * j + (n & 3);
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) breg[jj] = *reinterpret_cast<const f32x4*>(w_hh + row * H + w * KW + 16 * jj + 4 * q);
+  }
+  if (tid == 0) s_dead = 0;
+  // gate owner threads: (item b, unit u)
+  const int ob = tid >> 2, ou = tid & 3;
+  const bool owner = tid < 4 * B;
+  float c_state = 0.f;
+  float pnext[4] = {0.f, 0.f, 0.f, 0.f};
+  if (owner) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pnext[g] = sld<T>(pre, ((size_t)ob * T_len) * (4 * H) + g * H + 4 * j + ou);
+  }
+  __syncthreads();
+  bool dead = false;
+  int t = 0;
+  for (; t < T_len; ++t) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (t > 0) {
+      if (w == 0) {
+        const unsigned target = (unsigned)(t * (nb / LSTM_COOP_SHARDS));   // arrivals per shard so far
+        unsigned spins = 0;
+        for (;;) {
+          unsigned v = target;
+          if (lane < LSTM_COOP_SHARDS) v = __hip_atomic_load(sync + lane * LSTM_COOP_SHARD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned flag = lane == 0 ? __hip_atomic_load(sync + 200, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+          if (__any(flag != 0u) || ++spins > 400000u) {
+            if (lane == 0) { __hip_atomic_store(sync + 200, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dead = 1; }
+            break;
+          }
+          if (__all(v >= target)) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __syncthreads();
+      if (s_dead) { dead = true; break; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const float* hp = hbuf + (size_t)((t + 1) & 1) * 32 * H;
+      f32x4 areg[2][NI];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (mt < MT) {
+          const int item = min(mt * 16 + n, B - 1);
+#pragma unroll
+          for (int jj = 0; jj < NI; ++jj)
+            areg[mt][jj] = *reinterpret_cast<const f32x4*>(hp + (size_t)item * H + w * KW + 16 * jj + 4 * q);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < NI; ++jj) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[0][jj][e], breg[jj][e], acc[0], 0, 0, 0);
+          if (MT > 1) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[1][jj][e], breg[jj][e], acc[1], 0, 0, 0);
+        }
+      }
+    }
+    // D[row = 4*q + r][col = n]: row = item within the tile, col = gate row
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[w][mt][4 * q + r][n] = acc[mt][r];
+    __syncthreads();
+    if (owner) {
+      float gates[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = g * 4 + ou;
+        gates[g] = pnext[g] + ((part[0][ob >> 4][ob & 15][col] + part[1][ob >> 4][ob & 15][col]) +
+                               (part[2][ob >> 4][ob & 15][col] + part[3][ob >> 4][ob & 15][col]));
+      }
+      const float ig = sigmoid_acc(gates[0]), fg = sigmoid_acc(gates[1]);
+      const float gg = tanhf(gates[2]), og = sigmoid_acc(gates[3]);
+      c_state = fg * c_state + ig * gg;
+      const float h = og * tanhf(c_state);
+      __hip_atomic_store(hbuf + (size_t)(t & 1) * 32 * H + (size_t)ob * H + 4 * j + ou, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const size_t o = ((size_t)ob * T_len + t) * H + 4 * j + ou;
+      const float sk = skip ? sld<T>(skip, o) : 0.f;
+      if (t + 1 < T_len) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pnext[g] = sld<T>(pre, ((size_t)ob * T_len + t + 1) * (4 * H) + g * H + 4 * j + ou);
+      }
+      sst<T>(out, o, h + sk);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && t + 1 < T_len)
+      __hip_atomic_fetch_add(sync + (j % LSTM_COOP_SHARDS) * LSTM_COOP_SHARD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (dead && owner) {
+    for (int tt = t; tt < T_len; ++tt) sst<T>(out, ((size_t)ob * T_len + tt) * H + 4 * j + ou, __builtin_nanf(""));
+  }
+}
+
+template <typename T>
+static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out, const void* skip, int B, int T_len, int H,
+                                   void* ws, hipStream_t s) {
+  float* hbuf = reinterpret_cast<float*>(ws);
+  unsigned* sync = reinterpret_cast<unsigned*>(hbuf + (size_t)2 * 32 * H);
+  const size_t esz = sizeof(T);
+  for (int b0 = 0; b0 < B; b0 += 32) {
+    const int nb = std::min(32, B - b0);
+    hipError_t e = hipMemsetAsync(sync, 0, 256 * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    const char* p = reinterpret_cast<const char*>(pre) + (size_t)b0 * T_len * 4 * H * esz;
+    char* o = reinterpret_cast<char*>(out) + (size_t)b0 * T_len * H * esz;
+    const char* k = skip ? reinterpret_cast<const char*>(skip) + (size_t)b0 * T_len * H * esz : nullptr;
+    if (H == 512) hipLaunchKernelGGL((lstm_coop_kernel<T, 512>), dim3(H / 4), dim3(256), 0, s, p, w_rm, o, k, nb, T_len, hbuf, sync);
+    else hipLaunchKernelGGL((lstm_coop_kernel<T, 256>), dim3(H / 4), dim3(256), 0, s, p, w_rm, o, k, nb, T_len, hbuf, sync);
+  }
+  return hipGetLastError();
+}
+
+bool lstm_coop_eligible(int H) { return H == 256 || H == 512; }
+
+// w_rm: row-major [4H][H] fp32; ws: lstm_coop_ws_bytes(H) bytes of device scratch owned by the caller
+hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* out, const void* skip, int B, int T, int H,
+                            void* ws, hipStream_t s) {
+  if (!lstm_coop_eligible(H)) return hipErrorInvalidValue;
+  return dt == DT_F32 ? lstm_coop_launch<float>(pre, w_rm, out, skip, B, T, H, ws, s)
+                      : lstm_coop_launch<__bf16>(pre, w_rm, out, skip, B, T, H, ws, s);
+}
+
 // w_hh points at: [4H][H] row-major for the register variants (H = 64, 128), k-major [H/4][4H][4] otherwise.
 hipError_t launch_lstm_layer(int dt, const void* pre, const float* w_hh, void* out, const void* skip, int B, int T,
                              int H, hipStream_t s) {

@@ -60,17 +60,19 @@ def test_sconvtranspose1d_against_reference_vectors():
         assert rel(y.cpu().numpy(), g[n + ".y"]) < 1e-5, n
 
 
-@pytest.mark.parametrize("H,Tn", [(16, 11), (64, 300), (128, 160), (512, 24)])
-def test_slstm_all_kernel_variants(H, Tn):
-    """H=64/128 take the register-resident kernel, others the L2-streaming one (seanet.hip)."""
-    g = torch.Generator().manual_seed(H)
+@pytest.mark.parametrize("H,Tn,Bn", [(16, 11, 3), (64, 300, 3), (128, 160, 3), (512, 24, 3), (512, 130, 32), (512, 40, 37),
+                                     (256, 50, 20), (192, 9, 2)])
+def test_slstm_all_kernel_variants(H, Tn, Bn):
+    """H=64/128 take the register-resident kernel, H=256/512 the cooperative weight-stationary one (one or two
+    16-item MFMA tiles, >32 items = two launches), anything else the L2-streaming one (seanet.hip)."""
+    g = torch.Generator().manual_seed(H + Bn)
     b = 1.0 / np.sqrt(H)
     ws, sd = [], {}
     for layer in range(2):
         for nm, shape in (("weight_ih_l", (4 * H, H)), ("weight_hh_l", (4 * H, H)), ("bias_ih_l", (4 * H,)), ("bias_hh_l", (4 * H,))):
             w = (torch.rand(*shape, generator=g) * 2 - 1) * b
             ws.append(w.numpy()); sd[f"p.lstm.{nm}{layer}"] = w
-    x = torch.randn(3, H, Tn, generator=g)
+    x = torch.randn(Bn, H, Tn, generator=g)
     ref = O.lstm_skip(x, sd, "p", 2)
     y = engine("r84", "f32").slstm(x.cuda(), ws, 2)
     assert rel(y.cpu().numpy(), ref.numpy()) < 2e-5
