@@ -26,6 +26,7 @@ import torch  # noqa: E402
 from ladiffcodec_amd import lib as L, parallel, spec, synth  # noqa: E402
 from ladiffcodec_amd.spec import CodecConfig, UnetConfig  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -172,6 +173,7 @@ def main():
         # eager decode of the same batch (profiling pass, separate from the timed region above)
         eng.profile(True)
         eng.decode(wav, N, noise=None, per_item=True)
+        classes = eng.profile_read_classes()
         ms, launches, flops = eng.profile_read()
         eng.profile(False)
         log(f"profile pass: {launches} conv launches, {ms:.1f} ms")
@@ -198,6 +200,16 @@ def main():
                               "algorithmic_flops_per_launch": flops / max(1, launches),
                               "launches": launches, "avg_launch_us": 1000.0 * ms / max(1, launches),
                               "unet_step_gflop": step_flops / 1e9, "unet_step_conv_algorithmic_gb": step_bytes / 1e9}
+        # the other kernel classes of the UNet step against the roof that bounds them (same profiling pass)
+        other = []
+        for name, cms, cn, cfl, cby in classes:
+            if name in ("other", "conv_gemm") or cn == 0 or cms <= 0:
+                continue
+            gbs = cby / (cms * 1e-3) / 1e9
+            other.append({"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": gbs / HBM_PEAK_GBS, "launches": cn, "avg_launch_us": 1000.0 * cms / cn,
+                          "share_of_profiled_ms": cms / max(1e-9, sum(c[1] for c in classes))})
+        result["roofline"]["other_kernels"] = other
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cc, mc, u, sd_cond, sd_main, N, args.seconds, args.cpu_batch)
     if rank == 0:

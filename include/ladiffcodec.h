@@ -160,6 +160,19 @@ int ldc_gn_microbench(ldc_ctx* ctx, int dtype, int B, int L, int C, int with_res
 int ldc_conv_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups,
                         int iters, double* ms_per_launch);
 int ldc_profile_read(ldc_ctx* ctx, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
+/* Per kernel class (LDC_CLASS_*) totals of the same profiling pass: event-timed milliseconds, launches, algorithmic
+ * flops and algorithmic HBM bytes; arrays of n >= LDC_N_CLASSES entries (any may be NULL). */
+enum {
+  LDC_CLASS_OTHER = 0,       /* memsets, statistics fallbacks */
+  LDC_CLASS_CONV = 1,        /* implicit-GEMM Conv1d (F.conv1d in unet.py) -- MFMA bound */
+  LDC_CLASS_GN_APPLY = 2,    /* GroupNorm affine + scale/shift + SiLU (+ residual), unet.py:137-156 -- HBM bound */
+  LDC_CLASS_LAYERNORM = 3,   /* channel LayerNorm (+ residual), unet.py:82-101 -- HBM bound */
+  LDC_CLASS_LINATTN = 4,     /* LinearAttention core, unet.py:208-222 -- HBM bound */
+  LDC_CLASS_ATTN_FULL = 5,   /* bottleneck Attention core, unet.py:234-246 -- latency bound */
+  LDC_CLASS_ELEMENTWISE = 6, /* tanh before final_conv, unet.py:467 -- HBM bound */
+  LDC_N_CLASSES = 7
+};
+int ldc_profile_read_classes(ldc_ctx* ctx, int n, double* ms, int64_t* launches, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }

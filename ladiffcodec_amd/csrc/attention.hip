@@ -158,6 +158,175 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const void* qkv, void*
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 engine: the same two passes on the matrix cores (H = 4 heads x D = 32, one wave per head).
+//   ctx : context^T-free form  ctx[d][e] = sum_n p[n][d] v[n][e]  with the contraction over positions: the
+//         tile's k/v rows arrive as 16-byte row pieces and are written to LDS transposed ([col][row]) so that
+//         both MFMA operands are one ds_read_b128 each; p = exp(k - colmax) is rounded to bf16 once and the
+//         same rounded values feed the column sums.
+//   out : out^T[e][n] = sum_d ctx'[d][e] q'[n][d]; ctx' (= ctx / ksum * scale) is the stationary A operand, the
+//         q row pieces are the B operand straight from global memory, the softmax over d is done in registers
+//         (a row's 32 values live in lanes l and l^32), the result lands as 4 consecutive channels per lane.
+// ---------------------------------------------------------------------------------------------
+typedef float lf32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 lbf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ lf32x16 mfma_bf16(const uint4& a, const uint4& b, lf32x16 acc) {
+  lbf16x8 va, vb;
+  __builtin_memcpy(&va, &a, 16);
+  __builtin_memcpy(&vb, &b, 16);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc, 0, 0, 0);
+}
+
+template <int R>   // rows per workgroup
+__global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(const unsigned short* qkv, float* ws, int L, size_t ws_stride) {
+  constexpr int H = 4, D = 32, HD = 128, P = R + 8;
+  __shared__ __attribute__((aligned(16))) unsigned short spT[HD][P];
+  __shared__ __attribute__((aligned(16))) unsigned short svT[HD][P];
+  __shared__ float skmax[HD];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  float* wsb = ws + (size_t)b * ws_stride;
+  const int r0 = blockIdx.x * R;
+  constexpr int NP = R / 16;   // 16-byte pieces per thread and operand
+  uint4 kk[NP], vv[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int id = tid + 256 * i, row = id >> 4, c16 = id & 15;
+    if (r0 + row < L) {
+      const unsigned short* base = qkv + ((size_t)b * L + r0 + row) * (3 * HD) + 8 * c16;
+      kk[i] = *reinterpret_cast<const uint4*>(base + HD);
+      vv[i] = *reinterpret_cast<const uint4*>(base + 2 * HD);
+    } else {
+      kk[i] = make_uint4(0, 0, 0, 0); vv[i] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  if (tid < HD) skmax[tid] = fkey_inv(reinterpret_cast<const unsigned*>(wsb)[tid]);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int id = tid + 256 * i, row = id >> 4, c16 = id & 15;
+    const bool live = r0 + row < L;
+    const unsigned kw[4] = {kk[i].x, kk[i].y, kk[i].z, kk[i].w};
+    const unsigned vw[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int col = 8 * c16 + m;
+      const unsigned short kb = (unsigned short)((m & 1) ? (kw[m >> 1] >> 16) : (kw[m >> 1] & 0xffffu));
+      const unsigned short vb = (unsigned short)((m & 1) ? (vw[m >> 1] >> 16) : (vw[m >> 1] & 0xffffu));
+      spT[col][row] = live ? af2bf(__expf(abf2f(kb) - skmax[col])) : (unsigned short)0;
+      svT[col][row] = vb;
+    }
+  }
+  __syncthreads();
+  const int h = tid >> 6, lane = tid & 63, i32 = lane & 31, g = lane >> 5;
+  lf32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int sx = 0; sx < R / 16; ++sx) {
+    const uint4 a = *reinterpret_cast<const uint4*>(&spT[h * D + i32][16 * sx + 8 * g]);
+    const uint4 bq = *reinterpret_cast<const uint4*>(&svT[h * D + i32][16 * sx + 8 * g]);
+    acc = mfma_bf16(a, bq, acc);
+  }
+  float* ctx = wsb + 2 * HD + (size_t)h * D * D;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * g;
+    atomicAdd(&ctx[d * D + i32], acc[r]);
+  }
+  if (tid < HD) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q8 = 0; q8 < R / 8; ++q8) {
+      const uint4 u = *reinterpret_cast<const uint4*>(&spT[tid][8 * q8]);
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) sum += abf2f((unsigned short)(w[m] & 0xffffu)) + abf2f((unsigned short)(w[m] >> 16));
+    }
+    atomicAdd(&wsb[HD + tid], sum);
+  }
+}
+
+template <int TILES>   // 32-row tiles per workgroup
+__global__ __launch_bounds__(256) void linattn_out_mfma_kernel(const unsigned short* qkv, unsigned short* out, const float* ws,
+                                                               int L, size_t ws_stride, float scale) {
+  constexpr int D = 32, HD = 128;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int h = tid >> 6, lane = tid & 63, i32 = lane & 31, g = lane >> 5;
+  const int r0 = blockIdx.x * (32 * TILES);
+  // q row pieces first (independent of the context)
+  uint4 qq[TILES][2];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const int n = r0 + 32 * t + i32;
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      if (n < L) qq[t][sx] = *reinterpret_cast<const uint4*>(qkv + ((size_t)b * L + n) * (3 * HD) + h * D + 16 * sx + 8 * g);
+      else qq[t][sx] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  // stationary operand: A[i = e][k = d] = ctx[d][e] / ksum[d] * scale
+  const float* wsb = ws + (size_t)b * ws_stride;
+  uint4 af[2];
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx) {
+    unsigned w[4];
+#pragma unroll
+    for (int m = 0; m < 8; m += 2) {
+      const int d0 = 16 * sx + 8 * g + m;
+      const float c0 = wsb[2 * HD + (size_t)h * D * D + d0 * D + i32] * (scale / wsb[HD + h * D + d0]);
+      const float c1 = wsb[2 * HD + (size_t)h * D * D + (d0 + 1) * D + i32] * (scale / wsb[HD + h * D + d0 + 1]);
+      w[m >> 1] = (unsigned)af2bf(c0) | ((unsigned)af2bf(c1) << 16);
+    }
+    af[sx] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const int n = r0 + 32 * t + i32;
+    float x[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const unsigned w[4] = {qq[t][sx].x, qq[t][sx].y, qq[t][sx].z, qq[t][sx].w};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        x[8 * sx + 2 * m] = abf2f((unsigned short)(w[m] & 0xffffu));
+        x[8 * sx + 2 * m + 1] = abf2f((unsigned short)(w[m] >> 16));
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) mx = fmaxf(mx, x[m]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { x[m] = __expf(x[m] - mx); sum += x[m]; }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    uint4 bq[2];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      unsigned w[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        w[m] = (unsigned)af2bf(x[8 * sx + 2 * m] * inv) | ((unsigned)af2bf(x[8 * sx + 2 * m + 1] * inv) << 16);
+      bq[sx] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    lf32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = mfma_bf16(af[0], bq[0], acc);
+    acc = mfma_bf16(af[1], bq[1], acc);
+    if (n < L) {
+      unsigned short* orow = out + ((size_t)b * L + n) * HD + h * D;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const unsigned lo = (unsigned)af2bf(acc[4 * rr]) | ((unsigned)af2bf(acc[4 * rr + 1]) << 16);
+        const unsigned hi = (unsigned)af2bf(acc[4 * rr + 2]) | ((unsigned)af2bf(acc[4 * rr + 3]) << 16);
+        *reinterpret_cast<uint2*>(orow + 8 * rr + 4 * g) = make_uint2(lo, hi);
+      }
+    }
+  }
+}
+
 size_t linattn_ws_floats_per_item(int heads, int dim_head) { return linattn_ws_per_item(heads, dim_head); }
 
 // kmax_fused: the caller zeroed `ws` before the qkv conv and that conv's epilogue already produced the column
@@ -171,12 +340,20 @@ hipError_t launch_linattn(int dt, const void* qkv, void* out, float* ws, int B, 
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * wss * sizeof(float), s);
     if (e != hipSuccess) return e;
   }
-  const int rpb = 128;
+  static const int rpb_env = getenv("LDC_LINATTN_RPB") ? atoi(getenv("LDC_LINATTN_RPB")) : 0;
+  const int rpb = rpb_env > 0 ? rpb_env : 128;
   const int chunks = (L + rpb - 1) / rpb;
   const float scale = 1.0f / sqrtf((float)dim_head);
   const size_t lds_out = (size_t)heads * (dim_head * dim_head + 8) * sizeof(float);
   const int rows_out = 256 / heads;
-  if (dt == DT_F32) {
+  static const bool v1 = getenv("LDC_LINATTN_V1") != nullptr;
+  if (dt == DT_BF16 && heads == 4 && !v1) {
+    if (!kmax_fused) hipLaunchKernelGGL(linattn_kmax_kernel<__bf16>, dim3(chunks, B), dim3(256), 0, s, qkv, ws, L, HD, rpb, wss);
+    hipLaunchKernelGGL(linattn_ctx_mfma_kernel<64>, dim3((L + 63) / 64, B), dim3(256), 0, s,
+                       reinterpret_cast<const unsigned short*>(qkv), ws, L, wss);
+    hipLaunchKernelGGL(linattn_out_mfma_kernel<2>, dim3((L + 63) / 64, B), dim3(256), 0, s,
+                       reinterpret_cast<const unsigned short*>(qkv), reinterpret_cast<unsigned short*>(out), ws, L, wss, scale);
+  } else if (dt == DT_F32) {
     if (!kmax_fused) hipLaunchKernelGGL(linattn_kmax_kernel<float>, dim3(chunks, B), dim3(256), 0, s, qkv, ws, L, HD, rpb, wss);
     hipLaunchKernelGGL((linattn_ctx_kernel<float, 32>), dim3(chunks, B * heads), dim3(256), 0, s, qkv, ws, L, heads, rpb, wss);
     hipLaunchKernelGGL((linattn_out_kernel<float, 32>), dim3((L + rows_out - 1) / rows_out, B), dim3(256), lds_out, s, qkv,

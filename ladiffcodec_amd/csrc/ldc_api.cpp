@@ -185,6 +185,8 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
   std::vector<int> step_where;                                     // 0 main stream, 1 side stream, 2 fork, 3 join
   std::vector<hipEvent_t> marker_events;                           // one event per fork/join marker (no re-use inside a capture)
   std::vector<double> step_flops;
+  std::vector<int> step_class;                                     // LDC_CLASS_* of each op (profiling)
+  std::vector<double> step_bytes;                                  // algorithmic HBM bytes of each op
   struct Tap { void* p; int C; int L; };
   std::map<std::string, Tap> taps;
   double flops = 0, act_bytes = 0, conv_bytes = 0;   // conv_bytes: inputs + outputs + packed weights of every conv-GEMM
@@ -242,6 +244,10 @@ struct ldc_ctx {
   int64_t prof_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<double> prof_event_flops;
+  std::vector<int> prof_event_class;
+  std::vector<double> prof_event_bytes;
+  double cls_ms[LDC_N_CLASSES] = {}, cls_flops[LDC_N_CLASSES] = {}, cls_bytes[LDC_N_CLASSES] = {};
+  int64_t cls_launches[LDC_N_CLASSES] = {};
 };
 
 static hipStream_t pick_stream(ldc_ctx* c, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : c->own_stream; }
@@ -1286,12 +1292,17 @@ struct PlanBuilder {
     pl->step_is_conv.push_back(0);
     pl->step_where.push_back(kind);
     pl->step_flops.push_back(0);
+    pl->step_class.push_back(LDC_CLASS_OTHER);
+    pl->step_bytes.push_back(0);
   }
-  void add(std::function<hipError_t(hipStream_t)> f, bool is_conv = false, double flops = 0) {
+  void add(std::function<hipError_t(hipStream_t)> f, bool is_conv = false, double flops = 0, int cls = LDC_CLASS_OTHER,
+           double bytes = 0) {
     pl->step_ops.push_back(std::move(f));
     pl->step_where.push_back(where);
     pl->step_is_conv.push_back(is_conv ? 1 : 0);
     pl->step_flops.push_back(flops);
+    pl->step_class.push_back(is_conv ? LDC_CLASS_CONV : cls);
+    pl->step_bytes.push_back(bytes);
     pl->flops += flops;
   }
   void conv(const ConvLayer& ly, const void* x1, const void* x2, void* y, const void* residual, int L_in, int L_out,
@@ -1301,8 +1312,9 @@ struct PlanBuilder {
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
     cc.colmax = colmax; cc.colmax_lo = cm_lo; cc.colmax_hi = cm_hi; cc.colmax_stride = cm_stride;
     const ConvLayer* lp = &ly;
-    pl->conv_bytes += ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n) * es + (double)conv_packed_weight_bytes(ly);
-    add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out);
+    const double cbytes = ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n) * es + (double)conv_packed_weight_bytes(ly);
+    pl->conv_bytes += cbytes;
+    add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out, LDC_CLASS_CONV, cbytes);
   }
   float* next_stats() {
     const int g = c->unet.groups;
@@ -1336,13 +1348,13 @@ struct PlanBuilder {
     add([=](hipStream_t s) {
       return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, u->cur_ss + rp->ss_off,
                              0, nullptr, ACT_SILU, s);
-    });
+    }, false, 0, LDC_CLASS_GN_APPLY, 2.0 * Bn * L * rp->cout * es);
     conv(r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
     if (r.has_res) mark(3);
     add([=](hipStream_t s) {
       return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s);
-    });
+    }, false, 0, LDC_CLASS_GN_APPLY, 3.0 * Bn * L * rp->cout * es);
     return out;
   }
   // Residual(PreNorm(LinearAttention)) (unet.py:208-222) / Residual(PreNorm(Attention)) (:234-246)
@@ -1357,22 +1369,26 @@ struct PlanBuilder {
     // one workspace per LinearAttention layer when the k column-max is fused: all of them are zeroed by the
     // step's single memset (they sit behind the GroupNorm statistics)
     float* ws = (linear && c->fuse_kmax) ? linattn_ws + (size_t)(linattn_used++) * B * linattn_ws_floats_per_item(H, Dh) : linattn_ws;
-    add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s); });
+    add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s); }, false, 0, LDC_CLASS_LAYERNORM,
+        2.0 * rows * a.dim * es);
     if (linear) {
       const size_t wss = linattn_ws_floats_per_item(H, Dh);
       if (c->fuse_kmax) {
         conv(a.qkv, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
-        add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, true, s); });
+        add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, true, s); }, false, 0, LDC_CLASS_LINATTN,
+            4.0 * rows * hid * es);
       } else {
         conv(a.qkv, xn, nullptr, qkv, nullptr, L, L);
-        add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, false, s); });
+        add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, false, s); }, false, 0, LDC_CLASS_LINATTN,
+            5.0 * rows * hid * es);
       }
       void* t = act(rows, a.dim);
       conv(a.out, o, nullptr, t, nullptr, L, L);
-      add([=](hipStream_t s) { return launch_ln_rows(dt, t, out, x, ap->out_g, rows, ap->dim, s); });
+      add([=](hipStream_t s) { return launch_ln_rows(dt, t, out, x, ap->out_g, rows, ap->dim, s); }, false, 0, LDC_CLASS_LAYERNORM,
+          3.0 * rows * a.dim * es);
     } else {
       conv(a.qkv, xn, nullptr, qkv, nullptr, L, L);
-      add([=](hipStream_t s) { return launch_attn_full(dt, qkv, o, Bn, L, H, Dh, s); });
+      add([=](hipStream_t s) { return launch_attn_full(dt, qkv, o, Bn, L, H, Dh, s); }, false, 0, LDC_CLASS_ATTN_FULL, 4.0 * rows * hid * es);
       conv(a.out, o, nullptr, out, x, L, L);   // + x in the epilogue
     }
     return out;
@@ -1382,7 +1398,7 @@ struct PlanBuilder {
 static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const UnetW& u = c->unet;
   pl->B = B; pl->L = L; pl->F = F;
-  pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_where.clear(); pl->step_flops.clear(); pl->taps.clear();
+  pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_where.clear(); pl->step_flops.clear(); pl->step_class.clear(); pl->step_bytes.clear(); pl->taps.clear();
   pl->flops = 0; pl->act_bytes = 0; pl->conv_bytes = 0;
   const int dt = c->dt;
   const size_t es = dt_size(dt);
@@ -1478,7 +1494,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     void* th = pb.act(B * L, u.dim);
     const void* xin = x;
     const int64_t n = (int64_t)B * L * u.dim;
-    pb.add([=](hipStream_t s) { return launch_act(dt, xin, th, n, ACT_TANH, s); });
+    pb.add([=](hipStream_t s) { return launch_act(dt, xin, th, n, ACT_TANH, s); }, false, 0, LDC_CLASS_ELEMENTWISE, 2.0 * n * es);
     pb.conv(u.final_conv, th, nullptr, pl->eps_cl, nullptr, L, L);
   }
   return LDC_OK;
@@ -1537,7 +1553,7 @@ static int run_ops(ldc_ctx* c, Plan* pl, const std::vector<std::function<hipErro
   }
   size_t marker = 0;
   for (size_t i = 0; i < ops.size(); ++i) {
-    const bool prof = c->profile && is_step && pl->step_is_conv[i];
+    const bool prof = c->profile && is_step;
     const int where = is_step ? pl->step_where[i] : 0;
     if (where == 2) {
       if (use_side) {
@@ -1568,6 +1584,8 @@ static int run_ops(ldc_ctx* c, Plan* pl, const std::vector<std::function<hipErro
       HIPCHK(hipEventRecord(e1, s));
       c->prof_events.push_back({e0, e1});
       c->prof_event_flops.push_back(pl->step_flops[i]);
+      c->prof_event_class.push_back(pl->step_class[i]);
+      c->prof_event_bytes.push_back(pl->step_bytes[i]);
     }
   }
   return LDC_OK;
@@ -1968,27 +1986,49 @@ extern "C" int ldc_profile_enable(ldc_ctx* c, int on) {
   if (on) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     c->prof_events.clear();
-    c->prof_event_flops.clear();
+    c->prof_event_flops.clear(); c->prof_event_class.clear(); c->prof_event_bytes.clear();
     c->prof_ms = 0; c->prof_flops = 0; c->prof_launches = 0;
+    for (int k = 0; k < LDC_N_CLASSES; ++k) { c->cls_ms[k] = c->cls_flops[k] = c->cls_bytes[k] = 0; c->cls_launches[k] = 0; }
+  }
+  return LDC_OK;
+}
+
+static int profile_collect(ldc_ctx* c) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipDeviceSynchronize());
+  for (size_t i = 0; i < c->prof_events.size(); ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
+    const int k = c->prof_event_class[i];
+    c->cls_ms[k] += ms; c->cls_flops[k] += c->prof_event_flops[i]; c->cls_bytes[k] += c->prof_event_bytes[i]; c->cls_launches[k] += 1;
+    if (k == LDC_CLASS_CONV) {
+      c->prof_ms += ms;
+      c->prof_flops += c->prof_event_flops[i];
+      c->prof_launches += 1;
+    }
+    (void)hipEventDestroy(c->prof_events[i].first);
+    (void)hipEventDestroy(c->prof_events[i].second);
+  }
+  c->prof_events.clear();
+  c->prof_event_flops.clear(); c->prof_event_class.clear(); c->prof_event_bytes.clear();
+  return LDC_OK;
+}
+
+extern "C" int ldc_profile_read_classes(ldc_ctx* c, int n, double* ms, int64_t* launches, double* flops, double* bytes) {
+  if (!c || n < 1) return fail(LDC_E_INVALID, "bad arguments");
+  LDCCHK(profile_collect(c));
+  for (int k = 0; k < n && k < LDC_N_CLASSES; ++k) {
+    if (ms) ms[k] = c->cls_ms[k];
+    if (launches) launches[k] = c->cls_launches[k];
+    if (flops) flops[k] = c->cls_flops[k];
+    if (bytes) bytes[k] = c->cls_bytes[k];
   }
   return LDC_OK;
 }
 
 extern "C" int ldc_profile_read(ldc_ctx* c, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total) {
   if (!c) return fail(LDC_E_INVALID, "null ctx");
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipDeviceSynchronize());
-  for (size_t i = 0; i < c->prof_events.size(); ++i) {
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
-    c->prof_ms += ms;
-    c->prof_flops += c->prof_event_flops[i];
-    c->prof_launches += 1;
-    (void)hipEventDestroy(c->prof_events[i].first);
-    (void)hipEventDestroy(c->prof_events[i].second);
-  }
-  c->prof_events.clear();
-  c->prof_event_flops.clear();
+  LDCCHK(profile_collect(c));
   if (conv_ms_total) *conv_ms_total = c->prof_ms;
   if (conv_launches) *conv_launches = c->prof_launches;
   if (conv_flops_total) *conv_flops_total = c->prof_flops;

@@ -248,6 +248,15 @@ class Engine:
         L.check(self.lib.ldc_profile_read(self._ctx, C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
 
+    CLASS_NAMES = ("other", "conv_gemm", "gn_apply", "layernorm", "linear_attention", "attention_full", "elementwise")
+
+    def profile_read_classes(self):
+        """Per kernel class: (name, ms, launches, algorithmic flops, algorithmic bytes) of the profiling pass."""
+        n = len(self.CLASS_NAMES)
+        ms, la, fl, by = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
+        L.check(self.lib.ldc_profile_read_classes(self._ctx, n, ms, la, fl, by))
+        return [(self.CLASS_NAMES[k], ms[k], la[k], fl[k], by[k]) for k in range(n)]
+
     # ---- L1 primitives (parity tests) ------------------------------------------------------------
     def sconv1d(self, x, w, b, stride=1, dilation=1, causal=True, pre_elu=False):
         x = self._f32(x)
