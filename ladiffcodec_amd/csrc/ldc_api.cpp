@@ -187,6 +187,7 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
   std::vector<double> step_flops;
   std::vector<int> step_class;                                     // LDC_CLASS_* of each op (profiling)
   std::vector<double> step_bytes;                                  // algorithmic HBM bytes of each op
+  std::vector<std::string> step_info;                              // human-readable shape (profile dump)
   struct Tap { void* p; int C; int L; };
   std::map<std::string, Tap> taps;
   double flops = 0, act_bytes = 0, conv_bytes = 0;   // conv_bytes: inputs + outputs + packed weights of every conv-GEMM
@@ -246,6 +247,7 @@ struct ldc_ctx {
   std::vector<double> prof_event_flops;
   std::vector<int> prof_event_class;
   std::vector<double> prof_event_bytes;
+  std::vector<std::string> prof_event_info;
   double cls_ms[LDC_N_CLASSES] = {}, cls_flops[LDC_N_CLASSES] = {}, cls_bytes[LDC_N_CLASSES] = {};
   int64_t cls_launches[LDC_N_CLASSES] = {};
 };
@@ -1294,6 +1296,7 @@ struct PlanBuilder {
     pl->step_flops.push_back(0);
     pl->step_class.push_back(LDC_CLASS_OTHER);
     pl->step_bytes.push_back(0);
+    pl->step_info.push_back("-");
   }
   void add(std::function<hipError_t(hipStream_t)> f, bool is_conv = false, double flops = 0, int cls = LDC_CLASS_OTHER,
            double bytes = 0) {
@@ -1303,8 +1306,11 @@ struct PlanBuilder {
     pl->step_flops.push_back(flops);
     pl->step_class.push_back(is_conv ? LDC_CLASS_CONV : cls);
     pl->step_bytes.push_back(bytes);
+    pl->step_info.push_back(info.empty() ? std::string("-") : info);
+    info.clear();
     pl->flops += flops;
   }
+  std::string info;   // description of the next op added
   void conv(const ConvLayer& ly, const void* x1, const void* x2, void* y, const void* residual, int L_in, int L_out,
             float* gn_sum = nullptr, unsigned* colmax = nullptr, int cm_lo = 0, int cm_hi = 0, int cm_stride = 0) {
     ConvCall cc;
@@ -1312,6 +1318,12 @@ struct PlanBuilder {
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
     cc.colmax = colmax; cc.colmax_lo = cm_lo; cc.colmax_hi = cm_hi; cc.colmax_stride = cm_stride;
     const ConvLayer* lp = &ly;
+    {
+      char buf[96];
+      snprintf(buf, sizeof(buf), "k%d_s%d_u%d_c%d+%d->%d_L%d%s%s", ly.taps, ly.stride, ly.ups, ly.cin1, ly.cin2, ly.n, L_out,
+               gn_sum ? "_gn" : "", colmax ? "_kmax" : "");
+      info = buf;
+    }
     const double cbytes = ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n) * es + (double)conv_packed_weight_bytes(ly);
     pl->conv_bytes += cbytes;
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out, LDC_CLASS_CONV, cbytes);
@@ -1398,7 +1410,7 @@ struct PlanBuilder {
 static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const UnetW& u = c->unet;
   pl->B = B; pl->L = L; pl->F = F;
-  pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_where.clear(); pl->step_flops.clear(); pl->step_class.clear(); pl->step_bytes.clear(); pl->taps.clear();
+  pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_where.clear(); pl->step_flops.clear(); pl->step_class.clear(); pl->step_bytes.clear(); pl->step_info.clear(); pl->taps.clear();
   pl->flops = 0; pl->act_bytes = 0; pl->conv_bytes = 0;
   const int dt = c->dt;
   const size_t es = dt_size(dt);
@@ -1586,6 +1598,7 @@ static int run_ops(ldc_ctx* c, Plan* pl, const std::vector<std::function<hipErro
       c->prof_event_flops.push_back(pl->step_flops[i]);
       c->prof_event_class.push_back(pl->step_class[i]);
       c->prof_event_bytes.push_back(pl->step_bytes[i]);
+      c->prof_event_info.push_back(pl->step_info[i] + "_B" + std::to_string(pl->B));
     }
   }
   return LDC_OK;
@@ -1672,7 +1685,8 @@ static int half_step(ldc_ctx* c, const Halves& h, int k, float* x, const float* 
 // (valid eagerly and under stream capture: the event edges become graph dependencies)
 static int one_step(ldc_ctx* c, const Halves& h, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
   HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, c->step_state, c->unet.cur_ss, s));
-  if (h.n >= 2 && !c->profile) {
+  static const bool serial_env = getenv("LDC_SERIAL") != nullptr;   // diagnostics: halves back to back, eager
+  if (h.n >= 2 && !c->profile && !serial_env) {
     HIPCHK(hipEventRecord(c->ev_fork, s));
     for (int k = 1; k < h.n; ++k) HIPCHK(hipStreamWaitEvent(c->aux_stream[k], c->ev_fork, 0));
 
@@ -1710,7 +1724,8 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   const int L = h.p[0]->L, F = h.p[0]->F;
   const int64_t stride = (int64_t)B * c->unet.channels * L;
   HIPCHK(launch_step_set(c->step_state, n_steps - 1, 0, s));
-  if (c->profile || n_steps < 3) {
+  static const bool serial_eager = getenv("LDC_SERIAL") != nullptr;
+  if (c->profile || serial_eager || n_steps < 3) {
     for (int i = 0; i < n_steps; ++i) LDCCHK(one_step(c, h, x, noise, stride, s));
     return LDC_OK;
   }
@@ -1986,7 +2001,7 @@ extern "C" int ldc_profile_enable(ldc_ctx* c, int on) {
   if (on) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     c->prof_events.clear();
-    c->prof_event_flops.clear(); c->prof_event_class.clear(); c->prof_event_bytes.clear();
+    c->prof_event_flops.clear(); c->prof_event_class.clear(); c->prof_event_bytes.clear(); c->prof_event_info.clear();
     c->prof_ms = 0; c->prof_flops = 0; c->prof_launches = 0;
     for (int k = 0; k < LDC_N_CLASSES; ++k) { c->cls_ms[k] = c->cls_flops[k] = c->cls_bytes[k] = 0; c->cls_launches[k] = 0; }
   }
@@ -1996,10 +2011,12 @@ extern "C" int ldc_profile_enable(ldc_ctx* c, int on) {
 static int profile_collect(ldc_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipDeviceSynchronize());
+  FILE* dump = getenv("LDC_PROFILE_DUMP") && !c->prof_events.empty() ? fopen(getenv("LDC_PROFILE_DUMP"), "a") : nullptr;
   for (size_t i = 0; i < c->prof_events.size(); ++i) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
     const int k = c->prof_event_class[i];
+    if (dump) fprintf(dump, "%d %.0f %.0f %.3f %s\n", k, c->prof_event_flops[i], c->prof_event_bytes[i], ms * 1e3, c->prof_event_info[i].c_str());
     c->cls_ms[k] += ms; c->cls_flops[k] += c->prof_event_flops[i]; c->cls_bytes[k] += c->prof_event_bytes[i]; c->cls_launches[k] += 1;
     if (k == LDC_CLASS_CONV) {
       c->prof_ms += ms;
@@ -2009,8 +2026,9 @@ static int profile_collect(ldc_ctx* c) {
     (void)hipEventDestroy(c->prof_events[i].first);
     (void)hipEventDestroy(c->prof_events[i].second);
   }
+  if (dump) fclose(dump);
   c->prof_events.clear();
-  c->prof_event_flops.clear(); c->prof_event_class.clear(); c->prof_event_bytes.clear();
+  c->prof_event_flops.clear(); c->prof_event_class.clear(); c->prof_event_bytes.clear(); c->prof_event_info.clear();
   return LDC_OK;
 }
 

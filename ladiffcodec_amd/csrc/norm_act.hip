@@ -35,6 +35,13 @@ struct Vec8<float> {
     q[0] = make_float4(v[0], v[1], v[2], v[3]);
     q[1] = make_float4(v[4], v[5], v[6], v[7]);
   }
+  static __device__ __forceinline__ void store_nt(void* p, size_t idx, const float (&v)[8]) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4* q = reinterpret_cast<f4*>(reinterpret_cast<float*>(p) + idx);
+    f4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    __builtin_nontemporal_store(a, q);
+    __builtin_nontemporal_store(b, q + 1);
+  }
 };
 template <>
 struct Vec8<__bf16> {
@@ -52,6 +59,13 @@ struct Vec8<__bf16> {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
     *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p) + idx) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ void store_nt(void* p, size_t idx, const float (&v)[8]) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    __builtin_nontemporal_store(w, reinterpret_cast<u4*>(reinterpret_cast<unsigned short*>(p) + idx));
   }
 };
 
@@ -240,7 +254,8 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] += rr[q][i];
       }
-      if (!(dbg & 4)) Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
+      if (dbg & 8) Vec8<T>::store_nt(y, ((size_t)b * L + r) * C + v * 8, o);
+      else if (!(dbg & 4)) Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
       else if (o[0] == 12345.678f) Vec8<T>::store(y, 0, o);
     }
   }

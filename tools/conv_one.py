@@ -10,6 +10,7 @@ from ladiffcodec_amd import lib as L  # noqa: E402
 Lx, c1, c2, co, k, st, ups = (int(v) for v in sys.argv[1:8])
 iters = int(sys.argv[8]) if len(sys.argv) > 8 else 10
 dtype = sys.argv[9] if len(sys.argv) > 9 else "bf16"
+Bn = int(os.environ.get("LDC_B", "32"))
 lib = L.load()
 cfg = L.LdcConfig()
 cfg.compute_dtype = L.LDC_BF16
@@ -20,7 +21,7 @@ cfg.diff_dims = 256
 ctx = C.c_void_p()
 L.check(lib.ldc_create(C.byref(cfg), 0, C.byref(ctx)))
 ms = C.c_double()
-L.check(lib.ldc_conv_microbench(ctx, L.LDC_BF16 if dtype == "bf16" else L.LDC_F32, 32, Lx, c1, c2, co, k, st, ups, iters, C.byref(ms)))
-fl = 2.0 * 32 * (2 * Lx if ups else (Lx // 2 if st == 2 else Lx)) * co * (c1 + c2) * k
+L.check(lib.ldc_conv_microbench(ctx, L.LDC_BF16 if dtype == "bf16" else L.LDC_F32, Bn, Lx, c1, c2, co, k, st, ups, iters, C.byref(ms)))
+fl = 2.0 * Bn * (2 * Lx if ups else (Lx // 2 if st == 2 else Lx)) * co * (c1 + c2) * k
 print(f"{ms.value * 1e3:.1f} us  {fl / ms.value / 1e9:.1f} TFLOP/s")
 lib.ldc_destroy(ctx)
