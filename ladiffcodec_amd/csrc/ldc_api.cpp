@@ -231,6 +231,7 @@ struct ldc_ctx {
   hipEvent_t ev_side_fork[kMaxParts] = {nullptr, nullptr, nullptr, nullptr}, ev_side_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int side_streams = 0;
   int fuse_kmax = 1;
+  int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
   int fuse_gn_stats = 1;
   std::vector<void*> plan_mem;
   // scratch arena for codec stages and boundary buffers
@@ -859,6 +860,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->split_batch = getenv("LDC_NO_SPLIT") ? 1 : (getenv("LDC_SPLIT") ? std::max(1, std::min(kMaxParts, atoi(getenv("LDC_SPLIT")))) : 2);
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
+  c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, 2 * sizeof(int)));
   c->step_state = (int*)p;
@@ -867,6 +869,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
 }
 
 static void drop_plans(ldc_ctx* c) {
+  (void)hipDeviceSynchronize();   // nothing captured or planned may still be running when it is destroyed
   for (auto& g : c->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   c->graphs.clear();
@@ -1333,7 +1336,9 @@ struct PlanBuilder {
     return stats_pool + (size_t)(stats_used++) * B * g * 2;
   }
   // ResnetBlock.forward (unet.py:176-192)
-  void* resnet(const ResnetW& r, const void* x1, const void* x2, int L) {
+  // ln_g != null: the block's last kernel also writes LayerNorm(out) * ln_g to *xn_out (the PreNorm of the attention
+  // block that consumes `out`)
+  void* resnet(const ResnetW& r, const void* x1, const void* x2, int L, const float* ln_g = nullptr, void** xn_out = nullptr) {
     const int rows = B * L, dt = c->dt, g = c->unet.groups, Bn = B;
     const UnetW* u = &c->unet;
     void* a = act(rows, r.cout);
@@ -1364,16 +1369,21 @@ struct PlanBuilder {
     conv(r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
     if (r.has_res) mark(3);
+    void* xn = nullptr;
+    if (ln_g && xn_out && c->fuse_ln && gn_apply_ln_fusable(r.cout)) {
+      xn = act(rows, r.cout);
+      *xn_out = xn;
+    }
     add([=](hipStream_t s) {
-      return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s);
-    }, false, 0, LDC_CLASS_GN_APPLY, 3.0 * Bn * L * rp->cout * es);
+      return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s, xn, ln_g);
+    }, false, 0, LDC_CLASS_GN_APPLY, (xn ? 4.0 : 3.0) * Bn * L * rp->cout * es);
     return out;
   }
   // Residual(PreNorm(LinearAttention)) (unet.py:208-222) / Residual(PreNorm(Attention)) (:234-246)
-  void* attention(const LinAttnW& a, const void* x, int L, bool linear) {
+  void* attention(const LinAttnW& a, const void* x, int L, bool linear, void* xn_pre = nullptr) {
     const int rows = B * L, dt = c->dt, Bn = B;
     const int H = c->unet.heads, Dh = c->unet.dim_head, hid = H * Dh;
-    void* xn = act(rows, a.dim);
+    void* xn = xn_pre ? xn_pre : act(rows, a.dim);
     void* qkv = act(rows, 3 * hid);
     void* o = act(rows, hid);
     void* out = act(rows, a.dim);
@@ -1381,8 +1391,9 @@ struct PlanBuilder {
     // one workspace per LinearAttention layer when the k column-max is fused: all of them are zeroed by the
     // step's single memset (they sit behind the GroupNorm statistics)
     float* ws = (linear && c->fuse_kmax) ? linattn_ws + (size_t)(linattn_used++) * B * linattn_ws_floats_per_item(H, Dh) : linattn_ws;
-    add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s); }, false, 0, LDC_CLASS_LAYERNORM,
-        2.0 * rows * a.dim * es);
+    if (!xn_pre)
+      add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s); }, false, 0, LDC_CLASS_LAYERNORM,
+          2.0 * rows * a.dim * es);
     if (linear) {
       const size_t wss = linattn_ws_floats_per_item(H, Dh);
       if (c->fuse_kmax) {
@@ -1475,8 +1486,9 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   for (size_t i = 0; i < u.downs.size(); ++i) {
     const LevelW& lv = u.downs[i];
     x = pb.resnet(lv.b1, x, nullptr, Lc); hs.push_back({x, Lc});
-    x = pb.resnet(lv.b2, x, nullptr, Lc);
-    x = pb.attention(lv.attn, x, Lc, true); hs.push_back({x, Lc});
+    void* xn = nullptr;
+    x = pb.resnet(lv.b2, x, nullptr, Lc, lv.attn.norm_g, &xn);
+    x = pb.attention(lv.attn, x, Lc, true, xn); hs.push_back({x, Lc});
     int Ln = Lc;
     if (lv.kind == 0) Ln = (Lc + 2 - 4) / 2 + 1;
     void* y = pb.act(B * Ln, lv.cout);
@@ -1484,16 +1496,20 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     x = y; Lc = Ln;
     pl->taps["down" + std::to_string(i)] = {y, lv.cout, Lc};
   }
-  x = pb.resnet(u.mid1, x, nullptr, Lc);
-  x = pb.attention(u.mid_attn, x, Lc, false);
+  {
+    void* xn = nullptr;
+    x = pb.resnet(u.mid1, x, nullptr, Lc, u.mid_attn.norm_g, &xn);
+    x = pb.attention(u.mid_attn, x, Lc, false, xn);
+  }
   x = pb.resnet(u.mid2, x, nullptr, Lc);
   pl->taps["mid"] = {const_cast<void*>(x), u.dims.back(), Lc};
   for (size_t i = 0; i < u.ups.size(); ++i) {
     const LevelW& lv = u.ups[i];
     if (hs.back().second != Lc) return fail(LDC_E_INVALID, "latent length %d is not divisible by 2^%zu", L, u.downs.size() - 1);
     x = pb.resnet(lv.b1, x, hs.back().first, Lc); hs.pop_back();
-    x = pb.resnet(lv.b2, x, hs.back().first, Lc); hs.pop_back();
-    x = pb.attention(lv.attn, x, Lc, true);
+    void* xn = nullptr;
+    x = pb.resnet(lv.b2, x, hs.back().first, Lc, lv.attn.norm_g, &xn); hs.pop_back();
+    x = pb.attention(lv.attn, x, Lc, true, xn);
     const int Ln = lv.kind == 1 ? 2 * Lc : Lc;
     void* y = pb.act(B * Ln, lv.cout);
     pb.conv(lv.resample, x, nullptr, y, nullptr, Lc, Ln);
@@ -1739,7 +1755,12 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   }
   int done = 0;
   if (!sg->exec || sg->noise != noise || sg->x != x || sg->stream != s) {
-    if (sg->exec) { (void)hipGraphExecDestroy(sg->exec); sg->exec = nullptr; }
+    if (sg->exec) {
+      // replays of the old executable graph may still be in flight on its stream: drain it before destroying
+      if (sg->stream) HIPCHK(hipStreamSynchronize(sg->stream));
+      (void)hipGraphExecDestroy(sg->exec);
+      sg->exec = nullptr;
+    }
     // first step eagerly: loads code objects / sets function attributes outside of the capture
     LDCCHK(one_step(c, h, x, noise, stride, s));
     done = 1;
@@ -2136,7 +2157,15 @@ extern "C" int ldc_gn_microbench(ldc_ctx* c, int dtype, int B, int L, int C, int
   HIPCHK(hipMemcpy(gb, hg.data(), hg.size() * 4, hipMemcpyHostToDevice));
   float* g = (float*)gb;
   hipStream_t s = c->own_stream;
-  auto go = [&]() { return launch_gn_apply(dt, x, y, with_residual ? r : nullptr, B, L, C, 8, (float*)st, g, g + C, g + 2 * C, 0, nullptr, ACT_SILU, s); };
+  void* yln = nullptr;
+  const int mode = getenv("LDC_GN_LN") ? atoi(getenv("LDC_GN_LN")) : 0;   // 1: fused LayerNorm output, 2: separate ln_rows launch
+  if (mode) LDCCHK(keep.alloc(&yln, n * es));
+  auto go = [&]() {
+    hipError_t e = launch_gn_apply(dt, x, y, with_residual ? r : nullptr, B, L, C, 8, (float*)st, g, g + C, g + 2 * C, 0, nullptr, ACT_SILU, s,
+                                   mode == 1 ? yln : nullptr, g);
+    if (e == hipSuccess && mode == 2) e = launch_ln_rows(dt, y, yln, nullptr, g, B * L, C, s);
+    return e;
+  };
   for (int i = 0; i < 3; ++i) HIPCHK(go());
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));

@@ -72,7 +72,9 @@ hipError_t launch_gn_stats(int dt, const void* x, int B, int L, int C, int group
 // by *t_ptr from a table with row stride ss_stride, or null.  eps 1e-5.
 hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual, int B, int L, int C, int groups,
                            const float* stats, const float* gamma, const float* beta, const float* ss_table,
-                           int ss_stride, const int* t_ptr, int act, hipStream_t s);
+                           int ss_stride, const int* t_ptr, int act, hipStream_t s, void* y_ln = nullptr, const float* ln_g = nullptr);
+// y_ln != null: also write channel-LayerNorm(y) * ln_g (needs gn_apply_ln_fusable(C) and ACT_SILU)
+bool gn_apply_ln_fusable(int C);
 // channel LayerNorm (gain only, biased var, eps 1e-5) per row; y = LN(x)*g (+ residual)
 hipError_t launch_ln_rows(int dt, const void* x, void* y, const void* residual, const float* g, int rows, int C,
                           hipStream_t s);

@@ -186,14 +186,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x, void* y, c
 // Fast variant: grid (row chunks, B).  The per-channel affine of this item (mean, rstd, gamma, beta and the
 // timestep scale/shift folded into a*x+b) is built once per workgroup in LDS; a thread then keeps ONE 8-channel
 // column and streams U rows with all loads in flight before the first use.  Needs C/8 to divide 256, C <= 2048.
-template <typename T, int ACT>   // ACT >= 0: compile-time activation; -1: runtime `act`
+// LN: additionally write the channel LayerNorm (unet.py:82-101, the PreNorm of the attention block that follows
+// a ResnetBlock) of the freshly produced rows to `y_ln`: a row's channels sit in C/8 consecutive threads, so the
+// two-pass mean/variance is a shuffle reduction (plus one LDS hop when a row spans two wavefronts, C = 1024).
+template <typename T, int ACT, bool LN, int VPR = 0, int U = 8>   // ACT >= 0: compile-time activation; -1: runtime `act`; VPR = C/8 (LN only); U rows per thread
 __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void* y, const void* residual, int L, int C,
                                                             int groups, int rows_per_block, const float* stats,
                                                             const float* gamma, const float* beta, const float* ss_table,
-                                                            int ss_stride, const int* t_ptr, int act, int dbg) {
+                                                            int ss_stride, const int* t_ptr, int act, int dbg,
+                                                            void* y_ln, const float* ln_g) {
   __shared__ __attribute__((aligned(16))) float s_a[2048];
   __shared__ __attribute__((aligned(16))) float s_b[2048];
-  constexpr int U = 8;
+  __shared__ float s_red[LN ? 2 * 4 * 8 : 1];   // [sum | sumsq][wave][q]
   const int vpr = C / 8;
   const int b = blockIdx.y;
   const int v = threadIdx.x % vpr, rph = threadIdx.x / vpr, nph = 256 / vpr;
@@ -240,9 +244,11 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
     cb[0] = b0.x; cb[1] = b0.y; cb[2] = b0.z; cb[3] = b0.w; cb[4] = b1.x; cb[5] = b1.y; cb[6] = b1.z; cb[7] = b1.w;
   }
   // 3. apply and store
+  float lsum[LN ? U : 1];
 #pragma unroll
   for (int q = 0; q < U; ++q) {
     const int r = rb + q * nph;
+    if (LN) lsum[q] = 0.f;
     if (r < r1) {
       float o[8];
 #pragma unroll
@@ -257,31 +263,127 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
       if (dbg & 8) Vec8<T>::store_nt(y, ((size_t)b * L + r) * C + v * 8, o);
       else if (!(dbg & 4)) Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
       else if (o[0] == 12345.678f) Vec8<T>::store(y, 0, o);
+      if (LN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { f[q][i] = o[i]; lsum[q] += o[i]; }
+      }
+    }
+  }
+  if (LN) {
+    // row-wise mean and (biased) variance in one sweep: a row = VPR consecutive threads, VPR compile-time
+    constexpr int SPAN = VPR < 64 ? VPR : 64;
+    const int wave = threadIdx.x >> 6;
+    const float inv_c = 1.0f / (float)(VPR * 8);
+    float lsq[U], mean[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = fmaf(f[q][i], f[q][i], acc);
+      lsq[q] = acc;
+    }
+#pragma unroll
+    for (int o = SPAN >> 1; o > 0; o >>= 1) {
+      float t0[U], t1[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) { t0[q] = __shfl_xor(lsum[q], o); t1[q] = __shfl_xor(lsq[q], o); }
+#pragma unroll
+      for (int q = 0; q < U; ++q) { lsum[q] += t0[q]; lsq[q] += t1[q]; }
+    }
+    if (VPR > 64) {   // a row spans VPR/64 wavefronts
+      if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < U; ++q) { s_red[wave * 8 + q] = lsum[q]; s_red[(4 + wave) * 8 + q] = lsq[q]; }
+      }
+      __syncthreads();
+      constexpr int WPR = VPR > 64 ? VPR / 64 : 1;
+      const int w0 = (wave / WPR) * WPR;
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPR; ++w) { a0 += s_red[(w0 + w) * 8 + q]; a1 += s_red[(4 + w0 + w) * 8 + q]; }
+        lsum[q] = a0; lsq[q] = a1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      mean[q] = lsum[q] * inv_c;
+      lsum[q] = fmaxf(lsq[q] * inv_c - mean[q] * mean[q], 0.0f);   // variance
+    }
+    float g8[8];
+    {
+      const float4 g0 = *reinterpret_cast<const float4*>(ln_g + v * 8), g1 = *reinterpret_cast<const float4*>(ln_g + v * 8 + 4);
+      g8[0] = g0.x; g8[1] = g0.y; g8[2] = g0.z; g8[3] = g0.w; g8[4] = g1.x; g8[5] = g1.y; g8[6] = g1.z; g8[7] = g1.w;
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int r = rb + q * nph;
+      if (r < r1) {
+        const float rstd = rsqrtf(lsum[q] + 1e-5f);
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (f[q][i] - mean[q]) * rstd * g8[i];
+        Vec8<T>::store(y_ln, ((size_t)b * L + r) * C + v * 8, o);
+      }
     }
   }
 }
 
+bool gn_apply_ln_fusable(int C) { return C == 256 || C == 512 || C == 1024; }
+
+// Rows per thread: these kernels run as ONE round of workgroups, so a thread's serial instruction stream (64
+// elements at U = 8: ~1500 VALU instructions with bf16 packing and SiLU) IS the kernel's duration.  Measured at the
+// half-batch level shapes: U = 8 8.3-10.4 us, U = 2 4.6-7.1 us, U = 1 4.0-7.6 us.  Pick the largest U that still
+// gives >= 4 workgroups per CU (LDC_GN_U overrides).
+static int gn_pick_u(int B, int L, int vpr) {
+  static int forced = -1;
+  if (forced < 0) forced = getenv("LDC_GN_U") ? atoi(getenv("LDC_GN_U")) : 0;
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+  const int nph = 256 / vpr;
+  for (int u = 8; u > 1; u >>= 1)
+    if ((long)B * ((L + nph * u - 1) / (nph * u)) >= 1024) return u;
+  return 1;
+}
+
+template <typename T, int ACT, bool LN, int VPR>
+static void gn_launch_u(int U, dim3 grid, hipStream_t s, const void* x, void* y, const void* residual, int L, int C, int groups, int rpb,
+                        const float* stats, const float* gamma, const float* beta, const float* ss_table, int ss_stride,
+                        const int* t_ptr, int act, int dbg, void* y_ln, const float* ln_g) {
+#define LDC_GN_GO(UU)                                                                                                     \
+  hipLaunchKernelGGL((gn_apply_cols_kernel<T, ACT, LN, VPR, UU>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, \
+                     stats, gamma, beta, ss_table, ss_stride, t_ptr, act, dbg, y_ln, ln_g)
+  if (U == 8) LDC_GN_GO(8); else if (U == 4) LDC_GN_GO(4); else if (U == 2) LDC_GN_GO(2); else LDC_GN_GO(1);
+#undef LDC_GN_GO
+}
+
 hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual, int B, int L, int C, int groups,
                            const float* stats, const float* gamma, const float* beta, const float* ss_table,
-                           int ss_stride, const int* t_ptr, int act, hipStream_t s) {
+                           int ss_stride, const int* t_ptr, int act, hipStream_t s, void* y_ln, const float* ln_g) {
   const int vpr = C / 8;
+  if (y_ln && (!gn_apply_ln_fusable(C) || act != ACT_SILU)) return hipErrorInvalidValue;
   if (C % 8 == 0 && vpr <= 256 && 256 % vpr == 0 && C <= 2048) {
-    const int rpb = (256 / vpr) * 8;   // one 8-row trip per thread
+    const int U = gn_pick_u(B, L, vpr);
+    const int rpb = (256 / vpr) * U;   // one U-row trip per thread
     static int dbg = -1;
     if (dbg < 0) dbg = getenv("LDC_GN_DEBUG") ? atoi(getenv("LDC_GN_DEBUG")) : 0;
     dim3 grid((L + rpb - 1) / rpb, B);
-    if (dt == DT_F32 && act == ACT_SILU)
-      hipLaunchKernelGGL((gn_apply_cols_kernel<float, ACT_SILU>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
-                         gamma, beta, ss_table, ss_stride, t_ptr, act, dbg);
-    else if (dt == DT_F32)
-      hipLaunchKernelGGL((gn_apply_cols_kernel<float, -1>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
-                         gamma, beta, ss_table, ss_stride, t_ptr, act, dbg);
-    else if (act == ACT_SILU)
-      hipLaunchKernelGGL((gn_apply_cols_kernel<__bf16, ACT_SILU>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
-                         gamma, beta, ss_table, ss_stride, t_ptr, act, dbg);
-    else
-      hipLaunchKernelGGL((gn_apply_cols_kernel<__bf16, -1>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, stats,
-                         gamma, beta, ss_table, ss_stride, t_ptr, act, dbg);
+#define LDC_GN_ARGS grid, s, x, y, residual, L, C, groups, rpb, stats, gamma, beta, ss_table, ss_stride, t_ptr, act, dbg, y_ln, ln_g
+    if (y_ln) {
+      if (dt == DT_F32) {
+        if (vpr == 32) gn_launch_u<float, ACT_SILU, true, 32>(U, LDC_GN_ARGS);
+        else if (vpr == 64) gn_launch_u<float, ACT_SILU, true, 64>(U, LDC_GN_ARGS);
+        else gn_launch_u<float, ACT_SILU, true, 128>(U, LDC_GN_ARGS);
+      } else {
+        if (vpr == 32) gn_launch_u<__bf16, ACT_SILU, true, 32>(U, LDC_GN_ARGS);
+        else if (vpr == 64) gn_launch_u<__bf16, ACT_SILU, true, 64>(U, LDC_GN_ARGS);
+        else gn_launch_u<__bf16, ACT_SILU, true, 128>(U, LDC_GN_ARGS);
+      }
+    } else if (dt == DT_F32 && act == ACT_SILU) gn_launch_u<float, ACT_SILU, false, 0>(U, LDC_GN_ARGS);
+    else if (dt == DT_F32) gn_launch_u<float, -1, false, 0>(U, LDC_GN_ARGS);
+    else if (act == ACT_SILU) gn_launch_u<__bf16, ACT_SILU, false, 0>(U, LDC_GN_ARGS);
+    else gn_launch_u<__bf16, -1, false, 0>(U, LDC_GN_ARGS);
+#undef LDC_GN_ARGS
     return hipGetLastError();
   }
   const size_t total = (size_t)B * L * (C / 8);
