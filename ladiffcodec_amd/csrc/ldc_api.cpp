@@ -179,6 +179,8 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
   void* cond_cl = nullptr;      // [B*L][cond_channels]   (processed)
   void* eps_cl = nullptr;       // [B*L][channels]
   float* maxabs = nullptr;      // [B]
+  int* step_state = nullptr;    // device int[2] {t, j} of THIS part: the parts of a batch advance independently
+  float* cur_ss = nullptr;      // [ss_stride] timestep-MLP row of the step this part is executing
   std::vector<std::function<hipError_t(hipStream_t)>> cond_ops;   // process_cond (once per denoise)
   std::vector<std::function<hipError_t(hipStream_t)>> step_ops;   // Unet1D.forward after process_cond
   std::vector<int> step_is_conv;                                   // 1 where step_ops[i] is a conv-GEMM launch
@@ -202,12 +204,13 @@ struct Halves {                // (the name dates from the two-way split; n part
   int b0[kMaxParts] = {0, 0, 0, 0};   // first item of each part
 };
 
-struct StepGraph {   // hipGraph of {unet step (both halves), p_sample_update, step_advance}
-  int B = 0, L = 0, F = 0;
+struct StepGraph {   // per batch part: hipGraph of {step_begin, unet step, p_sample_update, step_advance}
+  int B = 0, L = 0, F = 0, n = 0;
   const float* noise = nullptr;
   float* x = nullptr;
   hipStream_t stream = nullptr;
-  hipGraphExec_t exec = nullptr;
+  hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool any() const { return exec[0] != nullptr; }
 };
 
 struct ldc_ctx {
@@ -871,7 +874,8 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
 static void drop_plans(ldc_ctx* c) {
   (void)hipDeviceSynchronize();   // nothing captured or planned may still be running when it is destroyed
   for (auto& g : c->graphs)
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto& e : g.exec)
+      if (e) (void)hipGraphExecDestroy(e);
   c->graphs.clear();
   for (auto& pl : c->plans)
     for (hipEvent_t e : pl->marker_events) (void)hipEventDestroy(e);
@@ -1341,6 +1345,7 @@ struct PlanBuilder {
   void* resnet(const ResnetW& r, const void* x1, const void* x2, int L, const float* ln_g = nullptr, void** xn_out = nullptr) {
     const int rows = B * L, dt = c->dt, g = c->unet.groups, Bn = B;
     const UnetW* u = &c->unet;
+    const float* cur_ss = pl->cur_ss;
     void* a = act(rows, r.cout);
     void* b = act(rows, r.cout);
     void* d = act(rows, r.cout);
@@ -1363,7 +1368,7 @@ struct PlanBuilder {
     const ResnetW* rp = &r;
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
     add([=](hipStream_t s) {
-      return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, u->cur_ss + rp->ss_off,
+      return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, cur_ss + rp->ss_off,
                              0, nullptr, ACT_SILU, s);
     }, false, 0, LDC_CLASS_GN_APPLY, 2.0 * Bn * L * rp->cout * es);
     conv(r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
@@ -1435,6 +1440,8 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   pb.linattn_ws = pb.stats_pool + gn_bytes / 4;
   const size_t stats_bytes = gn_bytes + (c->fuse_kmax ? lin_bytes : 0);
   pl->maxabs = (float*)ar.alloc((size_t)B * 4);
+  pl->step_state = (int*)ar.alloc(64);
+  pl->cur_ss = (float*)ar.alloc((size_t)std::max(1, u.ss_stride) * 4);
   pl->x_cl = ar.alloc((size_t)B * L * Cx * es);
   pl->eps_cl = ar.alloc((size_t)B * L * Cx * es);
   pl->cond_cl = ar.alloc((size_t)B * L * Cc * es);
@@ -1657,10 +1664,10 @@ extern "C" int ldc_unet_forward(ldc_ctx* c, const float* x, int t, const float* 
   LDCCHK(get_halves(c, B, L, F, s, &h));
   LDCCHK(load_cond(c, h, cond, s));
   LDCCHK(load_x(c, h, x, s));
-  HIPCHK(launch_step_set(c->step_state, t, 0, s));
-  HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, c->step_state, c->unet.cur_ss, s));
   for (int k = 0; k < h.n; ++k) {
     Plan* pl = h.p[k];
+    HIPCHK(launch_step_set(pl->step_state, t, 0, s));
+    HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, s));
     LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
     HIPCHK(launch_from_cl(c->dt, pl->eps_cl, eps_out + (size_t)h.b0[k] * c->unet.channels * L, pl->B, c->unet.channels, L, nullptr,
                           0, 0.f, s));
@@ -1688,34 +1695,50 @@ extern "C" int ldc_unet_debug_tap(ldc_ctx* c, const char* name, float* out, int6
   return finish_stream(c, stream);
 }
 
+// one reverse-diffusion step of batch part k on stream s: select the timestep row, run the UNet, update the state,
+// advance this part's step counter.  Parts never interact, so each is a self-contained chain.
 static int half_step(ldc_ctx* c, const Halves& h, int k, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
   Plan* pl = h.p[k];
   const size_t off = (size_t)h.b0[k] * c->unet.channels * pl->L;
+  HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, s));
   LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
   HIPCHK(launch_p_sample_update(c->dt, x + off, pl->eps_cl, noise ? noise + off : nullptr, noise_stride, pl->x_cl, pl->B,
-                                c->unet.channels, pl->L, c->sched, c->step_state, c->cfg.noise_seed, (uint64_t)off, s));
+                                c->unet.channels, pl->L, c->sched, pl->step_state, c->cfg.noise_seed, (uint64_t)off, s));
+  HIPCHK(launch_step_advance(pl->step_state, s));
   return LDC_OK;
 }
 
-// one reverse-diffusion step for the whole batch; two halves fork onto the auxiliary stream and join again
-// (valid eagerly and under stream capture: the event edges become graph dependencies)
-static int one_step(ldc_ctx* c, const Halves& h, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
-  HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, c->step_state, c->unet.cur_ss, s));
-  static const bool serial_env = getenv("LDC_SERIAL") != nullptr;   // diagnostics: halves back to back, eager
-  if (h.n >= 2 && !c->profile && !serial_env) {
-    HIPCHK(hipEventRecord(c->ev_fork, s));
-    for (int k = 1; k < h.n; ++k) HIPCHK(hipStreamWaitEvent(c->aux_stream[k], c->ev_fork, 0));
+static bool parts_parallel(ldc_ctx* c, const Halves& h) {
+  static const bool serial_env = getenv("LDC_SERIAL") != nullptr;   // diagnostics: parts back to back, eager
+  return h.n >= 2 && !c->profile && !serial_env;
+}
+// the parts' streams pick up after everything queued on s / s waits for every part
+static int fork_parts(ldc_ctx* c, const Halves& h, hipStream_t s) {
+  HIPCHK(hipEventRecord(c->ev_fork, s));
+  for (int k = 1; k < h.n; ++k) HIPCHK(hipStreamWaitEvent(c->aux_stream[k], c->ev_fork, 0));
+  return LDC_OK;
+}
+static int join_parts(ldc_ctx* c, const Halves& h, hipStream_t s) {
+  for (int k = 1; k < h.n; ++k) {
+    HIPCHK(hipEventRecord(c->ev_join[k], c->aux_stream[k]));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
+  }
+  return LDC_OK;
+}
+static int set_steps(ldc_ctx* c, const Halves& h, int t, int j, hipStream_t s) {
+  for (int k = 0; k < h.n; ++k) HIPCHK(launch_step_set(h.p[k]->step_state, t, j, s));
+  return LDC_OK;
+}
 
-    LDCCHK(half_step(c, h, 0, x, noise, noise_stride, s));
-    for (int k = 1; k < h.n; ++k) {
-      LDCCHK(half_step(c, h, k, x, noise, noise_stride, c->aux_stream[k]));
-      HIPCHK(hipEventRecord(c->ev_join[k], c->aux_stream[k]));
-      HIPCHK(hipStreamWaitEvent(s, c->ev_join[k], 0));
-    }
+// one step of every part, eagerly: part 0 on s, the others on the auxiliary streams, joined at the end
+static int one_step(ldc_ctx* c, const Halves& h, float* x, const float* noise, int64_t noise_stride, hipStream_t s) {
+  if (parts_parallel(c, h)) {
+    LDCCHK(fork_parts(c, h, s));
+    for (int k = 0; k < h.n; ++k) LDCCHK(half_step(c, h, k, x, noise, noise_stride, k == 0 ? s : c->aux_stream[k]));
+    LDCCHK(join_parts(c, h, s));
   } else {
     for (int k = 0; k < h.n; ++k) LDCCHK(half_step(c, h, k, x, noise, noise_stride, s));
   }
-  HIPCHK(launch_step_advance(c->step_state, s));
   return LDC_OK;
 }
 
@@ -1730,7 +1753,7 @@ extern "C" int ldc_p_sample(ldc_ctx* c, float* x, int t, const float* cond, cons
   LDCCHK(get_halves(c, B, L, F, s, &h));
   LDCCHK(load_cond(c, h, cond, s));
   LDCCHK(load_x(c, h, x, s));
-  HIPCHK(launch_step_set(c->step_state, t, 0, s));
+  LDCCHK(set_steps(c, h, t, 0, s));
   LDCCHK(one_step(c, h, x, noise, 0, s));
   return finish_stream(c, stream);
 }
@@ -1739,7 +1762,7 @@ extern "C" int ldc_p_sample(ldc_ctx* c, float* x, int t, const float* cond, cons
 static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const float* noise, int n_steps, hipStream_t s) {
   const int L = h.p[0]->L, F = h.p[0]->F;
   const int64_t stride = (int64_t)B * c->unet.channels * L;
-  HIPCHK(launch_step_set(c->step_state, n_steps - 1, 0, s));
+  LDCCHK(set_steps(c, h, n_steps - 1, 0, s));
   static const bool serial_eager = getenv("LDC_SERIAL") != nullptr;
   if (c->profile || serial_eager || n_steps < 3) {
     for (int i = 0; i < n_steps; ++i) LDCCHK(one_step(c, h, x, noise, stride, s));
@@ -1753,29 +1776,47 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
     sg = &c->graphs.back();
     sg->B = B; sg->L = L; sg->F = F;
   }
+  const bool par = parts_parallel(c, h);
+  // steps per replayed graph: the parts fork at the head of the graph and join at its tail, so K > 1 lets them
+  // drift apart for K steps (concurrent replays of SEPARATE graphs on different streams were measured: the ROCm
+  // 7.2 runtime serialises them, 198 vs 188 ms)
+  static int K_env = -1;
+  if (K_env < 0) K_env = getenv("LDC_GRAPH_STEPS") ? std::max(1, atoi(getenv("LDC_GRAPH_STEPS"))) : 5;
+  const int K = std::min(K_env, std::max(1, n_steps - 1));
   int done = 0;
-  if (!sg->exec || sg->noise != noise || sg->x != x || sg->stream != s) {
-    if (sg->exec) {
-      // replays of the old executable graph may still be in flight on its stream: drain it before destroying
-      if (sg->stream) HIPCHK(hipStreamSynchronize(sg->stream));
-      (void)hipGraphExecDestroy(sg->exec);
-      sg->exec = nullptr;
+  if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K) {
+    if (sg->any()) {
+      // replays of the old executable graphs may still be in flight: drain before destroying
+      HIPCHK(hipDeviceSynchronize());
+      for (auto& e : sg->exec) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
     }
     // first step eagerly: loads code objects / sets function attributes outside of the capture
     LDCCHK(one_step(c, h, x, noise, stride, s));
     done = 1;
-    hipGraph_t g = nullptr;
-    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-    int r = one_step(c, h, x, noise, stride, s);
-    hipError_t e = hipStreamEndCapture(s, &g);
-    if (r != LDC_OK) { if (g) (void)hipGraphDestroy(g); return r; }
-    if (e != hipSuccess) return fail(LDC_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-    e = hipGraphInstantiate(&sg->exec, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { sg->exec = nullptr; return fail(LDC_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
-    sg->noise = noise; sg->x = x; sg->stream = s;
+    // exec[0]: K steps of every part; exec[1]: one step (remainder); the device-side step counters make every
+    // replay continue where the last one stopped
+    for (int which = 0; which < 2; ++which) {
+      const int steps = which == 0 ? K : 1;
+      if (which == 1 && K == 1) break;
+      hipGraph_t g = nullptr;
+      HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+      int r = LDC_OK;
+      if (par) r = fork_parts(c, h, s);
+      for (int k = 0; k < h.n && r == LDC_OK; ++k)
+        for (int i = 0; i < steps && r == LDC_OK; ++i) r = half_step(c, h, k, x, noise, stride, (k == 0 || !par) ? s : c->aux_stream[k]);
+      if (par && r == LDC_OK) r = join_parts(c, h, s);
+      hipError_t e = hipStreamEndCapture(s, &g);
+      if (r != LDC_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+      if (e != hipSuccess) return fail(LDC_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      e = hipGraphInstantiate(&sg->exec[which], g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (e != hipSuccess) { sg->exec[which] = nullptr; return fail(LDC_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+    }
+    sg->noise = noise; sg->x = x; sg->stream = s; sg->n = h.n * 100 + K;
   }
-  for (int i = done; i < n_steps; ++i) HIPCHK(hipGraphLaunch(sg->exec, s));
+  int i = done;
+  for (; i + K <= n_steps; i += K) HIPCHK(hipGraphLaunch(sg->exec[0], s));
+  for (; i < n_steps; ++i) HIPCHK(hipGraphLaunch(sg->exec[K == 1 ? 0 : 1], s));
   return LDC_OK;
 }
 
