@@ -371,59 +371,80 @@ hipError_t launch_linattn(int dt, const void* qkv, void* out, float* ws, int B, 
 // Full softmax attention at the bottleneck: one workgroup per (item, head); K and V of the head live in
 // LDS as fp32 (n <= 512), each thread owns query rows and runs an online softmax over the keys.
 // ---------------------------------------------------------------------------------------------
+// 64 queries x 4 key-partitions per workgroup: lane 4*i + p walks keys p, p+4, ... of query i with an online
+// softmax, the four partial states are merged with two butterfly exchanges, every lane then writes 8 of the 32
+// output channels.  (One thread per query was a 75-key serial loop on 75 of 256 threads: 36 us for L = 75.)
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_full_kernel(const void* qkv, void* out, int L, int H, float scale) {
+  constexpr int P = D + 4;   // padded row: the 4 lanes of a query read 4 different keys without bank conflicts
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sk = reinterpret_cast<float*>(smem_raw);   // [L][D]
-  float* sv = sk + (size_t)L * D;                   // [L][D]
+  float* sk = reinterpret_cast<float*>(smem_raw);   // [L][P]
+  float* sv = sk + (size_t)L * P;                   // [L][P]
   const int HD = H * D;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  for (int idx = threadIdx.x; idx < L * D; idx += 256) {
-    const int r = idx / D, c = idx % D;
-    const size_t base = ((size_t)(b * L + r)) * (3 * HD) + h * D + c;
-    sk[idx] = ld1<T>(qkv, base + HD);
-    sv[idx] = ld1<T>(qkv, base + 2 * HD);
+  for (int idx = threadIdx.x; idx < L * (D / 8); idx += 256) {
+    const int r = idx / (D / 8), c8 = idx % (D / 8);
+    const size_t base = ((size_t)(b * L + r)) * (3 * HD) + h * D + c8 * 8;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      sk[r * P + c8 * 8 + m] = ld1<T>(qkv, base + HD + m);
+      sv[r * P + c8 * 8 + m] = ld1<T>(qkv, base + 2 * HD + m);
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < L; i += 256) {
-    float q[D], acc[D];
-    const size_t qb = ((size_t)(b * L + i)) * (3 * HD) + h * D;
+  const int part = threadIdx.x & 3;
+  const int i = blockIdx.y * 64 + (threadIdx.x >> 2);
+  const int iq = min(i, L - 1);
+  float q[D], acc[D];
+  const size_t qb = ((size_t)(b * L + iq)) * (3 * HD) + h * D;
 #pragma unroll
-    for (int d = 0; d < D; ++d) { q[d] = ld1<T>(qkv, qb + d) * scale; acc[d] = 0.f; }
-    float m = -INFINITY, l = 0.f;
-    for (int j = 0; j < L; ++j) {
-      const float4* kj = reinterpret_cast<const float4*>(sk + (size_t)j * D);
-      float sdot = 0.f;
+  for (int d = 0; d < D; ++d) { q[d] = ld1<T>(qkv, qb + d) * scale; acc[d] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  for (int j = part; j < L; j += 4) {
+    const float4* kj = reinterpret_cast<const float4*>(sk + (size_t)j * P);
+    float sdot = 0.f;
 #pragma unroll
-      for (int d4 = 0; d4 < D / 4; ++d4) {
-        const float4 kv = kj[d4];
-        sdot += q[4 * d4] * kv.x + q[4 * d4 + 1] * kv.y + q[4 * d4 + 2] * kv.z + q[4 * d4 + 3] * kv.w;
-      }
-      const float mn = fmaxf(m, sdot);
-      const float corr = __expf(m - mn);
-      const float p = __expf(sdot - mn);
-      l = l * corr + p;
-      const float4* vj = reinterpret_cast<const float4*>(sv + (size_t)j * D);
-#pragma unroll
-      for (int d4 = 0; d4 < D / 4; ++d4) {
-        const float4 vv = vj[d4];
-        acc[4 * d4] = acc[4 * d4] * corr + p * vv.x;
-        acc[4 * d4 + 1] = acc[4 * d4 + 1] * corr + p * vv.y;
-        acc[4 * d4 + 2] = acc[4 * d4 + 2] * corr + p * vv.z;
-        acc[4 * d4 + 3] = acc[4 * d4 + 3] * corr + p * vv.w;
-      }
-      m = mn;
+    for (int d4 = 0; d4 < D / 4; ++d4) {
+      const float4 kv = kj[d4];
+      sdot += q[4 * d4] * kv.x + q[4 * d4 + 1] * kv.y + q[4 * d4 + 2] * kv.z + q[4 * d4 + 3] * kv.w;
     }
+    const float mn = fmaxf(m, sdot);
+    const float corr = __expf(m - mn);
+    const float p = __expf(sdot - mn);
+    l = l * corr + p;
+    const float4* vj = reinterpret_cast<const float4*>(sv + (size_t)j * P);
+#pragma unroll
+    for (int d4 = 0; d4 < D / 4; ++d4) {
+      const float4 vv = vj[d4];
+      acc[4 * d4] = acc[4 * d4] * corr + p * vv.x;
+      acc[4 * d4 + 1] = acc[4 * d4 + 1] * corr + p * vv.y;
+      acc[4 * d4 + 2] = acc[4 * d4 + 2] * corr + p * vv.z;
+      acc[4 * d4 + 3] = acc[4 * d4 + 3] * corr + p * vv.w;
+    }
+    m = mn;
+  }
+#pragma unroll
+  for (int step = 1; step <= 2; step <<= 1) {
+    const float mo = __shfl_xor(m, step), lo = __shfl_xor(l, step);
+    const float mn = fmaxf(m, mo);
+    const float c1 = mn == -INFINITY ? 0.f : __expf(m - mn), c2 = mn == -INFINITY ? 0.f : __expf(mo - mn);
+    l = l * c1 + lo * c2;
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = acc[d] * c1 + __shfl_xor(acc[d], step) * c2;
+    m = mn;
+  }
+  if (i < L) {
     const float inv = 1.0f / l;
     const size_t ob = ((size_t)(b * L + i)) * HD + h * D;
 #pragma unroll
-    for (int d = 0; d < D; ++d) st1<T>(out, ob + d, acc[d] * inv);
+    for (int d = 0; d < D; ++d)
+      if ((d >> 3) == part) st1<T>(out, ob + d, acc[d] * inv);
   }
 }
 
 hipError_t launch_attn_full(int dt, const void* qkv, void* out, int B, int L, int heads, int dim_head, hipStream_t s) {
   if (dim_head != 32) return hipErrorInvalidValue;
-  const size_t lds = (size_t)2 * L * dim_head * sizeof(float);
+  const size_t lds = (size_t)2 * L * (dim_head + 4) * sizeof(float);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)dim_head);
   static bool opt_in = false;
@@ -432,10 +453,11 @@ hipError_t launch_attn_full(int dt, const void* qkv, void* out, int B, int L, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<__bf16, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     opt_in = true;
   }
+  dim3 grid(B * heads, (L + 63) / 64);
   if (dt == DT_F32)
-    hipLaunchKernelGGL((attn_full_kernel<float, 32>), dim3(B * heads), dim3(256), lds, s, qkv, out, L, heads, scale);
+    hipLaunchKernelGGL((attn_full_kernel<float, 32>), grid, dim3(256), lds, s, qkv, out, L, heads, scale);
   else
-    hipLaunchKernelGGL((attn_full_kernel<__bf16, 32>), dim3(B * heads), dim3(256), lds, s, qkv, out, L, heads, scale);
+    hipLaunchKernelGGL((attn_full_kernel<__bf16, 32>), grid, dim3(256), lds, s, qkv, out, L, heads, scale);
   return hipGetLastError();
 }
 

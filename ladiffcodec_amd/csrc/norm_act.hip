@@ -447,9 +447,70 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const void* x, void* y, co
   }
 }
 
+// Row held in registers (C <= 512 * NV): one global read, two-pass statistics on the registers, one write.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_rows_reg_kernel(const void* x, void* y, const void* residual, const float* g,
+                                                          int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const int vec_per_row = C / 8;
+  float f[NV][8], r[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = lane + 64 * k;
+    if (v < vec_per_row) {
+      Vec8<T>::load(x, (size_t)row * C + v * 8, f[k]);
+      if (residual) Vec8<T>::load(residual, (size_t)row * C + v * 8, r[k]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += f[k][i];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (lane + 64 * k < vec_per_row) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = f[k][i] - mean; ss += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = rsqrtf(ss / (float)C + 1e-5f);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = lane + 64 * k;
+    if (v < vec_per_row) {
+      float o8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o8[i] = (f[k][i] - mean) * rstd * g[v * 8 + i];
+      if (residual) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] += r[k][i];
+      }
+      Vec8<T>::store(y, (size_t)row * C + v * 8, o8);
+    }
+  }
+}
+
 hipError_t launch_ln_rows(int dt, const void* x, void* y, const void* residual, const float* g, int rows, int C,
                           hipStream_t s) {
   if (C % 8) return hipErrorInvalidValue;
+  if (C <= 1024) {
+    const int nb = (rows + 3) / 4;
+    if (dt == DT_F32) {
+      if (C <= 512) hipLaunchKernelGGL((ln_rows_reg_kernel<float, 1>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C);
+      else hipLaunchKernelGGL((ln_rows_reg_kernel<float, 2>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C);
+    } else {
+      if (C <= 512) hipLaunchKernelGGL((ln_rows_reg_kernel<__bf16, 1>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C);
+      else hipLaunchKernelGGL((ln_rows_reg_kernel<__bf16, 2>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C);
+    }
+    return hipGetLastError();
+  }
   int blocks = std::min((rows + 3) / 4, 256 * 8);
   if (blocks < 1) blocks = 1;
   if (dt == DT_F32)
