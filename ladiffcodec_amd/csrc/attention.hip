@@ -8,16 +8,12 @@
 // passes over the qkv rows ([rows][384], channels-last): linattn reads qkv twice (k statistics,
 // then k,v) plus q once and writes [rows][128]; algorithmic bytes ~ rows * (384*2 + 128) * sizeof(dtype).
 #include "ldc_kernels.h"
+#include "ldc_math.h"
 
 namespace ldc {
 
 __device__ __forceinline__ float abf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short af2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short af2bf(float f) { return hw_bf16(f); }
 template <typename T>
 __device__ __forceinline__ float ld1(const void* p, size_t i);
 template <>

@@ -33,12 +33,7 @@ struct ConvKArgs {
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                                  // round to nearest even
-  return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return hw_bf16(f); }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {

@@ -8,16 +8,12 @@
 // All kernels here are HBM-bound: p_sample_update moves 4 fp32 reads/writes + 2 dtype accesses per
 // element of [B,128,L].
 #include "ldc_kernels.h"
+#include "ldc_math.h"
 
 namespace ldc {
 
 __device__ __forceinline__ float dbf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short df2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short df2bf(float f) { return hw_bf16(f); }
 template <typename T>
 __device__ __forceinline__ float dld(const void* p, size_t i);
 template <>

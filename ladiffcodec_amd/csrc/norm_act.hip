@@ -13,12 +13,7 @@
 namespace ldc {
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf(float f) { return hw_bf16(f); }
 
 // 8 consecutive channels per thread: one 16 B (bf16) or two 16 B (f32) accesses
 template <typename T>
@@ -57,14 +52,14 @@ struct Vec8<__bf16> {
   static __device__ __forceinline__ void store(void* p, size_t idx, const float (&v)[8]) {
     unsigned w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = hw_bf16x2(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p) + idx) = make_uint4(w[0], w[1], w[2], w[3]);
   }
   static __device__ __forceinline__ void store_nt(void* p, size_t idx, const float (&v)[8]) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     u4 w;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = hw_bf16x2(v[2 * i], v[2 * i + 1]);
     __builtin_nontemporal_store(w, reinterpret_cast<u4*>(reinterpret_cast<unsigned short*>(p) + idx));
   }
 };

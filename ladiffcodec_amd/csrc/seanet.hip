@@ -8,16 +8,12 @@
 //               sequential h_{t-1} -> h_t chain, latency-bound: one workgroup per utterance keeps W_hh in
 //               registers (H <= 128: one gate row per thread) or streams a k-major copy from L2 (H = 512).
 #include "ldc_kernels.h"
+#include "ldc_math.h"
 
 namespace ldc {
 
 __device__ __forceinline__ float sbf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short sf2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short sf2bf(float f) { return hw_bf16(f); }
 template <typename T>
 __device__ __forceinline__ float sld(const void* p, size_t i);
 template <>
