@@ -204,17 +204,31 @@ __device__ __forceinline__ void epilogue_gn_stats(const ConvKArgs& a, f32x16 (&a
     for (int bb = b_first; bb <= b_last; ++bb) {
       const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
       float s = 0.f, ss = 0.f;
+      if (b_first == b_last && m0 + BM <= M) {
+        // the usual case: the whole tile lies inside one item -- no per-element row predicates
+        if (col_ok) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (col_ok && m >= lo && m < hi) {
-            const float v = acc[i][j][r] + bv;
-            s += v;
-            ss += v * v;
-          }
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[i][j][r] + bv;
+              s += v;
+              ss = fmaf(v, v, ss);
+            }
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+            if (col_ok && m >= lo && m < hi) {
+              const float v = acc[i][j][r] + bv;
+              s += v;
+              ss += v * v;
+            }
+          }
+      }
       s += __shfl_xor(s, 32);
       ss += __shfl_xor(ss, 32);
 #pragma unroll

@@ -61,10 +61,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("LDC_LIB_PATH", LIB_PATH)   # tuning aid: A/B two builds of the library on one GPU box
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            f"(or `make -C {CSRC}`). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, i64p, fp = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p
     lib.ldc_last_error.restype = C.c_char_p
     lib.ldc_version.restype = C.c_char_p
