@@ -2162,22 +2162,24 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
   if (getenv("LDC_CONV_STAMPS")) {
     const int nblk = 1 << 16;
     void* st = nullptr;
-    LDCCHK(keep.alloc(&st, (size_t)nblk * 4 * 8));
-    HIPCHK(hipMemset(st, 0, (size_t)nblk * 4 * 8));
+    LDCCHK(keep.alloc(&st, (size_t)nblk * 8 * 8));
+    HIPCHK(hipMemset(st, 0, (size_t)nblk * 8 * 8));
     ldc::g_conv_stamps = (unsigned long long*)st;
     hipError_t le = launch_conv(ly, cc, s);
     ldc::g_conv_stamps = nullptr;
     HIPCHK(le);
     HIPCHK(hipStreamSynchronize(s));
-    std::vector<unsigned long long> h((size_t)nblk * 4);
+    std::vector<unsigned long long> h((size_t)nblk * 8);
     HIPCHK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
-    double pro = 0, loop = 0, epi = 0; int n = 0; unsigned long long tmin = ~0ull, tmax = 0;
+    double pro = 0, loop = 0, epi = 0, tab = 0, dma = 0; int n = 0;
     for (int b = 0; b < nblk; ++b) {
-      if (!h[4 * b + 3]) continue;
-      pro += (double)(h[4 * b + 1] - h[4 * b]); loop += (double)(h[4 * b + 2] - h[4 * b + 1]); epi += (double)(h[4 * b + 3] - h[4 * b + 2]);
-      tmin = std::min(tmin, h[4 * b]); tmax = std::max(tmax, h[4 * b + 3]); ++n;
+      if (!h[8 * b + 3]) continue;
+      pro += (double)(h[8 * b + 1] - h[8 * b]); loop += (double)(h[8 * b + 2] - h[8 * b + 1]); epi += (double)(h[8 * b + 3] - h[8 * b + 2]);
+      tab += (double)(h[8 * b + 4] - h[8 * b]); dma += (double)(h[8 * b + 5] - h[8 * b + 4]);
+      ++n;
     }
-    if (n) fprintf(stderr, "  stamps (100 MHz ticks): blocks=%d prologue=%.1f loop=%.1f epilogue=%.1f  kernel span=%.1f\n", n, pro / n, loop / n, epi / n, (double)(tmax - tmin));
+    if (n) fprintf(stderr, "  stamps (shader cycles per workgroup): blocks=%d prologue=%.1f (tile+copy tables %.1f, first copies issued %.1f, fragment tables %.1f) loop=%.1f epilogue=%.1f\n",
+                   n, pro / n, tab / n, dma / n, (pro - tab - dma) / n, loop / n, epi / n);
   }
   return LDC_OK;
 }
