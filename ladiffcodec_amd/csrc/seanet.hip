@@ -90,13 +90,18 @@ __global__ __launch_bounds__(4 * H) void lstm_reg_kernel(const void* pre, const 
   for (int t = 0; t < T_len; ++t) {
     float g = p_next;
     if (t + 1 < T_len) p_next = sld<T>(pre, ((size_t)b * T_len + t + 1) * (4 * H) + row);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // packed fp32 FMAs (v_pk_fma_f32): the 4H x H mat-vec is VALU-issue-bound, one instruction per two products
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < H; k += 4) {
       const float4 hv = *reinterpret_cast<const float4*>(&sh[k]);
-      a0 += w[k] * hv.x; a1 += w[k + 1] * hv.y; a2 += w[k + 2] * hv.z; a3 += w[k + 3] * hv.w;
+      const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+      const f32x2 w01 = {w[k], w[k + 1]}, w23 = {w[k + 2], w[k + 3]};
+      a01 = __builtin_elementwise_fma(w01, h01, a01);
+      a23 = __builtin_elementwise_fma(w23, h23, a23);
     }
-    g += (a0 + a1) + (a2 + a3);
+    g += (a01[0] + a01[1]) + (a23[0] + a23[1]);
     sg[row] = g;
     __syncthreads();
     if (row < H) {
