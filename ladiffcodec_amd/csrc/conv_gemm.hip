@@ -337,10 +337,16 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     if (e != hipSuccess || launched) return e;
   }
   a.win_rows = std::min(span, c.B * c.L_in) + 1;
-  const int bn = ly.bn;
+  int bn = ly.bn;
+  // few-tile GEMMs with a long K (the SEANet encoder's last strided / k=7 convs: 3 840 rows x 3 584..4 096 deep, 30
+  // tiles of 128 x 128 took 0.5 ms each on 30 CUs): 64 x 64 tiles put 4x the workgroups on the chip
+  const long tiles128 = (long)((M + 127) / 128) * (ly.n_pad / bn);
+  const bool small = !ly.tr_stride && tiles128 < 128 && ly.n_pad % 64 == 0 && bn >= 64;
+  if (small) bn = 64;
   a.tg = std::max(1, std::min(ly.taps, (40 * 1024) / (bn * kPitch)));
   const size_t lds = (size_t)(a.win_rows + 1) * kPitch + (size_t)a.tg * bn * kPitch;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (small) return ly.dt == DT_F32 ? launch_cfg<float, 2, 2, 1, 1>(a, M, lds, s) : launch_cfg<__bf16, 2, 2, 1, 1>(a, M, lds, s);
   if (ly.dt == DT_F32) {
     if (bn == 128) return launch_cfg<float, 2, 2, 2, 2>(a, M, lds, s);
     if (bn == 64) return launch_cfg<float, 2, 2, 2, 1>(a, M, lds, s);
