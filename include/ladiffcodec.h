@@ -124,6 +124,19 @@ int ldc_p_sample(ldc_ctx* ctx, float* x_inout, int t, const float* cond, const f
  * One denoise step is captured in a hipGraph keyed by (B, L, F) and replayed n_steps times. */
 int ldc_denoise(ldc_ctx* ctx, float* img_inout, const float* cond, const float* noise, int n_steps, int B, int L,
                 int F, void* stream);
+/* SURVEY.md section 8(f) row 1 -- the two alternative decode modes left commented in sample.py:96-122; same kernels,
+ * different loop driver.
+ * diffusion.p_sample_loop(shape, condition) (ddpm_loss.py:253-266): ancestral sampling over all timesteps.
+ * fill_start != 0: img is drawn ~N(0,1) on the device first (ddpm_loss.py:257); 0: img already holds the start image.
+ * noise [timesteps,B,C,L] or NULL as for ldc_denoise. */
+int ldc_p_sample_loop(ldc_ctx* ctx, float* img_inout, const float* cond, const float* noise, int fill_start, int B, int L,
+                      int F, void* stream);
+/* diffusion.infilling(infill_img, condition, midway_t, lam=lam) (ddpm_loss.py:331-367): per t = midway_t-1..0
+ *   img <- p_sample(img,t); img <- (1-lam) img + lam infill; infill <- p_sample(infill,t); img <- (1-lam) img + lam infill.
+ * Both img and infill_img are updated in place (the reference returns img).  fill_start != 0: img is drawn ~U[0,1) first
+ * (ddpm_loss.py:336).  noise [2*midway_t,B,C,L] (draw 2i for img, 2i+1 for infill at iteration i) or NULL. */
+int ldc_infilling(ldc_ctx* ctx, float* img_inout, float* infill_inout, const float* cond, int midway_t, const float* noise,
+                  float lam, int fill_start, int B, int L, int F, void* stream);
 /* sample.py:133-134: x /= std(x)+1e-8 ; x /= max|x|+1e-8.  per_item: 0 whole tensor, 1 per item. */
 int ldc_output_normalise(ldc_ctx* ctx, float* wav_inout, int B, int T, int per_item, void* stream);
 /* The whole per-batch body of synthesis() (sample.py:94-134) on resident buffers:

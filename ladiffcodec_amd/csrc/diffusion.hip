@@ -7,6 +7,8 @@
 //   output normalisation : sample.py:133-134
 // All kernels here are HBM-bound: p_sample_update moves 4 fp32 reads/writes + 2 dtype accesses per
 // element of [B,128,L].
+#include <algorithm>
+
 #include "ldc_kernels.h"
 #include "ldc_math.h"
 
@@ -223,6 +225,38 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const vo
     const int l = l0 + i, c = c0 + tx;
     if (l < L && c < C) dst<T>(x_cl, ((size_t)b * L + l) * C + c, tile[tx][i]);
   }
+}
+
+// start images of the alternative samplers: standard normal (p_sample_loop, ddpm_loss.py:257) or uniform [0,1)
+// (infilling, ddpm_loss.py:336) from the same counter-based generator; stream `step` keeps them apart from the
+// per-step noise draws
+__global__ __launch_bounds__(256) void random_fill_kernel(float* x, int64_t n, int uniform, uint64_t seed, unsigned step) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (uniform) {
+      unsigned c[4] = {(unsigned)i, (unsigned)((uint64_t)i >> 32), step, 0x4c444322u};
+      unsigned k[2] = {(unsigned)seed, (unsigned)(seed >> 32)};
+#pragma unroll
+      for (int r = 0; r < 10; ++r) philox_round(c, k);
+      x[i] = (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+    } else {
+      x[i] = philox_normal(seed, step, (uint64_t)i);
+    }
+  }
+}
+hipError_t launch_random_fill(float* x, int64_t n, int uniform, uint64_t seed, unsigned step, hipStream_t s) {
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(random_fill_kernel, dim3(std::max(1, blocks)), dim3(256), 0, s, x, n, uniform, seed, step);
+  return hipGetLastError();
+}
+
+// x = a*x + b*y (the blends of infilling, ddpm_loss.py:357,361)
+__global__ __launch_bounds__(256) void axpby_kernel(float* x, const float* y, float a, float b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = a * x[i] + b * y[i];
+}
+hipError_t launch_axpby(float* x, const float* y, float a, float b, int64_t n, hipStream_t s) {
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(axpby_kernel, dim3(std::max(1, blocks)), dim3(256), 0, s, x, y, a, b, n);
+  return hipGetLastError();
 }
 
 hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const float* noise, int64_t noise_step_stride,

@@ -1835,6 +1835,54 @@ extern "C" int ldc_denoise(ldc_ctx* c, float* img, const float* cond, const floa
   return finish_stream(c, stream);
 }
 
+// GaussianDiffusion1D.p_sample_loop (ddpm_loss.py:253-266): ancestral sampling over ALL timesteps from a standard
+// normal start.  img == NULL on entry is not allowed: the caller passes the buffer; fill_start != 0 draws the start
+// image on the device (Philox stream 0xffffffff), otherwise the buffer's contents are the start image (parity runs).
+extern "C" int ldc_p_sample_loop(ldc_ctx* c, float* img, const float* cond, const float* noise, int fill_start, int B, int L,
+                                 int F, void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!img || !cond) return fail(LDC_E_INVALID, "null tensor");
+  LDCCHK(check_unet_args(c, B, L, F));
+  hipStream_t s = pick_stream(c, stream);
+  if (fill_start) HIPCHK(launch_random_fill(img, (int64_t)B * c->unet.channels * L, 0, c->cfg.noise_seed, 0xffffffffu, s));
+  Halves h;
+  LDCCHK(get_halves(c, B, L, F, s, &h));
+  LDCCHK(load_cond(c, h, cond, s));
+  LDCCHK(load_x(c, h, img, s));
+  LDCCHK(denoise_loop(c, h, B, img, noise, c->unet.timesteps, s));
+  return finish_stream(c, stream);
+}
+
+// GaussianDiffusion1D.infilling (ddpm_loss.py:331-367): for t = midway_t-1 .. 0
+//   img <- p_sample(img, t); img <- (1-lam) img + lam infill; infill <- p_sample(infill, t); img <- (1-lam) img + lam infill
+// `noise` (optional, parity runs): [2*midway_t][B][C][L], draw 2*i for img and 2*i+1 for infill at iteration i.
+// fill_start != 0 draws the uniform [0,1) start image of ddpm_loss.py:336 on the device.
+extern "C" int ldc_infilling(ldc_ctx* c, float* img, float* infill_img, const float* cond, int midway_t, const float* noise,
+                             float lam, int fill_start, int B, int L, int F, void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!img || !infill_img || !cond) return fail(LDC_E_INVALID, "null tensor");
+  if (midway_t < 1 || midway_t > c->unet.timesteps) return fail(LDC_E_INVALID, "midway_t must be in [1,%d]", c->unet.timesteps);
+  LDCCHK(check_unet_args(c, B, L, F));
+  hipStream_t s = pick_stream(c, stream);
+  const int64_t n = (int64_t)B * c->unet.channels * L;
+  if (fill_start) HIPCHK(launch_random_fill(img, n, 1, c->cfg.noise_seed, 0xfffffffeu, s));
+  Halves h;
+  LDCCHK(get_halves(c, B, L, F, s, &h));
+  LDCCHK(load_cond(c, h, cond, s));
+  int draw = 0;
+  for (int t = midway_t - 1; t >= 0; --t) {
+    LDCCHK(load_x(c, h, img, s));
+    LDCCHK(set_steps(c, h, t, draw++, s));
+    LDCCHK(one_step(c, h, img, noise, n, s));
+    HIPCHK(launch_axpby(img, infill_img, 1.0f - lam, lam, n, s));
+    LDCCHK(load_x(c, h, infill_img, s));
+    LDCCHK(set_steps(c, h, t, draw++, s));
+    LDCCHK(one_step(c, h, infill_img, noise, n, s));
+    HIPCHK(launch_axpby(img, infill_img, 1.0f - lam, lam, n, s));
+  }
+  return finish_stream(c, stream);
+}
+
 static int ensure_outnorm(ldc_ctx* c, int B) {
   const size_t need = output_normalise_ws_bytes(B);
   if (need <= c->outnorm_ws_bytes) return LDC_OK;

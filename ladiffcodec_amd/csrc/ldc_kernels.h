@@ -113,6 +113,8 @@ struct StepTables {            // device pointers, fp32 [T]
 };
 // x [B][C][L] fp32 in place; eps_cl [B][L][C] dt; noise [.. j ..][B][C][L] fp32 or null (Philox);
 // also writes x_cl [B][L][C] dt (the next step's UNet input).  Reads t, j from st.
+hipError_t launch_random_fill(float* x, int64_t n, int uniform, uint64_t seed, unsigned step, hipStream_t s);
+hipError_t launch_axpby(float* x, const float* y, float a, float b, int64_t n, hipStream_t s);
 hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const float* noise, int64_t noise_step_stride,
                                   void* x_cl, int B, int C, int L, StepTables tb, const int* st, uint64_t seed,
                                   uint64_t elem_base, hipStream_t s);

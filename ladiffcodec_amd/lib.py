@@ -20,7 +20,7 @@ MAX_RATIOS = 8
 EXPORTS = [
     "ldc_last_error", "ldc_version", "ldc_create", "ldc_destroy", "ldc_set_weight", "ldc_finalize_weights",
     "ldc_seanet_encode", "ldc_seanet_decode", "ldc_rvq_encode", "ldc_rvq_decode", "ldc_get_cond",
-    "ldc_cond_upsample", "ldc_unet_forward", "ldc_p_sample", "ldc_denoise", "ldc_output_normalise", "ldc_decode",
+    "ldc_cond_upsample", "ldc_unet_forward", "ldc_p_sample", "ldc_denoise", "ldc_p_sample_loop", "ldc_infilling", "ldc_output_normalise", "ldc_decode",
     "ldc_sconv1d", "ldc_sconvtr1d", "ldc_slstm", "ldc_unet_debug_tap", "ldc_unet_step_cost", "ldc_profile_enable",
     "ldc_profile_read", "ldc_profile_read_classes", "ldc_conv_microbench", "ldc_gn_microbench",
 ]
@@ -82,6 +82,8 @@ def load() -> C.CDLL:
     lib.ldc_unet_forward.argtypes = [vp, fp, i32, fp, i32, i32, i32, fp, vp]
     lib.ldc_p_sample.argtypes = [vp, fp, i32, fp, fp, i32, i32, i32, vp]
     lib.ldc_denoise.argtypes = [vp, fp, fp, fp, i32, i32, i32, i32, vp]
+    lib.ldc_p_sample_loop.argtypes = [vp, fp, fp, fp, i32, i32, i32, i32, vp]
+    lib.ldc_infilling.argtypes = [vp, fp, fp, fp, i32, fp, C.c_float, i32, i32, i32, i32, vp]
     lib.ldc_output_normalise.argtypes = [vp, fp, i32, i32, i32, vp]
     lib.ldc_decode.argtypes = [vp, fp, i32, i32, i32, fp, i32, fp, fp, fp, vp, vp]
     lib.ldc_sconv1d.argtypes = [vp, fp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, fp, vp]

@@ -206,6 +206,42 @@ class Engine:
         self._exit()
         return img
 
+    def p_sample_loop(self, cond, img=None, noise=None, length: Optional[int] = None):
+        """diffusion.p_sample_loop: all `timesteps` ancestral steps from `img` (or from a device-drawn N(0,1) image)."""
+        cond = self._f32(cond)
+        B, _, F = cond.shape
+        if img is None:
+            Lx = int(length) if length is not None else F * int(np.prod(self.unet.upsampling_ratios))
+            img = self.torch.empty(B, self.unet.inp_channels, Lx, device=cond.device, dtype=self.torch.float32)
+            fill = 1
+        else:
+            img = self._f32(img).clone()
+            fill = 0
+        noise = self._f32(noise) if noise is not None else None
+        s = self._enter()
+        L.check(self.lib.ldc_p_sample_loop(self._ctx, img.data_ptr(), cond.data_ptr(),
+                                           noise.data_ptr() if noise is not None else None, fill, B, img.shape[2], F, s))
+        self._exit()
+        return img
+
+    def infilling(self, infill_img, cond, midway_t: int, lam: float = 0.8, img=None, noise=None):
+        """diffusion.infilling; returns (img, infill_img) after the loop (the reference returns img)."""
+        cond = self._f32(cond)
+        infill = self._f32(infill_img).clone()
+        B, _, Lx = infill.shape
+        if img is None:
+            img = self.torch.empty_like(infill)
+            fill = 1
+        else:
+            img = self._f32(img).clone()
+            fill = 0
+        noise = self._f32(noise) if noise is not None else None
+        s = self._enter()
+        L.check(self.lib.ldc_infilling(self._ctx, img.data_ptr(), infill.data_ptr(), cond.data_ptr(), int(midway_t),
+                                       noise.data_ptr() if noise is not None else None, float(lam), fill, B, Lx, cond.shape[2], s))
+        self._exit()
+        return img, infill
+
     def output_normalise(self, wav, per_item: bool = False):
         wav = self._f32(wav).clone()
         B = wav.shape[0]
@@ -341,6 +377,21 @@ class _Diffusion:
         if tuple(img.shape) == tuple(condition.shape):       # ddpm_loss.py:376-378
             img = self._eng.cond_upsample(img, 0)
         return self._eng.denoise(img, condition, int(t), noise)
+
+    def p_sample_loop(self, shape, condition=None, img=None, noise=None):
+        """ddpm_loss.py:253-266; `img`/`noise` inject the start image and the per-step draws (parity runs)."""
+        return self._eng.p_sample_loop(condition, img=img, noise=noise, length=shape[2])
+
+    def sample(self, batch_size=16, condition=None):
+        """ddpm_loss.py:305-309 (DDIM sampling is not on the hot path: is_ddim_sampling is False at 1000 steps)."""
+        assert self.seq_length is not None, "set diffusion.seq_length as the reference's constructor does"
+        return self.p_sample_loop((batch_size, self._eng.unet.inp_channels, self.seq_length), condition)
+
+    def infilling(self, infill_img, condition, midway_t=None, noise=None, offset=0, lam=0.8, img=None, noises=None):
+        """ddpm_loss.py:331-367 (`noise` and `offset` are accepted and unused, as in the reference); `img`/`noises`
+        inject the start image and the 2*midway_t draws (parity runs)."""
+        out, _ = self._eng.infilling(infill_img, condition, int(midway_t), lam=lam, img=img, noise=noises)
+        return out
 
 
 class DiffAudioRep:

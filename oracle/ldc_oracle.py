@@ -400,6 +400,32 @@ def halfway_sampling(sd: SD, u: UnetConfig, img: torch.Tensor, cond: torch.Tenso
     return img
 
 
+def _draw(noises, j):
+    return noises(j) if callable(noises) else noises[j]
+
+
+def p_sample_loop(sd: SD, u: UnetConfig, img: torch.Tensor, cond: torch.Tensor, noises) -> torch.Tensor:
+    """GaussianDiffusion1D.p_sample_loop, ddpm_loss.py:253-266: t = T-1 ... 0 over ALL timesteps, starting from `img`
+    (the reference draws it ~ N(0,1), :257).  `noises[j]` (or noises(j)) is the draw of loop iteration j."""
+    T = int(sd["diffusion.betas"].shape[0])
+    for j, t in enumerate(reversed(range(T))):
+        img = p_sample(sd, u, img, t, cond, None if t == 0 else _draw(noises, j))
+    return img
+
+
+def infilling(sd: SD, u: UnetConfig, img: torch.Tensor, infill_img: torch.Tensor, cond: torch.Tensor, midway_t: int,
+              noises, lam: float = 0.8):
+    """GaussianDiffusion1D.infilling, ddpm_loss.py:331-367 (self_condition False).  `img` is the start image (the
+    reference draws it ~ U[0,1), :336); draws 2i / 2i+1 feed the two p_sample calls of iteration i.  Returns
+    (img, infill_img); the reference returns img."""
+    for i, t in enumerate(reversed(range(midway_t))):
+        img = p_sample(sd, u, img, t, cond, None if t == 0 else _draw(noises, 2 * i))            # :349
+        img = (1 - lam) * img + lam * infill_img                                                   # :357
+        infill_img = p_sample(sd, u, infill_img, t, cond, None if t == 0 else _draw(noises, 2 * i + 1))   # :359
+        img = (1 - lam) * img + lam * infill_img                                                   # :361
+    return img, infill_img
+
+
 # ----------------------------------------------------------------------------------------------
 # L5 harness arithmetic  (reference srcs/sample.py:94-134)
 # ----------------------------------------------------------------------------------------------

@@ -41,3 +41,15 @@ def T(x):
 def rel_err(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def driver_noises(g):
+    """The noise tapes of tests/golden/drivers_*.npz, regenerated from the recorded seed exactly as tools/gen_golden.py
+    drew them (the tapes themselves would be 40 MB): (loop draws [T,1,128,L], infilling draws [2*midway_t,1,128,L])."""
+    _, _, seed_in, midway_t, n_t = (int(v) for v in g["meta"])
+    L = g["loop_img0"].shape[2]
+    gg = torch.Generator().manual_seed(seed_in + 1)
+    loop = torch.stack([torch.randn(1, 128, L, generator=gg) for _ in range(n_t)])
+    g2 = torch.Generator().manual_seed(seed_in + 3)
+    fill = torch.stack([torch.randn(1, 128, L, generator=g2) for _ in range(2 * midway_t)])
+    return loop, fill, midway_t

@@ -293,3 +293,31 @@ def test_full_width_unet_step_against_oracle(dtype):
     have = e.denoise(img.cuda(), cond.cuda(), n, noise.cuda()).cpu()
     assert rel(have.numpy(), want.numpy()) < (1e-3 if dtype == "f32" else 0.2)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------- other samplers
+def test_p_sample_loop_and_infilling_drivers():
+    """diffusion.p_sample_loop (1000 steps, 5 per replayed graph) and diffusion.infilling through the C ABI against the
+    reference's runs (tests/golden/drivers_r84.npz) with injected start images and noise tapes; then the device-drawn
+    (Philox) variants: finite, bounded, reproducible."""
+    from helpers import driver_noises
+    g = load_golden("drivers_r84")
+    e = engine("r84", "f32")
+    loop_noise, fill_noise, midway_t = driver_noises(g)
+    cond = cu(g["cond"])
+    got = e.p_sample_loop(cond, img=cu(g["loop_img0"]), noise=loop_noise.cuda())
+    assert rel(got.cpu().numpy(), g["loop_out"]) < 2e-3
+    img, infill = e.infilling(cu(g["fill_infill0"]), cond, midway_t, lam=0.8, img=cu(g["fill_img0"]), noise=fill_noise.cuda())
+    assert rel(img.cpu().numpy(), g["fill_out"]) < 1e-4
+    # facade with the reference's names
+    from ladiffcodec_amd.model import DiffAudioRep
+    m = DiffAudioRep(e, L.MODEL_MAIN)
+    same = m.diffusion.infilling(cu(g["fill_infill0"]), cond, midway_t=midway_t, lam=0.8, img=cu(g["fill_img0"]), noises=fill_noise.cuda())
+    assert torch.equal(same, img) or rel(same.cpu().numpy(), img.cpu().numpy()) < 1e-5
+    # device-side start images and draws
+    a = e.infilling(cu(g["fill_infill0"]), cond, 4)[0]
+    b = e.infilling(cu(g["fill_infill0"]), cond, 4)[0]
+    assert torch.isfinite(a).all() and rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    m.diffusion.seq_length = g["loop_img0"].shape[2]
+    s1 = m.diffusion.sample(batch_size=1, condition=cond)
+    assert s1.shape == (1, 128, g["loop_img0"].shape[2]) and torch.isfinite(s1).all() and float(s1.abs().max()) <= 1.0 + 1e-4

@@ -6,7 +6,7 @@ import torch
 
 from ladiffcodec_amd import synth
 from oracle import ldc_oracle as O
-from helpers import CASES, COND_CFG, T, cond_sd_np, load_golden, main_sd_np, rel_err
+from helpers import CASES, COND_CFG, T, cond_sd_np, driver_noises, load_golden, main_sd_np, rel_err
 
 TOL = 2e-5   # fp32 CPU vs fp32 CPU, different op order only
 
@@ -101,3 +101,17 @@ def test_end_to_end_stage_tensors():
     assert rel_err(out["img0"].numpy(), g["img0"]) < TOL
     assert rel_err(out["latents"].numpy(), g["latents"]) < 2e-4
     assert rel_err(out["wav"].numpy(), g["wav_out"]) < 1e-3
+
+
+def test_alternative_samplers_match_reference():
+    """p_sample_loop (all 1000 steps from a normal start) and infilling, against the
+    reference's own runs with the same start images and noise tapes."""
+    g = load_golden("drivers_r84")
+    mc, u, _ = CASES["r84"]
+    sd = synth.to_torch(main_sd_np("r84"))
+    loop_noise, fill_noise, midway_t = driver_noises(g)
+    cond = T(g["cond"])
+    out = O.p_sample_loop(sd, u, T(g["loop_img0"]), cond, loop_noise)
+    assert rel_err(out.numpy(), g["loop_out"]) < 2e-4      # 1000 chained steps
+    img, _ = O.infilling(sd, u, T(g["fill_img0"]), T(g["fill_infill0"]), cond, midway_t, fill_noise, lam=0.8)
+    assert rel_err(img.numpy(), g["fill_out"]) < TOL

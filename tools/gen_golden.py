@@ -71,6 +71,14 @@ class NoiseTape:
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = os.environ.get("GOLDEN_ONLY")   # regenerate a single fixture family (the zip containers carry timestamps)
+    if only:
+        real_save = np.savez_compressed
+
+        def filtered(path, **kw):
+            if only in os.path.basename(path):
+                real_save(path, **kw)
+        np.savez_compressed = filtered
     ref = import_reference()
     import srcs.losses.ddpm_loss as ref_ddpm
     from srcs.modules.conv import SConv1d, SConvTranspose1d
@@ -188,8 +196,60 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"ladiff_{tag}.npz"), **out)
         print(f"ladiff_{tag}: L={L} eps", out["eps_t0"].shape, "latents absmax", float(np.abs(out["latents"]).max()))
 
+    # ---------------------------------------------------------------- p_sample_loop and infilling drivers
+    def drivers_case(tag, mc, u, T, seed_w, seed_in, midway_t):
+        main = build_main_model(ref, mc, u, seed=seed_w)
+        wav = torch.from_numpy(synth.synthetic_wav(1, T, seed=seed_in)) * 0.5
+        L = T // mc.hop_length
+        n_t = main.diffusion.num_timesteps
+        out = {"wav": np32(wav), "meta": np.array([seed_w, T, seed_in, midway_t, n_t], np.int64)}
+        with torch.no_grad():
+            cond = cond_model.get_cond(wav)
+            out["cond"] = np32(cond)
+            # p_sample_loop: start image torch.randn(shape) from the global generator, per-step draws from a tape
+            # regenerated at test time from the same seeds (the tape itself would be 82 MB)
+            torch.manual_seed(seed_in)
+            img0 = torch.randn(1, 128, L)
+            gg = torch.Generator().manual_seed(seed_in + 1)
+            tape = NoiseTape([torch.randn(1, 128, L, generator=gg) for _ in range(n_t)])
+            ref_ddpm.torch.randn_like, saved = tape, ref_ddpm.torch.randn_like
+            ref_ddpm.tqdm, saved_tqdm = (lambda it, **k: it), ref_ddpm.tqdm
+            try:
+                torch.manual_seed(seed_in)
+                res = main.diffusion.p_sample_loop((1, 128, L), condition=cond)
+                assert tape.i == n_t - 1
+                out["loop_img0"] = np32(img0)
+                out["loop_out"] = np32(res)
+                # infilling: start image torch.rand(...) from the global generator; `noise` given so that the
+                # reference's unused default draw (:352) does not consume a tape entry
+                main.diffusion.seq_length = L
+                torch.manual_seed(seed_in + 2)
+                fill0 = torch.rand(1, 128, L)
+                infill = cond
+                for layer in main.diff_model.upsampling_layers:
+                    infill = layer(infill)
+                infill = infill / (torch.max(torch.abs(infill.flatten())) + 1e-8)
+                g2 = torch.Generator().manual_seed(seed_in + 3)
+                tape2 = NoiseTape([torch.randn(1, 128, L, generator=g2) for _ in range(2 * midway_t)])
+                ref_ddpm.torch.randn_like = tape2
+                torch.manual_seed(seed_in + 2)
+                filled = main.diffusion.infilling(infill.clone(), cond, midway_t=midway_t, noise=torch.zeros(1), lam=0.8)
+                assert tape2.i == 2 * (midway_t - 1)
+                out["fill_img0"] = np32(fill0)
+                out["fill_infill0"] = np32(infill)
+                out["fill_out"] = np32(filled)
+            finally:
+                ref_ddpm.torch.randn_like = saved
+                ref_ddpm.tqdm = saved_tqdm
+        np.savez_compressed(os.path.join(OUT, f"drivers_{tag}.npz"), **out)
+        print(f"drivers_{tag}: loop_out absmax", float(np.abs(out["loop_out"]).max()), "fill_out absmax", float(np.abs(out["fill_out"]).max()))
+
     mc84 = CodecConfig(enc_ratios=(8, 4), quantization=False)
     u84 = UnetConfig(dim=32, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    if os.environ.get("GOLDEN_ONLY") == "drivers":
+        drivers_case("r84", mc84, u84, T=2560, seed_w=21, seed_in=777, midway_t=5)
+        return
+    drivers_case("r84", mc84, u84, T=2560, seed_w=21, seed_in=777, midway_t=5)
     ladiff_case("r84", mc84, u84, T=5120, n_chain=4, seed_w=21, seed_in=4321)
     mc8 = CodecConfig(enc_ratios=(8,), quantization=False)
     u8 = UnetConfig(dim=32, upsampling_ratios=(5, 4, 2), unet_scale_cond=False)

@@ -55,6 +55,20 @@ def import_reference():
     _placeholder("librosa")
     _placeholder("srcs.modules.transformer_discrete", Transformer=object)
     _placeholder("srcs.losses.discrete_diff", AbsorbingDiffusion=object)
-    sys.path.insert(0, REFERENCE_ROOT)
-    import srcs.model as ref_model  # noqa: E402
+    # this repo ships its own `srcs` package (the `python -m srcs.sample` drop-in shim): make sure the name resolves
+    # to the reference here
+    for name in [n for n in sys.modules if n == "srcs" or (n.startswith("srcs.") and not hasattr(sys.modules[n], "Transformer")
+                                                        and not hasattr(sys.modules[n], "AbsorbingDiffusion"))]:
+        del sys.modules[name]
+    # (the reference's `srcs` has no __init__.py, i.e. it is a namespace package, and a regular package of the same
+    # name anywhere on sys.path wins over it: hide those entries while importing)
+    import os
+    hidden = [p for p in sys.path if os.path.exists(os.path.join(p or ".", "srcs", "__init__.py"))]
+    saved_path = list(sys.path)
+    sys.path[:] = [REFERENCE_ROOT] + [p for p in sys.path if p not in hidden]
+    try:
+        import srcs.model as ref_model  # noqa: E402
+    finally:
+        sys.path[:] = [REFERENCE_ROOT] + saved_path
+    assert ref_model.__file__.startswith(REFERENCE_ROOT), ref_model.__file__
     return ref_model
