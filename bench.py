@@ -100,6 +100,12 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=1)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: RCCL prints a banner (version / hostname / library path) on
+    # file descriptor 1 when the process group comes up, so route fd 1 to stderr until the result is written
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank, local_rank, world = parallel.init_process_group("nccl")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -213,7 +219,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cc, mc, u, sd_cond, sd_main, N, args.seconds, args.cpu_batch)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
+    os.close(result_fd)
     eng.close()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
