@@ -184,17 +184,25 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const vo
                                                               int64_t noise_step_stride, void* x_cl, int C, int L,
                                                               StepTables tb, const int* st, uint64_t seed, uint64_t elem_base) {
   __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  // the tensor loads do not depend on the step: issue them before the (dependent) step-counter -> schedule-table chain
+  // eps tile: read channels-last (coalesced over c), hand over transposed
+  float ev[4], xin[4];
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int i = ty + ii * 8;
+    const int l = l0 + i, c = c0 + tx;
+    ev[ii] = (l < L && c < C) ? dld<T>(eps_cl, ((size_t)b * L + l) * C + c) : 0.f;
+    const int cc = c0 + i, ll = l0 + tx;
+    xin[ii] = (cc < C && ll < L) ? x[((size_t)b * C + cc) * L + ll] : 0.f;
+  }
   const int t = st[0], j = st[1];
   const float recip = tb.sqrt_recip_alphas_cumprod[t], recipm1 = tb.sqrt_recipm1_alphas_cumprod[t];
   const float c1 = tb.posterior_mean_coef1[t], c2 = tb.posterior_mean_coef2[t];
   const float sigma = expf(0.5f * tb.posterior_log_variance_clipped[t]);
-  const int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  // eps tile: read channels-last (coalesced over c), hand over transposed
-  for (int i = ty; i < 32; i += 8) {
-    const int l = l0 + i, c = c0 + tx;
-    tile[i][tx] = (l < L && c < C) ? dld<T>(eps_cl, ((size_t)b * L + l) * C + c) : 0.f;
-  }
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) tile[ty + ii * 8][tx] = ev[ii];
   __syncthreads();
   float newv[4];
 #pragma unroll
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const vo
     newv[ii] = 0.f;
     if (c < C && l < L) {
       const size_t idx = ((size_t)b * C + c) * L + l;
-      const float xv = x[idx];
+      const float xv = xin[ii];
       const float e = tile[tx][i];
       float x0 = recip * xv - recipm1 * e;
       x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
