@@ -175,6 +175,24 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, unsigned step, uin
   return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
 }
 
+// four normals from one Philox block: both Box-Muller branches of two (u1, u2) pairs
+__device__ __forceinline__ void philox_normal4(uint64_t seed, unsigned step, uint64_t group, float (&z)[4]) {
+  unsigned c[4] = {(unsigned)group, (unsigned)(group >> 32), step, 0x4c444323u};
+  unsigned k[2] = {(unsigned)seed, (unsigned)(seed >> 32)};
+#pragma unroll
+  for (int i = 0; i < 10; ++i) philox_round(c, k);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)(c[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+    const float u2 = (float)(c[2 * h + 1] >> 8) * (1.0f / 16777216.0f);        // [0,1)
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    z[2 * h] = r * cs;
+    z[2 * h + 1] = r * sn;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // p_sample update on [B][C][L] fp32 state, eps arriving channels-last; also emits the channels-last
 // copy of the new state for the next UNet call.  Tile: 32 positions x 32 channels.
@@ -205,6 +223,10 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const vo
   for (int ii = 0; ii < 4; ++ii) tile[ty + ii * 8][tx] = ev[ii];
   __syncthreads();
   float newv[4];
+  // the thread's four elements (channels c0+ty+{0,8,16,24}, one position) share one Philox block; the block index is
+  // the global index of the first of them, so the draws do not depend on how the batch is split
+  float zz[4] = {0.f, 0.f, 0.f, 0.f};
+  if (t > 0 && !noise) philox_normal4(seed, (unsigned)j, elem_base + ((size_t)b * C + c0 + ty) * L + l0 + tx, zz);
 #pragma unroll
   for (int ii = 0; ii < 4; ++ii) {
     const int i = ty + ii * 8;
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const vo
       x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
       float v = c1 * x0 + c2 * xv;
       if (t > 0) {
-        const float z = noise ? noise[(size_t)j * noise_step_stride + idx] : philox_normal(seed, (unsigned)j, elem_base + idx);
+        const float z = noise ? noise[(size_t)j * noise_step_stride + idx] : zz[ii];
         v += sigma * z;
       }
       x[idx] = v;
