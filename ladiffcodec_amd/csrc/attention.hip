@@ -7,6 +7,8 @@
 // The 1x1 convs either side run on the conv-GEMM kernel.  These cores are HBM/L2-bound streaming
 // passes over the qkv rows ([rows][384], channels-last): linattn reads qkv twice (k statistics,
 // then k,v) plus q once and writes [rows][128]; algorithmic bytes ~ rows * (384*2 + 128) * sizeof(dtype).
+#include <algorithm>
+
 #include "ldc_kernels.h"
 #include "ldc_math.h"
 
@@ -370,24 +372,16 @@ hipError_t launch_linattn(int dt, const void* qkv, void* out, float* ws, int B, 
 // 64 queries x 4 key-partitions per workgroup: lane 4*i + p walks keys p, p+4, ... of query i with an online
 // softmax, the four partial states are merged with two butterfly exchanges, every lane then writes 8 of the 32
 // output channels.  (One thread per query was a 75-key serial loop on 75 of 256 threads: 36 us for L = 75.)
+// Keys/values pass through LDS in chunks of CH positions, so the sequence length is unbounded (a 35 s utterance
+// has n = 1094 at the bottleneck; the reference's softmax attention has no limit either).
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_full_kernel(const void* qkv, void* out, int L, int H, float scale) {
+__global__ __launch_bounds__(256) void attn_full_kernel(const void* qkv, void* out, int L, int H, float scale, int CH) {
   constexpr int P = D + 4;   // padded row: the 4 lanes of a query read 4 different keys without bank conflicts
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sk = reinterpret_cast<float*>(smem_raw);   // [L][P]
-  float* sv = sk + (size_t)L * P;                   // [L][P]
+  float* sk = reinterpret_cast<float*>(smem_raw);   // [CH][P]
+  float* sv = sk + (size_t)CH * P;                  // [CH][P]
   const int HD = H * D;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  for (int idx = threadIdx.x; idx < L * (D / 8); idx += 256) {
-    const int r = idx / (D / 8), c8 = idx % (D / 8);
-    const size_t base = ((size_t)(b * L + r)) * (3 * HD) + h * D + c8 * 8;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      sk[r * P + c8 * 8 + m] = ld1<T>(qkv, base + HD + m);
-      sv[r * P + c8 * 8 + m] = ld1<T>(qkv, base + 2 * HD + m);
-    }
-  }
-  __syncthreads();
   const int part = threadIdx.x & 3;
   const int i = blockIdx.y * 64 + (threadIdx.x >> 2);
   const int iq = min(i, L - 1);
@@ -396,28 +390,42 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const void* qkv, void* o
 #pragma unroll
   for (int d = 0; d < D; ++d) { q[d] = ld1<T>(qkv, qb + d) * scale; acc[d] = 0.f; }
   float m = -INFINITY, l = 0.f;
-  for (int j = part; j < L; j += 4) {
-    const float4* kj = reinterpret_cast<const float4*>(sk + (size_t)j * P);
-    float sdot = 0.f;
+  for (int k0 = 0; k0 < L; k0 += CH) {
+    const int nk = min(CH, L - k0);
+    if (k0) __syncthreads();   // everyone is done with the previous chunk
+    for (int idx = threadIdx.x; idx < nk * (D / 8); idx += 256) {
+      const int r = idx / (D / 8), c8 = idx % (D / 8);
+      const size_t base = ((size_t)(b * L + k0 + r)) * (3 * HD) + h * D + c8 * 8;
 #pragma unroll
-    for (int d4 = 0; d4 < D / 4; ++d4) {
-      const float4 kv = kj[d4];
-      sdot += q[4 * d4] * kv.x + q[4 * d4 + 1] * kv.y + q[4 * d4 + 2] * kv.z + q[4 * d4 + 3] * kv.w;
+      for (int mm = 0; mm < 8; ++mm) {
+        sk[r * P + c8 * 8 + mm] = ld1<T>(qkv, base + HD + mm);
+        sv[r * P + c8 * 8 + mm] = ld1<T>(qkv, base + 2 * HD + mm);
+      }
     }
-    const float mn = fmaxf(m, sdot);
-    const float corr = __expf(m - mn);
-    const float p = __expf(sdot - mn);
-    l = l * corr + p;
-    const float4* vj = reinterpret_cast<const float4*>(sv + (size_t)j * P);
+    __syncthreads();
+    for (int j = part; j < nk; j += 4) {
+      const float4* kj = reinterpret_cast<const float4*>(sk + (size_t)j * P);
+      float sdot = 0.f;
 #pragma unroll
-    for (int d4 = 0; d4 < D / 4; ++d4) {
-      const float4 vv = vj[d4];
-      acc[4 * d4] = acc[4 * d4] * corr + p * vv.x;
-      acc[4 * d4 + 1] = acc[4 * d4 + 1] * corr + p * vv.y;
-      acc[4 * d4 + 2] = acc[4 * d4 + 2] * corr + p * vv.z;
-      acc[4 * d4 + 3] = acc[4 * d4 + 3] * corr + p * vv.w;
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 kv = kj[d4];
+        sdot += q[4 * d4] * kv.x + q[4 * d4 + 1] * kv.y + q[4 * d4 + 2] * kv.z + q[4 * d4 + 3] * kv.w;
+      }
+      const float mn = fmaxf(m, sdot);
+      const float corr = __expf(m - mn);
+      const float p = __expf(sdot - mn);
+      l = l * corr + p;
+      const float4* vj = reinterpret_cast<const float4*>(sv + (size_t)j * P);
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 vv = vj[d4];
+        acc[4 * d4] = acc[4 * d4] * corr + p * vv.x;
+        acc[4 * d4 + 1] = acc[4 * d4 + 1] * corr + p * vv.y;
+        acc[4 * d4 + 2] = acc[4 * d4 + 2] * corr + p * vv.z;
+        acc[4 * d4 + 3] = acc[4 * d4 + 3] * corr + p * vv.w;
+      }
+      m = mn;
     }
-    m = mn;
   }
 #pragma unroll
   for (int step = 1; step <= 2; step <<= 1) {
@@ -440,8 +448,8 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const void* qkv, void* o
 
 hipError_t launch_attn_full(int dt, const void* qkv, void* out, int B, int L, int heads, int dim_head, hipStream_t s) {
   if (dim_head != 32) return hipErrorInvalidValue;
-  const size_t lds = (size_t)2 * L * (dim_head + 4) * sizeof(float);
-  if (lds > 150 * 1024) return hipErrorInvalidValue;
+  const int CH = std::min(L, 256);
+  const size_t lds = (size_t)2 * CH * (dim_head + 4) * sizeof(float);
   const float scale = 1.0f / sqrtf((float)dim_head);
   static bool opt_in = false;
   if (!opt_in) {
@@ -451,9 +459,9 @@ hipError_t launch_attn_full(int dt, const void* qkv, void* out, int B, int L, in
   }
   dim3 grid(B * heads, (L + 63) / 64);
   if (dt == DT_F32)
-    hipLaunchKernelGGL((attn_full_kernel<float, 32>), grid, dim3(256), lds, s, qkv, out, L, heads, scale);
+    hipLaunchKernelGGL((attn_full_kernel<float, 32>), grid, dim3(256), lds, s, qkv, out, L, heads, scale, CH);
   else
-    hipLaunchKernelGGL((attn_full_kernel<__bf16, 32>), grid, dim3(256), lds, s, qkv, out, L, heads, scale);
+    hipLaunchKernelGGL((attn_full_kernel<__bf16, 32>), grid, dim3(256), lds, s, qkv, out, L, heads, scale, CH);
   return hipGetLastError();
 }
 

@@ -321,3 +321,22 @@ def test_p_sample_loop_and_infilling_drivers():
     m.diffusion.seq_length = g["loop_img0"].shape[2]
     s1 = m.diffusion.sample(batch_size=1, condition=cond)
     assert s1.shape == (1, 128, g["loop_img0"].shape[2]) and torch.isfinite(s1).all() and float(s1.abs().max()) <= 1.0 + 1e-4
+
+
+def test_long_utterance_beyond_one_attention_chunk():
+    """17.9 s in one piece: latent L = 8960, bottleneck attention over n = 560 positions (three K/V chunks in LDS),
+    1792 LSTM steps in the cond codec; one UNet call against the oracle, then a short decode end to end."""
+    mc, u, _ = CASES["r84"]
+    e = engine("r84", "f32")
+    Tn = 286720
+    Lz, F = Tn // mc.hop_length, Tn // COND_CFG.hop_length
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(1, 128, Lz, generator=g) * 0.7
+    cond = torch.randn(1, 128, F, generator=g)
+    sd = synth.to_torch(main_sd_np("r84"))
+    ref = O.unet_forward(sd, u, x, torch.full((1,), 11, dtype=torch.long), cond)
+    got = e.unet_forward(x.cuda(), 11, cond.cuda()).cpu()
+    assert rel(got.numpy(), ref.numpy()) < 2e-4
+    wav = torch.from_numpy(synth.synthetic_wav(1, Tn, seed=5))
+    out = e.decode(wav.cuda(), 3, per_item=True)
+    assert out.shape == (1, 1, Tn) and torch.isfinite(out).all()
