@@ -242,6 +242,8 @@ struct ldc_ctx {
   size_t scratch_cap = 0;
   void* outnorm_ws = nullptr;
   size_t outnorm_ws_bytes = 0;
+  float* state_buf = nullptr;   // diffusion state of ldc_denoise / ldc_p_sample_loop: a stable address keeps the step graphs valid
+  size_t state_bytes = 0;
   hipStream_t own_stream = nullptr;
   // profiling
   bool profile = false;
@@ -891,6 +893,7 @@ extern "C" int ldc_destroy(ldc_ctx* c) {
   drop_plans(c);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->outnorm_ws) (void)hipFree(c->outnorm_ws);
+  if (c->state_buf) (void)hipFree(c->state_buf);
   if (c->step_state) (void)hipFree(c->step_state);
   for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1820,6 +1823,17 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   return LDC_OK;
 }
 
+static int ensure_state(ldc_ctx* c, size_t bytes) {
+  if (bytes <= c->state_bytes) return LDC_OK;
+  HIPCHK(hipDeviceSynchronize());
+  if (c->state_buf) HIPCHK(hipFree(c->state_buf));
+  c->state_buf = nullptr; c->state_bytes = 0;
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, bytes));
+  c->state_buf = (float*)p; c->state_bytes = bytes;
+  return LDC_OK;
+}
+
 extern "C" int ldc_denoise(ldc_ctx* c, float* img, const float* cond, const float* noise, int n_steps, int B, int L, int F,
                            void* stream) {
   LDCCHK(check_ready(c, LDC_MODEL_MAIN));
@@ -1830,8 +1844,14 @@ extern "C" int ldc_denoise(ldc_ctx* c, float* img, const float* cond, const floa
   Halves h;
   LDCCHK(get_halves(c, B, L, F, s, &h));
   LDCCHK(load_cond(c, h, cond, s));
-  LDCCHK(load_x(c, h, img, s));
-  LDCCHK(denoise_loop(c, h, B, img, noise, n_steps, s));
+  // the loop runs on a context-owned copy of the state: the captured step graphs hold its address, so callers may
+  // pass a different tensor every time without forcing a re-capture
+  const size_t nbytes = (size_t)B * c->unet.channels * L * 4;
+  LDCCHK(ensure_state(c, nbytes));
+  HIPCHK(hipMemcpyAsync(c->state_buf, img, nbytes, hipMemcpyDeviceToDevice, s));
+  LDCCHK(load_x(c, h, c->state_buf, s));
+  LDCCHK(denoise_loop(c, h, B, c->state_buf, noise, n_steps, s));
+  HIPCHK(hipMemcpyAsync(img, c->state_buf, nbytes, hipMemcpyDeviceToDevice, s));
   return finish_stream(c, stream);
 }
 
@@ -1848,8 +1868,12 @@ extern "C" int ldc_p_sample_loop(ldc_ctx* c, float* img, const float* cond, cons
   Halves h;
   LDCCHK(get_halves(c, B, L, F, s, &h));
   LDCCHK(load_cond(c, h, cond, s));
-  LDCCHK(load_x(c, h, img, s));
-  LDCCHK(denoise_loop(c, h, B, img, noise, c->unet.timesteps, s));
+  const size_t nbytes = (size_t)B * c->unet.channels * L * 4;
+  LDCCHK(ensure_state(c, nbytes));
+  HIPCHK(hipMemcpyAsync(c->state_buf, img, nbytes, hipMemcpyDeviceToDevice, s));
+  LDCCHK(load_x(c, h, c->state_buf, s));
+  LDCCHK(denoise_loop(c, h, B, c->state_buf, noise, c->unet.timesteps, s));
+  HIPCHK(hipMemcpyAsync(img, c->state_buf, nbytes, hipMemcpyDeviceToDevice, s));
   return finish_stream(c, stream);
 }
 
