@@ -121,7 +121,8 @@ int ldc_p_sample(ldc_ctx* ctx, float* x_inout, int t, const float* cond, const f
                  void* stream);
 /* diffusion.halfway_sampling(img, t=n_steps, condition=cond) (ddpm_loss.py:370-385): t = n_steps-1..0.
  * noise [n_steps,B,C,L] (entry j is consumed at iteration j; the last is unused) or NULL.
- * One denoise step is captured in a hipGraph keyed by (B, L, F) and replayed n_steps times. */
+ * Five steps of every batch part are captured in one hipGraph keyed by (B, L, F) and replayed; the loop runs on a
+ * context-owned copy of img, so a new tensor per call does not force a re-capture (a new noise pointer does). */
 int ldc_denoise(ldc_ctx* ctx, float* img_inout, const float* cond, const float* noise, int n_steps, int B, int L,
                 int F, void* stream);
 /* SURVEY.md section 8(f) row 1 -- the two alternative decode modes left commented in sample.py:96-122; same kernels,
