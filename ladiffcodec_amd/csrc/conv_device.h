@@ -30,6 +30,13 @@ struct ConvKArgs {
   int gn_groups, gn_cpg;
   unsigned* colmax;    // fused column max over positions (LinearAttention k softmax): ordered-uint keys, pre-zeroed
   int colmax_lo, colmax_hi, colmax_stride;   // columns [lo, hi) -> colmax[b * stride + col - lo]
+  // split-K (fast kernel, few-tile long-K layers): ksplit workgroups per tile each take a slice of the units, park
+  // their fp32 partial tile in sk_part and the last one to arrive (sk_count) sums them and runs the epilogue
+  int ksplit;
+  float* sk_part;
+  unsigned* sk_count;
+  long long sk_part_cap;   // floats
+  int sk_count_cap;        // tiles
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }

@@ -304,6 +304,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   a.gn_sum = nullptr; a.gn_groups = 0; a.gn_cpg = 1;
   a.colmax = c.colmax; a.colmax_lo = c.colmax_lo; a.colmax_hi = c.colmax_hi; a.colmax_stride = c.colmax_stride;
   if (ly.tr_stride) a.colmax = nullptr;
+  a.ksplit = 1; a.sk_part = c.sk_part; a.sk_count = c.sk_count; a.sk_part_cap = c.sk_part_cap; a.sk_count_cap = c.sk_count_cap;
   if (c.gn_sum && c.gn_groups > 0 && !ly.tr_stride) {
     const int cpg = ly.n / c.gn_groups;
     const bool pow2 = cpg >= 4 && (cpg & (cpg - 1)) == 0;

@@ -1293,6 +1293,10 @@ struct PlanBuilder {
   int stats_used = 0;
   float* linattn_ws = nullptr;
   int linattn_used = 0;
+  float* sk_part = nullptr;        // split-K workspace shared by the plan's convs (they run one after another)
+  unsigned* sk_count = nullptr;    // arrival counters, inside the region the step's memset clears
+  long long sk_part_cap = 0;
+  int sk_count_cap = 0;
 
   void* act(int rows, int C) {
     pl->act_bytes += (double)rows * C * es;
@@ -1327,6 +1331,7 @@ struct PlanBuilder {
     cc.B = B; cc.L_in = L_in; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.residual = residual; cc.y_ld = ly.n;
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
     cc.colmax = colmax; cc.colmax_lo = cm_lo; cc.colmax_hi = cm_hi; cc.colmax_stride = cm_stride;
+    cc.sk_part = sk_part; cc.sk_count = sk_count; cc.sk_part_cap = sk_part_cap; cc.sk_count_cap = sk_count_cap;
     const ConvLayer* lp = &ly;
     {
       char buf[96];
@@ -1439,9 +1444,15 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const size_t gn_bytes = (size_t)n_gn * B * u.groups * 2 * 4;
   const size_t n_lin = c->fuse_kmax ? u.downs.size() + u.ups.size() : 1;
   const size_t lin_bytes = n_lin * B * linattn_ws_floats_per_item(u.heads, u.dim_head) * 4;
-  pb.stats_pool = (float*)ar.alloc(gn_bytes + lin_bytes);
-  pb.linattn_ws = pb.stats_pool + gn_bytes / 4;
-  const size_t stats_bytes = gn_bytes + (c->fuse_kmax ? lin_bytes : 0);
+  const int sk_tiles_cap = 1024;
+  const size_t sk_count_bytes = (size_t)sk_tiles_cap * 4;
+  pb.stats_pool = (float*)ar.alloc(gn_bytes + sk_count_bytes + lin_bytes);
+  pb.sk_count = reinterpret_cast<unsigned*>(pb.stats_pool + gn_bytes / 4);
+  pb.sk_count_cap = sk_tiles_cap;
+  pb.linattn_ws = pb.stats_pool + (gn_bytes + sk_count_bytes) / 4;
+  const size_t stats_bytes = gn_bytes + sk_count_bytes + (c->fuse_kmax ? lin_bytes : 0);
+  pb.sk_part_cap = (long long)8 << 20;   // 8 M floats (32 MB): 3 slices of 200 tiles of 128 x 64 and then some
+  pb.sk_part = (float*)ar.alloc((size_t)pb.sk_part_cap * 4);
   pl->maxabs = (float*)ar.alloc((size_t)B * 4);
   pl->step_state = (int*)ar.alloc(64);
   pl->cur_ss = (float*)ar.alloc((size_t)std::max(1, u.ss_stride) * 4);
@@ -2217,6 +2228,13 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
   if (cin2) HIPCHK(hipMemset(x2, 0x3c, (size_t)B * L * cin2 * es));
   ConvCall cc;
   cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.y_ld = cout;
+  {   // split-K workspace as the plan builder provides it
+    void *part = nullptr, *cnt = nullptr;
+    LDCCHK(keep.alloc(&part, (size_t)(8 << 20) * 4));
+    LDCCHK(keep.alloc(&cnt, 1024 * 4));
+    HIPCHK(hipMemset(cnt, 0, 1024 * 4));
+    cc.sk_part = (float*)part; cc.sk_part_cap = (long long)8 << 20; cc.sk_count = (unsigned*)cnt; cc.sk_count_cap = 1024;
+  }
   hipStream_t s = c->own_stream;
   for (int i = 0; i < 3; ++i) HIPCHK(launch_conv(ly, cc, s));
   hipEvent_t e0, e1;

@@ -53,6 +53,10 @@ struct ConvCall {
   int gn_groups = 0;
   unsigned* colmax = nullptr; // optional fused per-item column max, columns [colmax_lo, colmax_hi), pre-zeroed keys
   int colmax_lo = 0, colmax_hi = 0, colmax_stride = 0;
+  float* sk_part = nullptr;   // optional split-K workspace (fp32 partial tiles) and arrival counters (pre-zeroed)
+  unsigned* sk_count = nullptr;
+  long long sk_part_cap = 0;  // floats
+  int sk_count_cap = 0;       // tiles
 };
 
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
