@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const f
       }
       __syncthreads();
       if (s_dead) { dead = true; break; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // agent-scope (sc0 sc1) 16-byte loads of the freshly published h: they go past the non-coherent L2 themselves, so
+      // no acquire fence (= L2 invalidate) is needed; issued through asm, released by one vmcnt(0)
       const float* hp = hbuf + (size_t)((t + 1) & 1) * 32 * H;
       f32x4 areg[2][NI];
 #pragma unroll
@@ -237,10 +238,19 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const f
         if (mt < MT) {
           const int item = min(mt * 16 + n, B - 1);
 #pragma unroll
-          for (int jj = 0; jj < NI; ++jj)
-            areg[mt][jj] = *reinterpret_cast<const f32x4*>(hp + (size_t)item * H + w * KW + 16 * jj + 4 * q);
+          for (int jj = 0; jj < NI; ++jj) {
+            const float* src = hp + (size_t)item * H + w * KW + 16 * jj + 4 * q;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(areg[mt][jj]) : "v"(src) : "memory");
+          }
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        if (mt < MT) {
+#pragma unroll
+          for (int jj = 0; jj < NI; ++jj) asm volatile("" : "+v"(areg[mt][jj]));
+        }
 #pragma unroll
       for (int jj = 0; jj < NI; ++jj) {
 #pragma unroll
