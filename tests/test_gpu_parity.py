@@ -340,3 +340,33 @@ def test_long_utterance_beyond_one_attention_chunk():
     wav = torch.from_numpy(synth.synthetic_wav(1, Tn, seed=5))
     out = e.decode(wav.cuda(), 3, per_item=True)
     assert out.shape == (1, 1, Tn) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bench_workload_items_against_oracle(dtype):
+    """The exact bench.py workload shape (BASELINE configs[1]: diff_dims 256, enc_ratios 8 4, 32 x 2.4 s, two batch
+    parts of 16) with 2 denoise steps and injected noise: two of the 32 decoded utterances (one from each part)
+    against the CPU oracle decoding them alone.  This runs every kernel configuration the benchmark runs
+    (128x64 / 64x64 tiles, split-K at the L=75 level, fused statistics, MFMA attention, cooperative LSTM)."""
+    from ladiffcodec_amd.model import Engine
+    from ladiffcodec_amd.spec import CodecConfig, UnetConfig
+    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    u = UnetConfig(dim=256, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    sd = synth.ladiff_state_dict(mc, u, seed=1)
+    sdc = cond_sd_np()
+    e = Engine(mc, u, COND_CFG, dtype=dtype)
+    e.load_state_dict(L.MODEL_MAIN, {k: v for k, v in sd.items() if not k.startswith("diffusion.model.")})
+    e.load_state_dict(L.MODEL_COND, sdc)
+    e.finalize(strict=True)
+    B, Tn, n = 32, 38400, 3
+    wav = torch.from_numpy(synth.synthetic_wav(B, Tn, seed=1234))
+    noise = torch.randn(n, B, 128, Tn // mc.hop_length, generator=torch.Generator().manual_seed(8))
+    got = e.decode(wav.cuda(), n, noise.cuda(), per_item=True, want_stages=True)
+    sd_t, sdc_t = synth.to_torch(sd), synth.to_torch(sdc)
+    for i in (3, 29):
+        ref = O.decode_utterances(sdc_t, COND_CFG, sd_t, mc, u, wav[i:i + 1], n, noise[:, i:i + 1], per_item=True)
+        assert torch.equal(got["codes"][:, i:i + 1].cpu(), ref["codes"]), "RVQ codes must be bit-exact"
+        lat_tol, wav_tol = (2e-4, 2e-3) if dtype == "f32" else (5e-2, 0.3)
+        assert rel(got["latents"][i:i + 1].cpu().numpy(), ref["latents"].numpy()) < lat_tol
+        assert rel(got["wav"][i:i + 1].cpu().numpy(), ref["wav"].numpy()) < wav_tol
+    e.close()
