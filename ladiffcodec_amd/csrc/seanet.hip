@@ -55,9 +55,59 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* x, void* y,
   }
 }
 
+// Cout/4 divides 256 (n_filters = 32): thread -> 4 fixed output channels (one 16-byte store per row), rows advance
+// by 1024/Cout per trip; the taps of the thread's channels live in registers (k <= 8).  The kernel writes
+// T*Cout*4 bytes per item and reads T*4: store width is what matters.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_cin1_rows_kernel(const float* x, void* y, const float* w, const float* bias,
+                                                             int L, int Cout, int k, int rows_per_block) {
+  const int b = blockIdx.y;
+  const int tpr = Cout / 4;   // threads per row
+  const int c4 = (threadIdx.x % tpr) * 4, r0 = threadIdx.x / tpr, rstep = 256 / tpr;
+  float wk[4][8], bv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bv[c] = bias ? bias[c4 + c] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) wk[c][t] = t < k ? w[(c4 + c) * k + t] : 0.f;
+  }
+  const int pad = k - 1;
+  const int lbeg = blockIdx.x * rows_per_block, lend = min(L, lbeg + rows_per_block);
+  const float* xb = x + (size_t)b * L;
+  for (int l = lbeg + r0; l < lend; l += rstep) {
+    float xv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      int u = l + t - pad;
+      if (u < 0) u = -u;            // causal reflect (left only; L > pad)
+      xv[t] = t < k ? xb[u] : 0.f;
+    }
+    float acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] = bv[c];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[c] = fmaf(wk[c][t], xv[t], acc[c]);
+    }
+    const size_t o = ((size_t)b * L + l) * Cout + c4;
+    if (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + o) = make_uint2(hw_bf16x2(acc[0], acc[1]), hw_bf16x2(acc[2], acc[3]));
+    }
+  }
+}
+
 hipError_t launch_conv_cin1(int dt, const float* x, void* y, const float* w, const float* bias, int B, int L, int Cout,
                             int k, hipStream_t s) {
   if (L <= k - 1) return hipErrorInvalidValue;
+  if (Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 && k <= 8) {
+    const int rpb = 8 * (1024 / Cout);
+    dim3 grid((L + rpb - 1) / rpb, B);
+    if (dt == DT_F32) hipLaunchKernelGGL(conv_cin1_rows_kernel<float>, grid, dim3(256), 0, s, x, y, w, bias, L, Cout, k, rpb);
+    else hipLaunchKernelGGL(conv_cin1_rows_kernel<__bf16>, grid, dim3(256), 0, s, x, y, w, bias, L, Cout, k, rpb);
+    return hipGetLastError();
+  }
   const size_t lds = (size_t)(Cout * k + Cout) * sizeof(float);
   int bx = (int)std::min<size_t>(((size_t)L * Cout + 255) / 256, 512);
   if (dt == DT_F32)
