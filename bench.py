@@ -90,14 +90,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c8"],
+                    help="c2 = BASELINE configs[1] (the metric's config: 3 kbps, enc_ratios 8 4, 50 steps); c3 = configs[2] per GPU "
+                         "(1.5 kbps condition, 200 steps); c8 = the released checkpoints' layout (enc_ratios 8, latent L = 4800, "
+                         "upsampling 5 4 2; README.md:30,35), 3 kbps, 50 steps")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=2.4)
-    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--denoise-steps", type=int, default=0, help="0 = the config's own (50; c3: 200)")
     ap.add_argument("--diff-dims", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the CPU-oracle sample (SURVEY 8d: B = 4)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result: RCCL prints a banner (version / hostname / library path) on
@@ -113,11 +117,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0)
-    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
-    u = UnetConfig(dim=args.diff_dims, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    kbps = 1.5 if args.config == "c3" else 3.0
+    cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=kbps)
+    if args.config == "c8":
+        mc = CodecConfig(enc_ratios=(8,), quantization=False)
+        u = UnetConfig(dim=args.diff_dims, upsampling_ratios=(5, 4, 2), unet_scale_cond=True)
+    else:
+        mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+        u = UnetConfig(dim=args.diff_dims, upsampling_ratios=(5, 2), unet_scale_cond=True)
     T = int(args.seconds * 16000) // 640 * 640
-    N = args.denoise_steps
+    N = args.denoise_steps or (200 if args.config == "c3" else 50)
+    if world > 1:
+        log(f"rank {rank}: RCCL process group up, {torch.distributed.get_world_size()} ranks (backend {torch.distributed.get_backend()})")
 
     # ---- weights: rank 0 builds the synthetic checkpoints, RCCL broadcasts them (one flat buffer each) ----
     main_layout = spec.codec_keys(mc) + spec.unet_keys(u, "diff_model") + [(f"diffusion.{b}", (u.timesteps,)) for b in spec.SCHEDULE_BUFFERS]
@@ -165,13 +176,15 @@ def main():
 
     audio_s = world * B * (T / 16000.0) * args.steps
     result = {
-        "metric": "audio-sec decoded / wall-sec, 16kHz 3kbps 50-step DDPM",
+        "metric": f"audio-sec decoded / wall-sec, 16kHz {kbps:g}kbps {N}-step DDPM",
         "value": audio_s / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio)",
-        "config": {"workload": f"LaDiffCodec 3 kbps, diff_dims={args.diff_dims}, enc_ratios 8 4, {N}-step DDPM, "
-                               f"batch={B}x{T / 16000.0:.1f} s utterances per GPU", "global_batch": world * B,
-                   "latent_len": T // mc.hop_length, "denoise_steps": N, "parallelism": f"dp{world} (utterance-sharded, no data-path collective)"},
+        "config": {"workload": f"LaDiffCodec {kbps:g} kbps, diff_dims={args.diff_dims}, enc_ratios {' '.join(map(str, mc.enc_ratios))}, "
+                               f"{N}-step DDPM, batch={B}x{T / 16000.0:.1f} s utterances per GPU", "name": args.config,
+                   "global_batch": world * B, "latent_len": T // mc.hop_length, "denoise_steps": N,
+                   "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                   "parallelism": f"dp{world} (utterance-sharded, no data-path collective)"},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -194,10 +207,12 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-        if os.path.exists(tpath) and args.dtype == "bf16" and B == 32 and N == 50:
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+        for name in ("r02_conv_traffic.json", "r01_conv_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath) and args.dtype == "bf16" and B == 32 and N == 50 and args.config == "c2":
+                traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                break
         convs_per_step = launches / max(1, N)
         result["roofline"] = {"bound": "mfma", "kernel": "conv_fast_kernel / conv_gemm_kernel (implicit-GEMM Conv1d on MFMA)",
                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,

@@ -12,9 +12,19 @@
  *     thread-local human-readable message for the last failure.  No C++ exception crosses the ABI.
  *   - Tensor arguments are DEVICE pointers owned by the caller, contiguous, in the reference's own
  *     layouts: activations [B, C, L] float32, RVQ codes [n_q, B, F] int64.  The caller keeps them
- *     alive until `stream` has been synchronised.  `stream` is a hipStream_t passed as void*
- *     (NULL = the default stream).  All work is asynchronous on that stream; the library never
- *     calls hipDeviceSynchronize in a stage call.
+ *     alive until `stream` has been synchronised.  `stream` is a hipStream_t passed as void*.
+ *     stream != NULL: all work is queued asynchronously on that stream.  stream == NULL: the call runs
+ *     on the context's own (non-blocking) stream and returns after synchronising it.
+ *   - Device-wide synchronisation happens only in three documented places, never in the steady
+ *     state: (1) when a context-owned workspace has to grow (first call at a larger shape),
+ *     (2) when a captured step graph is replaced or evicted (a new (B, L, F), a new noise pointer,
+ *     the LRU plan cache bound, see LDC_PLAN_CACHE_GB / LDC_PLAN_CACHE_N), (3) in ldc_destroy.
+ *   - Reproducibility: GroupNorm statistics and the fused column maxima are accumulated with fp32
+ *     atomics, so two identical UNet calls agree to rounding (~1e-6 relative), not bit for bit; the
+ *     split-K reduction order is fixed.  The codec stages (SEANet, LSTM, RVQ) use no atomics: RVQ code
+ *     indices are bit-reproducible.
+ *   - An asynchronous device-side failure (the cooperative LSTM's bounded spin timing out) is
+ *     reported as LDC_E_HIP by the synchronous call that hit it or by the next call on the context.
  *   - Weights are handed over on the HOST (float32, the `.amlt` state-dict tensors,
  *     srcs/utils.py:98-108), one call per state-dict key, then folded / packed / uploaded by
  *     `ldc_finalize_weights`.
@@ -73,7 +83,18 @@ typedef struct ldc_config {
   int32_t max_batch;
   int32_t max_latent_len;
   uint64_t noise_seed;                   /* device Philox stream used when noise == NULL */
+  int32_t final_activation;              /* --final_activation: LDC_ACT_* applied after both encoders' last conv */
+  int32_t reserved_;
 } ldc_config;
+
+/* --final_activation names (getattr(nn, name)() with default arguments, seanet.py:144-149) */
+#define LDC_ACT_NONE 0
+#define LDC_ACT_TANH 1
+#define LDC_ACT_SIGMOID 2
+#define LDC_ACT_ELU 3
+#define LDC_ACT_SILU 4
+#define LDC_ACT_GELU 5
+#define LDC_ACT_RELU 6
 
 const char* ldc_last_error(void);
 const char* ldc_version(void);
@@ -81,6 +102,11 @@ const char* ldc_version(void);
 /* lifecycle ---------------------------------------------------------------------------------- */
 int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out);
 int ldc_destroy(ldc_ctx* ctx);
+
+/* Device-drawn noise (noise == NULL): Philox4x32-10 keyed by (noise_seed, call counter); every sampler call that
+ * draws advances the counter, as every torch.randn_like of the reference (ddpm_loss.py:249) advances the global
+ * generator.  ldc_reseed sets the seed and rewinds the counter (the counterpart of torch.manual_seed). */
+int ldc_reseed(ldc_ctx* ctx, uint64_t seed);
 
 /* load_model(model, path, strict) -- srcs/utils.py:98-108.  One call per state-dict entry (after
  * the caller stripped any `module.` prefix).  `data` is a host float32 buffer of prod(shape)

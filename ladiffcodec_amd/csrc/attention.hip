@@ -338,14 +338,12 @@ hipError_t launch_linattn(int dt, const void* qkv, void* out, float* ws, int B, 
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * wss * sizeof(float), s);
     if (e != hipSuccess) return e;
   }
-  static const int rpb_env = getenv("LDC_LINATTN_RPB") ? atoi(getenv("LDC_LINATTN_RPB")) : 0;
-  const int rpb = rpb_env > 0 ? rpb_env : 128;
+  const int rpb = 128;
   const int chunks = (L + rpb - 1) / rpb;
   const float scale = 1.0f / sqrtf((float)dim_head);
   const size_t lds_out = (size_t)heads * (dim_head * dim_head + 8) * sizeof(float);
   const int rows_out = 256 / heads;
-  static const bool v1 = getenv("LDC_LINATTN_V1") != nullptr;
-  if (dt == DT_BF16 && heads == 4 && !v1) {
+  if (dt == DT_BF16 && heads == 4) {
     if (!kmax_fused) hipLaunchKernelGGL(linattn_kmax_kernel<__bf16>, dim3(chunks, B), dim3(256), 0, s, qkv, ws, L, HD, rpb, wss);
     hipLaunchKernelGGL(linattn_ctx_mfma_kernel<64>, dim3((L + 63) / 64, B), dim3(256), 0, s,
                        reinterpret_cast<const unsigned short*>(qkv), ws, L, wss);

@@ -37,6 +37,8 @@ struct ConvKArgs {
   unsigned* sk_count;
   long long sk_part_cap;   // floats
   int sk_count_cap;        // tiles
+  const ConvTune* tune;    // host-only (never read on the device)
+  long long* sk_need;      // host-only: dry run
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -48,6 +50,8 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case ACT_ELU: return fast_elu(v);
     case ACT_TANH: return fast_tanh(v);
     case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case ACT_RELU: return fmaxf(v, 0.0f);
     default: return v;
   }
 }

@@ -289,8 +289,6 @@ static hipError_t launch_cfg(const ConvKArgs& a, int M, size_t lds, hipStream_t 
   return hipGetLastError();
 }
 
-static int g_conv_force_v1 = -1;
-
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   ConvKArgs a;
   a.x1 = (const char*)c.x1; a.x2 = (const char*)c.x2; a.w = (const char*)ly.w; a.bias = ly.bias;
@@ -305,6 +303,8 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   a.colmax = c.colmax; a.colmax_lo = c.colmax_lo; a.colmax_hi = c.colmax_hi; a.colmax_stride = c.colmax_stride;
   if (ly.tr_stride) a.colmax = nullptr;
   a.ksplit = 1; a.sk_part = c.sk_part; a.sk_count = c.sk_count; a.sk_part_cap = c.sk_part_cap; a.sk_count_cap = c.sk_count_cap;
+  a.tune = c.tune; a.sk_need = c.sk_need;
+  if (c.sk_need) *c.sk_need = 0;
   if (c.gn_sum && c.gn_groups > 0 && !ly.tr_stride) {
     const int cpg = ly.n / c.gn_groups;
     const bool pow2 = cpg >= 4 && (cpg & (cpg - 1)) == 0;
@@ -331,12 +331,12 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     seam_slack = ((BM + c.L_rows - 1) / c.L_rows + 1) * leftover;
   }
   span += seam_slack;
-  if (g_conv_force_v1 < 0) g_conv_force_v1 = getenv("LDC_CONV_V1") ? 1 : 0;
-  if (!g_conv_force_v1 && conv_fast_eligible(ly)) {
+  if (!(c.tune && c.tune->force_generic) && conv_fast_eligible(ly)) {
     bool launched = false;
     hipError_t e = launch_conv_fast(ly, a, M, span, s, &launched);
     if (e != hipSuccess || launched) return e;
   }
+  if (c.sk_need) return hipSuccess;   // dry run: the generic kernel never splits K
   a.win_rows = std::min(span, c.B * c.L_in) + 1;
   int bn = ly.bn;
   // few-tile GEMMs with a long K (the SEANet encoder's last strided / k=7 convs: 3 840 rows x 3 584..4 096 deep, 30

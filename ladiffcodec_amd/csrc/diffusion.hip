@@ -154,6 +154,24 @@ hipError_t launch_scale_by_maxabs(int dt, void* x, int B, int64_t n_per_item, co
   return hipGetLastError();
 }
 
+// y = x / (maxabs[b] + eps), out of place (--unet_scale_x: the UNet input scaled per item, unet.py:432-433)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_copy_kernel(const void* x, void* y, int64_t n_per_item, const float* maxabs, float eps) {
+  const int b = blockIdx.y;
+  const float den = maxabs[b] + eps;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256) {
+    const size_t idx = (size_t)b * n_per_item + i;
+    dst<T>(y, idx, dld<T>(x, idx) / den);
+  }
+}
+hipError_t launch_scale_copy(int dt, const void* x, void* y, int B, int64_t n_per_item, const float* maxabs, float eps, hipStream_t s) {
+  int bx = (int)std::min<int64_t>((n_per_item + 255) / 256, 256);
+  if (bx < 1) bx = 1;
+  if (dt == DT_F32) hipLaunchKernelGGL(scale_copy_kernel<float>, dim3(bx, B), dim3(256), 0, s, x, y, n_per_item, maxabs, eps);
+  else hipLaunchKernelGGL(scale_copy_kernel<__bf16>, dim3(bx, B), dim3(256), 0, s, x, y, n_per_item, maxabs, eps);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller: one normal per (seed, step, element)
 // ---------------------------------------------------------------------------------------------
@@ -200,7 +218,7 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, unsigned step, uin
 template <typename T>
 __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const void* eps_cl, const float* noise,
                                                               int64_t noise_step_stride, void* x_cl, int C, int L,
-                                                              StepTables tb, const int* st, uint64_t seed, uint64_t elem_base) {
+                                                              StepTables tb, const int* st, uint64_t elem_base) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -216,6 +234,7 @@ __global__ __launch_bounds__(256) void p_sample_update_kernel(float* x, const vo
     xin[ii] = (cc < C && ll < L) ? x[((size_t)b * C + cc) * L + ll] : 0.f;
   }
   const int t = st[0], j = st[1];
+  const uint64_t seed = ((uint64_t)(unsigned)st[3] << 32) | (uint64_t)(unsigned)st[2];
   const float recip = tb.sqrt_recip_alphas_cumprod[t], recipm1 = tb.sqrt_recipm1_alphas_cumprod[t];
   const float c1 = tb.posterior_mean_coef1[t], c2 = tb.posterior_mean_coef2[t];
   const float sigma = expf(0.5f * tb.posterior_log_variance_clipped[t]);
@@ -290,15 +309,15 @@ hipError_t launch_axpby(float* x, const float* y, float a, float b, int64_t n, h
 }
 
 hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const float* noise, int64_t noise_step_stride,
-                                  void* x_cl, int B, int C, int L, StepTables tb, const int* st, uint64_t seed,
+                                  void* x_cl, int B, int C, int L, StepTables tb, const int* st,
                                   uint64_t elem_base, hipStream_t s) {
   dim3 grid((L + 31) / 32, (C + 31) / 32, B);
   if (dt == DT_F32)
     hipLaunchKernelGGL(p_sample_update_kernel<float>, grid, dim3(256), 0, s, x, eps_cl, noise, noise_step_stride, x_cl, C, L,
-                       tb, st, seed, elem_base);
+                       tb, st, elem_base);
   else
     hipLaunchKernelGGL(p_sample_update_kernel<__bf16>, grid, dim3(256), 0, s, x, eps_cl, noise, noise_step_stride, x_cl, C,
-                       L, tb, st, seed, elem_base);
+                       L, tb, st, elem_base);
   return hipGetLastError();
 }
 
@@ -306,9 +325,11 @@ __global__ void step_advance_kernel(int* st) {
   st[0] -= 1;
   st[1] += 1;
 }
-__global__ void step_set_kernel(int* st, int t, int j) {
+__global__ void step_set_kernel(int* st, int t, int j, unsigned key_lo, unsigned key_hi) {
   st[0] = t;
   st[1] = j;
+  st[2] = (int)key_lo;
+  st[3] = (int)key_hi;
 }
 __global__ __launch_bounds__(256) void step_begin_kernel(const float* table, int stride, const int* st, float* cur) {
   const float* row = table + (size_t)st[0] * stride;
@@ -322,8 +343,8 @@ hipError_t launch_step_advance(int* st, hipStream_t s) {
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, st);
   return hipGetLastError();
 }
-hipError_t launch_step_set(int* st, int t, int j, hipStream_t s) {
-  hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(1), 0, s, st, t, j);
+hipError_t launch_step_set(int* st, int t, int j, uint64_t noise_key, hipStream_t s) {
+  hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(1), 0, s, st, t, j, (unsigned)noise_key, (unsigned)(noise_key >> 32));
   return hipGetLastError();
 }
 

@@ -172,6 +172,9 @@ struct UnetW {
 
 struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells the two halves of a batch apart
   int B = 0, L = 0, F = 0, slot = 0;
+  uint64_t last_use = 0;        // LRU tick (ldc_ctx::use_tick)
+  long long sk_floats = 0;      // split-K workspace this plan's convs need (sized by a dry run of the launchers)
+  long long sk_need_max = 0;
   void* arena_base = nullptr;
   size_t arena_bytes = 0;
   void* x_cl = nullptr;         // [B*L][channels]
@@ -210,6 +213,7 @@ struct StepGraph {   // per batch part: hipGraph of {step_begin, unet step, p_sa
   float* x = nullptr;
   hipStream_t stream = nullptr;
   hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t last_use = 0;
   bool any() const { return exec[0] != nullptr; }
 };
 
@@ -236,7 +240,21 @@ struct ldc_ctx {
   int fuse_kmax = 1;
   int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
   int fuse_gn_stats = 1;
-  std::vector<void*> plan_mem;
+  // knobs read from the environment once, at ldc_create (per context, not process-global)
+  ConvTune tune;
+  int lstm_stream_only = 0;     // LDC_LSTM_STREAM: never use the cooperative LSTM
+  int serial_parts = 0;         // LDC_SERIAL: batch parts back to back, eager (diagnostics)
+  int graph_steps = 5;          // LDC_GRAPH_STEPS: denoise steps per replayed graph
+  // plan / graph cache (LRU): a corpus with many distinct lengths must not grow device memory without bound
+  uint64_t use_tick = 0, call_tick = 0;
+  size_t plan_bytes = 0, plan_bytes_cap = (size_t)48 << 30;   // LDC_PLAN_CACHE_GB
+  int plan_count_cap = 24;                                     // LDC_PLAN_CACHE_N
+  // device-drawn noise: every sampler call that draws advances the epoch, so no two calls share a realisation
+  uint64_t noise_epoch = 0, cur_key = 0;
+  // asynchronous device-side failure flag (cooperative LSTM timeout), host-mapped
+  unsigned* dev_flag_host = nullptr;
+  unsigned* dev_flag_dev = nullptr;
+  int enc_final_act = ACT_NONE;
   // scratch arena for codec stages and boundary buffers
   char* scratch = nullptr;
   size_t scratch_cap = 0;
@@ -259,9 +277,27 @@ struct ldc_ctx {
 };
 
 static hipStream_t pick_stream(ldc_ctx* c, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : c->own_stream; }
-static int finish_stream(ldc_ctx* c, void* s) {
-  if (!s) HIPCHK(hipStreamSynchronize(c->own_stream));   // NULL stream => synchronous call on the context's stream
+// A kernel that gave up (bounded spin of the cooperative LSTM) raises a host-mapped flag; it is reported by the first
+// API call that sees it: synchronous calls (stream == NULL) see their own failures, asynchronous ones the previous call's.
+static int check_dev_flag(ldc_ctx* c) {
+  if (c->dev_flag_host && *reinterpret_cast<volatile unsigned*>(c->dev_flag_host)) {
+    *reinterpret_cast<volatile unsigned*>(c->dev_flag_host) = 0u;
+    return fail(LDC_E_HIP, "cooperative LSTM: the hidden-state exchange timed out (its workgroups were not co-resident: is the "
+                           "GPU shared with another process?); the outputs of that call are NaN");
+  }
   return LDC_OK;
+}
+static int finish_stream(ldc_ctx* c, void* s) {
+  if (!s) {   // NULL stream => synchronous call on the context's own stream
+    HIPCHK(hipStreamSynchronize(c->own_stream));
+    return check_dev_flag(c);
+  }
+  return LDC_OK;
+}
+static uint64_t next_noise_key(ldc_ctx* c, bool draws) {
+  c->cur_key = c->cfg.noise_seed ^ (c->noise_epoch * 0x9E3779B97F4A7C15ull);
+  if (draws) ++c->noise_epoch;
+  return c->cur_key;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -502,6 +538,7 @@ static int build_codec(ldc_ctx* c, int which, const std::vector<int>& ratios, in
     SeaOp op;
     op.kind = SeaOp::CONV; op.cin = ch; op.cout = D; op.k = 7;
     LDCCHK(build_wn_conv(c, wr, "encoder.model." + std::to_string(idx) + ".conv.conv", ch, D, 7, 1, 1, ACT_ELU, &op.conv));
+    op.conv.post_act = c->enc_final_act;   // SEANetEncoder(final_activation=...) (seanet.py:144-149): both encoders get it
     cd.enc.push_back(op);
   }
   // ---- decoder ----
@@ -861,13 +898,47 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   // res_conv on a side stream (off the conv->norm->conv chain).  Only without the batch split: a fork inside an
   // already forked stream (or cross edges between sibling streams) crashes stream capture on ROCm 7.2, and the
   // two-way batch split is worth more (+9 % vs +3 %).
+  auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+  c->split_batch = getenv("LDC_NO_SPLIT") ? 1 : std::max(1, std::min(kMaxParts, env_int("LDC_SPLIT", 2)));
   c->side_streams = (getenv("LDC_SIDE") && c->split_batch == 1) ? 1 : 0;
-  c->split_batch = getenv("LDC_NO_SPLIT") ? 1 : (getenv("LDC_SPLIT") ? std::max(1, std::min(kMaxParts, atoi(getenv("LDC_SPLIT")))) : 2);
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
   c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
+  c->tune.force_generic = getenv("LDC_CONV_V1") ? 1 : 0;
+  c->tune.small_max = env_int("LDC_CONV_SMALL_TILES", c->tune.small_max);
+  c->tune.medium_max = env_int("LDC_CONV_MEDIUM_TILES", c->tune.medium_max);
+  c->tune.splitk = env_int("LDC_CONV_SPLITK", c->tune.splitk);
+  c->tune.sk_tiles = env_int("LDC_SK_TILES", c->tune.sk_tiles);
+  c->tune.sk_u2 = env_int("LDC_SK_U2", c->tune.sk_u2);
+  c->tune.sk_u3 = env_int("LDC_SK_U3", c->tune.sk_u3);
+  c->tune.m_fastest = env_int("LDC_CONV_MFAST", c->tune.m_fastest);
+  c->tune.debug = env_int("LDC_CONV_DEBUG", 0);
+  c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
+  c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
+  c->graph_steps = std::max(1, env_int("LDC_GRAPH_STEPS", 5));
+  c->plan_bytes_cap = (size_t)std::max(1, env_int("LDC_PLAN_CACHE_GB", 48)) << 30;
+  c->plan_count_cap = std::max(2 * kMaxParts, env_int("LDC_PLAN_CACHE_N", 24));
+  switch (cfg->final_activation) {
+    case LDC_ACT_NONE: c->enc_final_act = ACT_NONE; break;
+    case LDC_ACT_TANH: c->enc_final_act = ACT_TANH; break;
+    case LDC_ACT_SIGMOID: c->enc_final_act = ACT_SIGMOID; break;
+    case LDC_ACT_ELU: c->enc_final_act = ACT_ELU; break;
+    case LDC_ACT_SILU: c->enc_final_act = ACT_SILU; break;
+    case LDC_ACT_GELU: c->enc_final_act = ACT_GELU; break;
+    case LDC_ACT_RELU: c->enc_final_act = ACT_RELU; break;
+    default: return fail(LDC_E_INVALID, "final_activation code %d is not one of LDC_ACT_*", cfg->final_activation);
+  }
+  {
+    void* hp = nullptr;
+    HIPCHK(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+    memset(hp, 0, 64);
+    c->dev_flag_host = (unsigned*)hp;
+    void* dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, hp, 0));
+    c->dev_flag_dev = (unsigned*)dp;
+  }
   void* p = nullptr;
-  HIPCHK(hipMalloc(&p, 2 * sizeof(int)));
+  HIPCHK(hipMalloc(&p, 4 * sizeof(int)));
   c->step_state = (int*)p;
   *out = c.release();
   return LDC_OK;
@@ -879,11 +950,13 @@ static void drop_plans(ldc_ctx* c) {
     for (auto& e : g.exec)
       if (e) (void)hipGraphExecDestroy(e);
   c->graphs.clear();
-  for (auto& pl : c->plans)
+  for (auto& pl : c->plans) {
     for (hipEvent_t e : pl->marker_events) (void)hipEventDestroy(e);
+    if (pl->arena_base) (void)hipFree(pl->arena_base);
+  }
   c->plans.clear();
-  for (void* p : c->plan_mem) (void)hipFree(p);
-  c->plan_mem.clear();
+  c->plan_bytes = 0;
+  c->last_halves = Halves();
 }
 
 extern "C" int ldc_destroy(ldc_ctx* c) {
@@ -895,6 +968,7 @@ extern "C" int ldc_destroy(ldc_ctx* c) {
   if (c->outnorm_ws) (void)hipFree(c->outnorm_ws);
   if (c->state_buf) (void)hipFree(c->state_buf);
   if (c->step_state) (void)hipFree(c->step_state);
+  if (c->dev_flag_host) (void)hipHostFree(c->dev_flag_host);
   for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   for (int k = 1; k < kMaxParts; ++k) {
@@ -908,6 +982,13 @@ extern "C" int ldc_destroy(ldc_ctx* c) {
   }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+  return LDC_OK;
+}
+
+extern "C" int ldc_reseed(ldc_ctx* c, uint64_t seed) {
+  if (!c) return fail(LDC_E_INVALID, "null ctx");
+  c->cfg.noise_seed = seed;
+  c->noise_epoch = 0;
   return LDC_OK;
 }
 
@@ -962,6 +1043,8 @@ extern "C" int ldc_finalize_weights(ldc_ctx* c, int strict) {
 // ------------------------------------------------------------------------------------------------
 // scratch
 // ------------------------------------------------------------------------------------------------
+// Growth of a context-owned workspace is the one place a stage call waits for the device (the old buffer may still be
+// in use by earlier asynchronous calls); steady-state calls never do (include/ladiffcodec.h documents this).
 static int ensure_scratch(ldc_ctx* c, size_t bytes, hipStream_t s) {
   if (bytes <= c->scratch_cap) return LDC_OK;
   HIPCHK(hipStreamSynchronize(s));
@@ -1000,7 +1083,7 @@ struct SeaRun {   // measures or runs a SEANet stack
 static int sea_conv(SeaRun& R, const ConvLayer& ly, const void* x, const void* residual, int L_in, void** y, int* L_out,
                     int cout) {
   ConvCall cc;
-  cc.B = R.B; cc.L_in = L_in; cc.x1 = x; cc.residual = residual;
+  cc.B = R.B; cc.L_in = L_in; cc.x1 = x; cc.residual = residual; cc.tune = &R.c->tune;
   if (ly.tr_stride) {
     cc.L_rows = L_in + 1;
     cc.L_final = L_in * ly.tr_stride;
@@ -1052,16 +1135,20 @@ static int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in
         for (size_t n = 0; n < op.lstm.size(); ++n) {
           void* pre = R.ar->alloc((size_t)R.B * L * 4 * H * 4);
           void* o = R.ar->alloc((size_t)R.B * L * H * 4);
-          static const bool no_coop = getenv("LDC_LSTM_STREAM") != nullptr;
-          const bool coop = op.lstm[n].w_rm && !no_coop;
+          const bool coop = op.lstm[n].w_rm && !R.c->lstm_stream_only;
           void* lws = coop ? R.ar->alloc(lstm_coop_ws_bytes(H)) : nullptr;
           if (!R.dry) {
             ConvCall cc;
-            cc.B = R.B; cc.L_in = L; cc.L_rows = L; cc.x1 = in; cc.y = pre; cc.y_ld = 4 * H;
+            cc.B = R.B; cc.L_in = L; cc.L_rows = L; cc.x1 = in; cc.y = pre; cc.y_ld = 4 * H; cc.tune = &R.c->tune;
             HIPCHK(launch_conv(op.lstm[n].in_proj, cc, R.s));
             const bool lastl = n + 1 == op.lstm.size();
-            if (coop) HIPCHK(launch_lstm_coop(DT_F32, pre, op.lstm[n].w_rm, o, lastl ? x : nullptr, R.B, L, H, lws, R.s));
-            else HIPCHK(launch_lstm_layer(DT_F32, pre, op.lstm[n].w_hh, o, lastl ? x : nullptr, R.B, L, H, R.s));
+            hipError_t le = hipErrorCooperativeLaunchTooLarge;
+            if (coop) le = launch_lstm_coop(DT_F32, pre, op.lstm[n].w_rm, o, lastl ? x : nullptr, R.B, L, H, lws, R.c->dev_flag_dev, R.s);
+            if (le == hipErrorCooperativeLaunchTooLarge) {   // (or not eligible): one workgroup per item, W_hh streamed from L2
+              (void)hipGetLastError();
+              le = launch_lstm_layer(DT_F32, pre, op.lstm[n].w_hh, o, lastl ? x : nullptr, R.B, L, H, R.s);
+            }
+            HIPCHK(le);
           }
           in = o;
           y = o;
@@ -1099,7 +1186,7 @@ static int check_ready(ldc_ctx* c, int which, bool need_cond_codec = false) {
     return fail(LDC_E_STATE, "no cond model configured (has_cond_model = 0)");
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail(LDC_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
-  return LDC_OK;
+  return check_dev_flag(c);
 }
 
 extern "C" int ldc_seanet_encode(ldc_ctx* c, int which, const float* wav, int B, int T, float* z_out, void* stream) {
@@ -1236,7 +1323,7 @@ static int upsample_rows(ldc_ctx* c, const void* rows_in, int B, int F, Arena& a
   int L = F;
   for (const ConvLayer& ly : u.upsamplers) {
     ConvCall cc;
-    cc.B = B; cc.L_in = L; cc.L_rows = L + 1; cc.L_final = L * ly.tr_stride; cc.y_ld = ly.tr_cout; cc.x1 = x;
+    cc.B = B; cc.L_in = L; cc.L_rows = L + 1; cc.L_final = L * ly.tr_stride; cc.y_ld = ly.tr_cout; cc.x1 = x; cc.tune = &c->tune;
     void* y = ar.alloc((size_t)B * cc.L_final * ly.tr_cout * 4);
     cc.y = y;
     if (!dry) HIPCHK(launch_conv(ly, cc, s));
@@ -1332,6 +1419,14 @@ struct PlanBuilder {
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
     cc.colmax = colmax; cc.colmax_lo = cm_lo; cc.colmax_hi = cm_hi; cc.colmax_stride = cm_stride;
     cc.sk_part = sk_part; cc.sk_count = sk_count; cc.sk_part_cap = sk_part_cap; cc.sk_count_cap = sk_count_cap;
+    cc.tune = &c->tune;
+    {   // dry run of the launcher: how much split-K workspace would this conv use?
+      ConvCall d = cc;
+      long long need = 0;
+      d.sk_need = &need;
+      (void)launch_conv(ly, d, nullptr);
+      pl->sk_need_max = std::max(pl->sk_need_max, need);
+    }
     const ConvLayer* lp = &ly;
     {
       char buf[96];
@@ -1435,7 +1530,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const UnetW& u = c->unet;
   pl->B = B; pl->L = L; pl->F = F;
   pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_where.clear(); pl->step_flops.clear(); pl->step_class.clear(); pl->step_bytes.clear(); pl->step_info.clear(); pl->taps.clear();
-  pl->flops = 0; pl->act_bytes = 0; pl->conv_bytes = 0;
+  pl->flops = 0; pl->act_bytes = 0; pl->conv_bytes = 0; pl->sk_need_max = 0;
   const int dt = c->dt;
   const size_t es = dt_size(dt);
   const int Cc = u.cond_channels, Cx = u.channels;
@@ -1446,13 +1541,16 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const size_t lin_bytes = n_lin * B * linattn_ws_floats_per_item(u.heads, u.dim_head) * 4;
   const int sk_tiles_cap = 1024;
   const size_t sk_count_bytes = (size_t)sk_tiles_cap * 4;
-  pb.stats_pool = (float*)ar.alloc(gn_bytes + sk_count_bytes + lin_bytes);
+  const size_t sx_bytes = c->cfg.unet_scale_x ? (size_t)B * 4 : 0;   // per-item max|cat(cond, x)| of --unet_scale_x
+  pb.stats_pool = (float*)ar.alloc(gn_bytes + sk_count_bytes + lin_bytes + sx_bytes + 64);
   pb.sk_count = reinterpret_cast<unsigned*>(pb.stats_pool + gn_bytes / 4);
   pb.sk_count_cap = sk_tiles_cap;
   pb.linattn_ws = pb.stats_pool + (gn_bytes + sk_count_bytes) / 4;
-  const size_t stats_bytes = gn_bytes + sk_count_bytes + (c->fuse_kmax ? lin_bytes : 0);
-  pb.sk_part_cap = (long long)8 << 20;   // 8 M floats (32 MB): 3 slices of 200 tiles of 128 x 64 and then some
-  pb.sk_part = (float*)ar.alloc((size_t)pb.sk_part_cap * 4);
+  // the region the step's ONE memset clears: GroupNorm sums, split-K counters, fused k-max keys, scale_x maxima
+  float* sx_max = pb.linattn_ws + (c->fuse_kmax ? lin_bytes / 4 : 0);
+  const size_t stats_bytes = gn_bytes + sk_count_bytes + (c->fuse_kmax ? lin_bytes : 0) + sx_bytes;
+  pb.sk_part_cap = pl->sk_floats;   // sized from the convs' own needs by a dry planning pass (get_plan)
+  pb.sk_part = (float*)ar.alloc((size_t)std::max<long long>(pb.sk_part_cap, 4) * 4);
   pl->maxabs = (float*)ar.alloc((size_t)B * 4);
   pl->step_state = (int*)ar.alloc(64);
   pl->cur_ss = (float*)ar.alloc((size_t)std::max(1, u.ss_stride) * 4);
@@ -1467,7 +1565,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     int Lc = F;
     for (const ConvLayer& ly : u.upsamplers) {
       ConvCall cc;
-      cc.B = B; cc.L_in = Lc; cc.L_rows = Lc + 1; cc.L_final = Lc * ly.tr_stride; cc.y_ld = ly.tr_cout; cc.x1 = x;
+      cc.B = B; cc.L_in = Lc; cc.L_rows = Lc + 1; cc.L_final = Lc * ly.tr_stride; cc.y_ld = ly.tr_cout; cc.x1 = x; cc.tune = &c->tune;
       void* y = ar.alloc((size_t)B * cc.L_final * ly.tr_cout * 4);
       cc.y = y;
       const ConvLayer* lp = &ly;
@@ -1492,14 +1590,29 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     }
   }
   pl->taps["cond_proc"] = {pl->cond_cl, Cc, L};
-  if (c->cfg.unet_scale_x) return fail(LDC_E_INVALID, "--unet_scale_x is not supported");
   // ---- Unet1D.forward (unet.py:430-469) ----
   {
     float* sp = pb.stats_pool;
     pb.add([=](hipStream_t s) { return hipMemsetAsync(sp, 0, stats_bytes, s); });
   }
+  const void* in_cond = pl->cond_cl;
+  const void* in_x = pl->x_cl;
+  if (c->cfg.unet_scale_x) {
+    // unet.py:432-433: x = cat(cond, x) / (max|.| per item + 1e-20).  The max runs over both halves of the concatenation;
+    // the two scaled copies feed init_conv as its two inputs.
+    void* cs = ar.alloc((size_t)B * L * Cc * es);
+    void* xs = ar.alloc((size_t)B * L * Cx * es);
+    const void* cin = pl->cond_cl; const void* xin = pl->x_cl;
+    const int Bn = B;
+    const int64_t nc = (int64_t)L * Cc, nx = (int64_t)L * Cx;
+    pb.add([=](hipStream_t s) { return launch_maxabs(dt, cin, Bn, nc, 1, sx_max, s); });
+    pb.add([=](hipStream_t s) { return launch_maxabs(dt, xin, Bn, nx, 1, sx_max, s); });
+    pb.add([=](hipStream_t s) { return launch_scale_copy(dt, cin, cs, Bn, nc, sx_max, 1e-20f, s); }, false, 0, LDC_CLASS_ELEMENTWISE, 2.0 * B * nc * es);
+    pb.add([=](hipStream_t s) { return launch_scale_copy(dt, xin, xs, Bn, nx, sx_max, 1e-20f, s); }, false, 0, LDC_CLASS_ELEMENTWISE, 2.0 * B * nx * es);
+    in_cond = cs; in_x = xs;
+  }
   void* x0 = pb.act(B * L, u.dim);
-  pb.conv(u.init, pl->cond_cl, pl->x_cl, x0, nullptr, L, L);
+  pb.conv(u.init, in_cond, in_x, x0, nullptr, L, L);
   pl->taps["init"] = {x0, u.dim, L};
   const void* x = x0;
   int Lc = L;
@@ -1549,26 +1662,66 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   return LDC_OK;
 }
 
+// Drop plan `idx` (and every captured graph of its (L, F)): waits for the device first, nothing of it may be running.
+static void evict_plan(ldc_ctx* c, size_t idx) {
+  (void)hipDeviceSynchronize();
+  Plan* pl = c->plans[idx].get();
+  for (size_t g = 0; g < c->graphs.size();) {
+    if (c->graphs[g].L == pl->L && c->graphs[g].F == pl->F) {
+      for (auto& e : c->graphs[g].exec)
+        if (e) (void)hipGraphExecDestroy(e);
+      c->graphs.erase(c->graphs.begin() + g);
+    } else {
+      ++g;
+    }
+  }
+  for (int k = 0; k < c->last_halves.n; ++k)
+    if (c->last_halves.p[k] == pl) c->last_halves = Halves();
+  for (hipEvent_t e : pl->marker_events) (void)hipEventDestroy(e);
+  if (pl->arena_base) (void)hipFree(pl->arena_base);
+  c->plan_bytes -= pl->arena_bytes;
+  c->plans.erase(c->plans.begin() + idx);
+}
+
 static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Plan** out) {
   for (auto& p : c->plans)
     if (p->B == B && p->L == L && p->F == F && p->slot == slot) {
+      p->last_use = ++c->use_tick;
       *out = p.get();
       return LDC_OK;
     }
   std::unique_ptr<Plan> pl(new Plan());
+  {   // pass 1: what do the convs of this plan need as split-K workspace?
+    Arena dry;
+    LDCCHK(build_plan(c, pl.get(), dry, B, L, F));
+    pl->sk_floats = pl->sk_need_max;
+  }
   Arena measure;
   LDCCHK(build_plan(c, pl.get(), measure, B, L, F));
+  const size_t want = measure.off + 4096;
+  // LRU eviction: plans of the call being served (last_use > call_tick) are never candidates
+  for (;;) {
+    const bool over = c->plan_bytes + want > c->plan_bytes_cap || (int)c->plans.size() >= c->plan_count_cap;
+    if (!over) break;
+    size_t victim = c->plans.size();
+    for (size_t i = 0; i < c->plans.size(); ++i)
+      if (c->plans[i]->last_use <= c->call_tick && (victim == c->plans.size() || c->plans[i]->last_use < c->plans[victim]->last_use)) victim = i;
+    if (victim == c->plans.size()) break;   // everything cached belongs to this call: let hipMalloc decide
+    evict_plan(c, victim);
+  }
   void* base = nullptr;
-  hipError_t e = hipMalloc(&base, measure.off + 4096);
-  if (e != hipSuccess) return fail(LDC_E_NOMEM, "hipMalloc(%zu) for the UNet workspace failed: %s", measure.off, hipGetErrorString(e));
-  c->plan_mem.push_back(base);
+  hipError_t e = hipMalloc(&base, want);
+  if (e != hipSuccess) return fail(LDC_E_NOMEM, "hipMalloc(%zu) for the UNet workspace failed: %s", want, hipGetErrorString(e));
   Arena real;
   real.base = (char*)base;
-  real.cap = measure.off + 4096;
-  LDCCHK(build_plan(c, pl.get(), real, B, L, F));
+  real.cap = want;
+  int rc = build_plan(c, pl.get(), real, B, L, F);
+  if (rc != LDC_OK) { (void)hipFree(base); return rc; }
   pl->arena_base = base;
-  pl->arena_bytes = real.cap;
+  pl->arena_bytes = want;
   pl->slot = slot;
+  pl->last_use = ++c->use_tick;
+  c->plan_bytes += want;
   *out = pl.get();
   c->plans.push_back(std::move(pl));
   (void)s;
@@ -1577,6 +1730,7 @@ static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Pl
 
 static int get_halves(ldc_ctx* c, int B, int L, int F, hipStream_t s, Halves* h) {
   *h = Halves();
+  c->call_tick = c->use_tick;   // plans touched from here on belong to the call being served (not evictable)
   h->n = std::max(1, std::min(c->split_batch, B));
   for (int k = 0; k < h->n; ++k) {
     const int lo = (int)((long long)B * k / h->n), hi = (int)((long long)B * (k + 1) / h->n);
@@ -1662,7 +1816,7 @@ static int load_x(ldc_ctx* c, const Halves& h, const float* x, hipStream_t s) {
 
 static int check_unet_args(ldc_ctx* c, int B, int L, int F) {
   if (B <= 0 || L <= 0 || F <= 0) return fail(LDC_E_INVALID, "bad sizes");
-  if (c->unet.upsamplers.empty()) return fail(LDC_E_INVALID, "upsampling_ratios=None is not supported on the other_cond path");
+  // upsampling_ratios=None (unet.py:411): process_cond only scales, so the condition must already have the latent length
   if (F * upsample_factor(c) != L) return fail(LDC_E_INVALID, "L (%d) must equal F (%d) x prod(upsampling_ratios) (%d)", L, F, upsample_factor(c));
   return LDC_OK;
 }
@@ -1680,7 +1834,7 @@ extern "C" int ldc_unet_forward(ldc_ctx* c, const float* x, int t, const float* 
   LDCCHK(load_x(c, h, x, s));
   for (int k = 0; k < h.n; ++k) {
     Plan* pl = h.p[k];
-    HIPCHK(launch_step_set(pl->step_state, t, 0, s));
+    HIPCHK(launch_step_set(pl->step_state, t, 0, c->cur_key, s));
     HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, s));
     LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
     HIPCHK(launch_from_cl(c->dt, pl->eps_cl, eps_out + (size_t)h.b0[k] * c->unet.channels * L, pl->B, c->unet.channels, L, nullptr,
@@ -1717,14 +1871,13 @@ static int half_step(ldc_ctx* c, const Halves& h, int k, float* x, const float* 
   HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, s));
   LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
   HIPCHK(launch_p_sample_update(c->dt, x + off, pl->eps_cl, noise ? noise + off : nullptr, noise_stride, pl->x_cl, pl->B,
-                                c->unet.channels, pl->L, c->sched, pl->step_state, c->cfg.noise_seed, (uint64_t)off, s));
+                                c->unet.channels, pl->L, c->sched, pl->step_state, (uint64_t)off, s));
   HIPCHK(launch_step_advance(pl->step_state, s));
   return LDC_OK;
 }
 
 static bool parts_parallel(ldc_ctx* c, const Halves& h) {
-  static const bool serial_env = getenv("LDC_SERIAL") != nullptr;   // diagnostics: parts back to back, eager
-  return h.n >= 2 && !c->profile && !serial_env;
+  return h.n >= 2 && !c->profile && !c->serial_parts;   // LDC_SERIAL (diagnostics): parts back to back, eager
 }
 // the parts' streams pick up after everything queued on s / s waits for every part
 static int fork_parts(ldc_ctx* c, const Halves& h, hipStream_t s) {
@@ -1740,7 +1893,7 @@ static int join_parts(ldc_ctx* c, const Halves& h, hipStream_t s) {
   return LDC_OK;
 }
 static int set_steps(ldc_ctx* c, const Halves& h, int t, int j, hipStream_t s) {
-  for (int k = 0; k < h.n; ++k) HIPCHK(launch_step_set(h.p[k]->step_state, t, j, s));
+  for (int k = 0; k < h.n; ++k) HIPCHK(launch_step_set(h.p[k]->step_state, t, j, c->cur_key, s));
   return LDC_OK;
 }
 
@@ -1767,6 +1920,7 @@ extern "C" int ldc_p_sample(ldc_ctx* c, float* x, int t, const float* cond, cons
   LDCCHK(get_halves(c, B, L, F, s, &h));
   LDCCHK(load_cond(c, h, cond, s));
   LDCCHK(load_x(c, h, x, s));
+  next_noise_key(c, noise == nullptr && t > 0);
   LDCCHK(set_steps(c, h, t, 0, s));
   LDCCHK(one_step(c, h, x, noise, 0, s));
   return finish_stream(c, stream);
@@ -1777,8 +1931,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   const int L = h.p[0]->L, F = h.p[0]->F;
   const int64_t stride = (int64_t)B * c->unet.channels * L;
   LDCCHK(set_steps(c, h, n_steps - 1, 0, s));
-  static const bool serial_eager = getenv("LDC_SERIAL") != nullptr;
-  if (c->profile || serial_eager || n_steps < 3) {
+  if (c->profile || c->serial_parts || n_steps < 3) {
     for (int i = 0; i < n_steps; ++i) LDCCHK(one_step(c, h, x, noise, stride, s));
     return LDC_OK;
   }
@@ -1786,21 +1939,31 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   for (auto& g : c->graphs)
     if (g.B == B && g.L == L && g.F == F) sg = &g;
   if (!sg) {
+    // graphs of shapes whose plans are gone were dropped with them (evict_plan); additionally keep at most 16 alive
+    if (c->graphs.size() >= 16) {
+      size_t victim = 0;
+      for (size_t i = 1; i < c->graphs.size(); ++i)
+        if (c->graphs[i].last_use < c->graphs[victim].last_use) victim = i;
+      HIPCHK(hipDeviceSynchronize());
+      for (auto& e : c->graphs[victim].exec)
+        if (e) (void)hipGraphExecDestroy(e);
+      c->graphs.erase(c->graphs.begin() + victim);
+    }
     c->graphs.push_back(StepGraph());
     sg = &c->graphs.back();
     sg->B = B; sg->L = L; sg->F = F;
   }
+  sg->last_use = ++c->use_tick;
   const bool par = parts_parallel(c, h);
   // steps per replayed graph: the parts fork at the head of the graph and join at its tail, so K > 1 lets them
   // drift apart for K steps (concurrent replays of SEPARATE graphs on different streams were measured: the ROCm
   // 7.2 runtime serialises them, 198 vs 188 ms)
-  static int K_env = -1;
-  if (K_env < 0) K_env = getenv("LDC_GRAPH_STEPS") ? std::max(1, atoi(getenv("LDC_GRAPH_STEPS"))) : 5;
-  const int K = std::min(K_env, std::max(1, n_steps - 1));
+  const int K = std::min(c->graph_steps, std::max(1, n_steps - 1));
   int done = 0;
   if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K) {
     if (sg->any()) {
-      // replays of the old executable graphs may still be in flight: drain before destroying
+      // replays of the old executable graphs may still be in flight: drain before destroying (a re-capture is one of
+      // the documented places where a call waits for the device)
       HIPCHK(hipDeviceSynchronize());
       for (auto& e : sg->exec) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
     }
@@ -1861,6 +2024,7 @@ extern "C" int ldc_denoise(ldc_ctx* c, float* img, const float* cond, const floa
   LDCCHK(ensure_state(c, nbytes));
   HIPCHK(hipMemcpyAsync(c->state_buf, img, nbytes, hipMemcpyDeviceToDevice, s));
   LDCCHK(load_x(c, h, c->state_buf, s));
+  next_noise_key(c, noise == nullptr);
   LDCCHK(denoise_loop(c, h, B, c->state_buf, noise, n_steps, s));
   HIPCHK(hipMemcpyAsync(img, c->state_buf, nbytes, hipMemcpyDeviceToDevice, s));
   return finish_stream(c, stream);
@@ -1875,7 +2039,8 @@ extern "C" int ldc_p_sample_loop(ldc_ctx* c, float* img, const float* cond, cons
   if (!img || !cond) return fail(LDC_E_INVALID, "null tensor");
   LDCCHK(check_unet_args(c, B, L, F));
   hipStream_t s = pick_stream(c, stream);
-  if (fill_start) HIPCHK(launch_random_fill(img, (int64_t)B * c->unet.channels * L, 0, c->cfg.noise_seed, 0xffffffffu, s));
+  next_noise_key(c, noise == nullptr || fill_start);
+  if (fill_start) HIPCHK(launch_random_fill(img, (int64_t)B * c->unet.channels * L, 0, c->cur_key, 0xffffffffu, s));
   Halves h;
   LDCCHK(get_halves(c, B, L, F, s, &h));
   LDCCHK(load_cond(c, h, cond, s));
@@ -1900,7 +2065,8 @@ extern "C" int ldc_infilling(ldc_ctx* c, float* img, float* infill_img, const fl
   LDCCHK(check_unet_args(c, B, L, F));
   hipStream_t s = pick_stream(c, stream);
   const int64_t n = (int64_t)B * c->unet.channels * L;
-  if (fill_start) HIPCHK(launch_random_fill(img, n, 1, c->cfg.noise_seed, 0xfffffffeu, s));
+  next_noise_key(c, noise == nullptr || fill_start);
+  if (fill_start) HIPCHK(launch_random_fill(img, n, 1, c->cur_key, 0xfffffffeu, s));
   Halves h;
   LDCCHK(get_halves(c, B, L, F, s, &h));
   LDCCHK(load_cond(c, h, cond, s));
@@ -1977,6 +2143,7 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
         LDCCHK(run_ops(c, pl, pl->cond_ops, false, s));
       }
       LDCCHK(load_x(c, h, x, s));
+      next_noise_key(c, noise == nullptr);
       LDCCHK(denoise_loop(c, h, B, x, noise, n_steps, s));
     }
     // decoder (quirk Q3: no x18 un-scaling on this path, sample.py:131)
@@ -2234,6 +2401,7 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     LDCCHK(keep.alloc(&cnt, 1024 * 4));
     HIPCHK(hipMemset(cnt, 0, 1024 * 4));
     cc.sk_part = (float*)part; cc.sk_part_cap = (long long)8 << 20; cc.sk_count = (unsigned*)cnt; cc.sk_count_cap = 1024;
+    cc.tune = &c->tune;
   }
   hipStream_t s = c->own_stream;
   for (int i = 0; i < 3; ++i) HIPCHK(launch_conv(ly, cc, s));

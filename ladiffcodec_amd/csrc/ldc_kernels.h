@@ -12,7 +12,7 @@
 namespace ldc {
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_ELU = 2, ACT_TANH = 3, ACT_GELU = 4 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_ELU = 2, ACT_TANH = 3, ACT_GELU = 4, ACT_SIGMOID = 5, ACT_RELU = 6 };
 enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
 inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
@@ -39,6 +39,17 @@ struct ConvLayer {
   double flops_per_row = 0;   // 2*K*N, for accounting
 };
 
+// tuning knobs of the conv launchers; owned by the context (read from the environment once at ldc_create)
+struct ConvTune {
+  int force_generic = 0;        // LDC_CONV_V1: every conv on the generic kernel
+  int small_max = 60;           // LDC_CONV_SMALL_TILES: 64x64 tiles up to this many 128x128-equivalents
+  int medium_max = 1 << 30;     // LDC_CONV_MEDIUM_TILES: 128x64 tiles up to this many
+  int splitk = 1;               // LDC_CONV_SPLITK: 0 off | 1 by layer | 2 | 3
+  int sk_tiles = 200, sk_u2 = 24, sk_u3 = 60;   // LDC_SK_TILES / LDC_SK_U2 / LDC_SK_U3
+  int m_fastest = 1;            // LDC_CONV_MFAST: 0 N-tile fastest | 1 by operand size | 2 M-tile fastest
+  int debug = 0;                // LDC_CONV_DEBUG
+};
+
 struct ConvCall {
   const void* x1 = nullptr;
   const void* x2 = nullptr;
@@ -57,6 +68,8 @@ struct ConvCall {
   unsigned* sk_count = nullptr;
   long long sk_part_cap = 0;  // floats
   int sk_count_cap = 0;       // tiles
+  const ConvTune* tune = nullptr;   // null: defaults
+  long long* sk_need = nullptr;     // dry run: no launch, *sk_need = split-K workspace floats this call would use
 };
 
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
@@ -107,7 +120,9 @@ hipError_t launch_from_cl(int dt, const void* x_blc, float* y_bcl, int B, int C,
 // streams: n_per_item elements per item.
 hipError_t launch_maxabs(int dt, const void* x, int B, int64_t n_per_item, int per_item, float* maxabs,
                          hipStream_t s);
-// Step state on the device: st[0] = current t, st[1] = iteration index j.
+// Step state on the device: st[0] = current t, st[1] = iteration index j, st[2..3] = the 64-bit Philox key of the
+// current sampler call (seed mixed with the context's call counter on the host, written by launch_step_set: a
+// captured step graph therefore draws fresh noise on every replayed call).
 struct StepTables {            // device pointers, fp32 [T]
   const float* sqrt_recip_alphas_cumprod;
   const float* sqrt_recipm1_alphas_cumprod;
@@ -120,16 +135,18 @@ struct StepTables {            // device pointers, fp32 [T]
 hipError_t launch_random_fill(float* x, int64_t n, int uniform, uint64_t seed, unsigned step, hipStream_t s);
 hipError_t launch_axpby(float* x, const float* y, float a, float b, int64_t n, hipStream_t s);
 hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const float* noise, int64_t noise_step_stride,
-                                  void* x_cl, int B, int C, int L, StepTables tb, const int* st, uint64_t seed,
+                                  void* x_cl, int B, int C, int L, StepTables tb, const int* st,
                                   uint64_t elem_base, hipStream_t s);
 // x /= (maxabs[b or 0] + eps) in place on a raw element stream (n_per_item elements per item)
 hipError_t launch_scale_by_maxabs(int dt, void* x, int B, int64_t n_per_item, const float* maxabs, int per_item,
                                   float eps, hipStream_t s);
+hipError_t launch_scale_copy(int dt, const void* x, void* y, int B, int64_t n_per_item, const float* maxabs, float eps,
+                             hipStream_t s);
 hipError_t launch_step_advance(int* st, hipStream_t s);      // t -= 1, j += 1
 // cur[0..stride) = table[st[0]][0..stride): the current timestep's scale/shift row, so that consumers need no
 // dependent load through the step counter
 hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, hipStream_t s);
-hipError_t launch_step_set(int* st, int t, int j, hipStream_t s);
+hipError_t launch_step_set(int* st, int t, int j, uint64_t noise_key, hipStream_t s);
 // output normalisation (sample.py:133-134); ws: double [B][2] + float [B] zeroed by the launcher
 hipError_t launch_output_normalise(float* x, int B, int64_t n_per_item, int per_item, void* ws, hipStream_t s);
 size_t output_normalise_ws_bytes(int B);
@@ -148,8 +165,11 @@ hipError_t launch_lstm_layer(int dt, const void* pre, const float* w_hh, void* o
 // row-major [4H][H] matrix.
 bool lstm_coop_eligible(int H);
 size_t lstm_coop_ws_bytes(int H);
+// host_flag: device-visible mapped word set to 1 when the bounded h-exchange spin times out (the output is then NaN).
+// Launched cooperatively: returns hipErrorCooperativeLaunchTooLarge when the H/4 workgroups cannot be co-resident
+// (the caller falls back to launch_lstm_layer).
 hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* out, const void* skip, int B, int T, int H,
-                            void* ws, hipStream_t s);
+                            void* ws, unsigned* host_flag, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // rvq.hip

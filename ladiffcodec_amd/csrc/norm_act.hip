@@ -330,11 +330,8 @@ bool gn_apply_ln_fusable(int C) { return C == 256 || C == 512 || C == 1024; }
 // Rows per thread: these kernels run as ONE round of workgroups, so a thread's serial instruction stream (64
 // elements at U = 8: ~1500 VALU instructions with bf16 packing and SiLU) IS the kernel's duration.  Measured at the
 // half-batch level shapes: U = 8 8.3-10.4 us, U = 2 4.6-7.1 us, U = 1 4.0-7.6 us.  Pick the largest U that still
-// gives >= 4 workgroups per CU (LDC_GN_U overrides).
+// gives >= 4 workgroups per CU.
 static int gn_pick_u(int B, int L, int vpr) {
-  static int forced = -1;
-  if (forced < 0) forced = getenv("LDC_GN_U") ? atoi(getenv("LDC_GN_U")) : 0;
-  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
   const int nph = 256 / vpr;
   for (int u = 8; u > 1; u >>= 1)
     if ((long)B * ((L + nph * u - 1) / (nph * u)) >= 1024) return u;
@@ -360,8 +357,7 @@ hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual,
   if (C % 8 == 0 && vpr <= 256 && 256 % vpr == 0 && C <= 2048) {
     const int U = gn_pick_u(B, L, vpr);
     const int rpb = (256 / vpr) * U;   // one U-row trip per thread
-    static int dbg = -1;
-    if (dbg < 0) dbg = getenv("LDC_GN_DEBUG") ? atoi(getenv("LDC_GN_DEBUG")) : 0;
+    const int dbg = 0;
     dim3 grid((L + rpb - 1) / rpb, B);
 #define LDC_GN_ARGS grid, s, x, y, residual, L, C, groups, rpb, stats, gamma, beta, ss_table, ss_stride, t_ptr, act, dbg, y_ln, ln_g
     if (y_ln) {

@@ -229,7 +229,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <typename T, int H>
 __global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const float* w_hh, void* out, const void* skip,
-                                                        int B, int T_len, float* hbuf, unsigned* sync) {
+                                                        int B, int T_len, float* hbuf, unsigned* sync, unsigned* host_flag) {
   constexpr int KW = H / 4;      // k range of one wave
   constexpr int NI = KW / 16;    // float4 k-groups per lane
   __shared__ float part[4][2][16][16];
@@ -345,11 +345,13 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const f
   if (dead && owner) {
     for (int tt = t; tt < T_len; ++tt) sst<T>(out, ((size_t)ob * T_len + tt) * H + 4 * j + ou, __builtin_nanf(""));
   }
+  // the host learns about the timeout through a mapped word it checks at the next API call / synchronisation
+  if (dead && tid == 0 && host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <typename T>
 static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out, const void* skip, int B, int T_len, int H,
-                                   void* ws, hipStream_t s) {
+                                   void* ws, unsigned* host_flag, hipStream_t s) {
   float* hbuf = reinterpret_cast<float*>(ws);
   unsigned* sync = reinterpret_cast<unsigned*>(hbuf + (size_t)2 * 32 * H);
   const size_t esz = sizeof(T);
@@ -360,20 +362,25 @@ static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out
     const char* p = reinterpret_cast<const char*>(pre) + (size_t)b0 * T_len * 4 * H * esz;
     char* o = reinterpret_cast<char*>(out) + (size_t)b0 * T_len * H * esz;
     const char* k = skip ? reinterpret_cast<const char*>(skip) + (size_t)b0 * T_len * H * esz : nullptr;
-    if (H == 512) hipLaunchKernelGGL((lstm_coop_kernel<T, 512>), dim3(H / 4), dim3(256), 0, s, p, w_rm, o, k, nb, T_len, hbuf, sync);
-    else hipLaunchKernelGGL((lstm_coop_kernel<T, 256>), dim3(H / 4), dim3(256), 0, s, p, w_rm, o, k, nb, T_len, hbuf, sync);
+    // cooperative launch: the runtime checks that all H/4 workgroups can be resident together (the kernel's
+    // hand-rolled h exchange needs that); a grid it cannot place is refused here instead of spinning to the timeout
+    const void* pp = p; void* oo = o; const void* kk = k; int nbv = nb, tl = T_len;
+    void* args[] = {&pp, &w_rm, &oo, &kk, &nbv, &tl, &hbuf, &sync, &host_flag};
+    const void* fn = H == 512 ? reinterpret_cast<const void*>(lstm_coop_kernel<T, 512>) : reinterpret_cast<const void*>(lstm_coop_kernel<T, 256>);
+    e = hipLaunchCooperativeKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
+    if (e != hipSuccess) return e;
   }
-  return hipGetLastError();
+  return hipSuccess;
 }
 
 bool lstm_coop_eligible(int H) { return H == 256 || H == 512; }
 
 // w_rm: row-major [4H][H] fp32; ws: lstm_coop_ws_bytes(H) bytes of device scratch owned by the caller
 hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* out, const void* skip, int B, int T, int H,
-                            void* ws, hipStream_t s) {
+                            void* ws, unsigned* host_flag, hipStream_t s) {
   if (!lstm_coop_eligible(H)) return hipErrorInvalidValue;
-  return dt == DT_F32 ? lstm_coop_launch<float>(pre, w_rm, out, skip, B, T, H, ws, s)
-                      : lstm_coop_launch<__bf16>(pre, w_rm, out, skip, B, T, H, ws, s);
+  return dt == DT_F32 ? lstm_coop_launch<float>(pre, w_rm, out, skip, B, T, H, ws, host_flag, s)
+                      : lstm_coop_launch<__bf16>(pre, w_rm, out, skip, B, T, H, ws, host_flag, s);
 }
 
 // w_hh points at: [4H][H] row-major for the register variants (H = 64, 128), k-major [H/4][4H][4] otherwise.

@@ -18,7 +18,7 @@ MODEL_MAIN, MODEL_COND = 0, 1
 MAX_RATIOS = 8
 
 EXPORTS = [
-    "ldc_last_error", "ldc_version", "ldc_create", "ldc_destroy", "ldc_set_weight", "ldc_finalize_weights",
+    "ldc_last_error", "ldc_version", "ldc_create", "ldc_destroy", "ldc_reseed", "ldc_set_weight", "ldc_finalize_weights",
     "ldc_seanet_encode", "ldc_seanet_decode", "ldc_rvq_encode", "ldc_rvq_decode", "ldc_get_cond",
     "ldc_cond_upsample", "ldc_unet_forward", "ldc_p_sample", "ldc_denoise", "ldc_p_sample_loop", "ldc_infilling", "ldc_output_normalise", "ldc_decode",
     "ldc_sconv1d", "ldc_sconvtr1d", "ldc_slstm", "ldc_unet_debug_tap", "ldc_unet_step_cost", "ldc_profile_enable",
@@ -33,8 +33,13 @@ class LdcConfig(C.Structure):
         ("enc_ratios", C.c_int32 * MAX_RATIOS), ("diff_dims", C.c_int32), ("n_upsampling_ratios", C.c_int32),
         ("upsampling_ratios", C.c_int32 * MAX_RATIOS), ("unet_scale_cond", C.c_int32), ("unet_scale_x", C.c_int32),
         ("has_cond_model", C.c_int32), ("cond_bandwidth", C.c_float), ("max_batch", C.c_int32),
-        ("max_latent_len", C.c_int32), ("noise_seed", C.c_uint64),
+        ("max_latent_len", C.c_int32), ("noise_seed", C.c_uint64), ("final_activation", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
+
+
+# --final_activation names -> LDC_ACT_* (include/ladiffcodec.h)
+FINAL_ACTIVATIONS = {None: 0, "Identity": 0, "Tanh": 1, "Sigmoid": 2, "ELU": 3, "SiLU": 4, "GELU": 5, "ReLU": 6}
 
 
 class LdcError(RuntimeError):
@@ -71,6 +76,7 @@ def load() -> C.CDLL:
     lib.ldc_version.restype = C.c_char_p
     lib.ldc_create.argtypes = [C.POINTER(LdcConfig), i32, C.POINTER(vp)]
     lib.ldc_destroy.argtypes = [vp]
+    lib.ldc_reseed.argtypes = [vp, C.c_uint64]
     lib.ldc_set_weight.argtypes = [vp, i32, C.c_char_p, vp, i64p, i32]
     lib.ldc_finalize_weights.argtypes = [vp, i32]
     lib.ldc_seanet_encode.argtypes = [vp, i32, fp, i32, i32, fp, vp]

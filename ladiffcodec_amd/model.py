@@ -57,10 +57,19 @@ class Engine:
         cfg.has_cond_model = int(cond_codec is not None)
         cfg.cond_bandwidth = float(cond_codec.bandwidth) if cond_codec is not None else 3.0
         cfg.noise_seed = noise_seed
+        if main_codec.final_activation not in L.FINAL_ACTIVATIONS:
+            raise ValueError(f"final_activation {main_codec.final_activation!r}: one of {sorted(k for k in L.FINAL_ACTIVATIONS if k)}")
+        if cond_codec is not None and cond_codec.final_activation != main_codec.final_activation:
+            raise ValueError("both models are built with the same --final_activation (sample.py:54,63)")
+        cfg.final_activation = L.FINAL_ACTIVATIONS[main_codec.final_activation]
         self._ctx = C.c_void_p()
         L.check(self.lib.ldc_create(C.byref(cfg), device, C.byref(self._ctx)))
         self.stream = torch.cuda.Stream(device=self.device)
         self._finalized = False
+
+    def reseed(self, seed: int) -> None:
+        """torch.manual_seed counterpart for the device-drawn noise: sets the Philox seed and rewinds the call counter."""
+        L.check(self.lib.ldc_reseed(self._ctx, int(seed)))
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx:
@@ -158,7 +167,7 @@ class Engine:
     def cond_upsample(self, cond, normalise: int = 0):
         cond = self._f32(cond)
         B, Cc, F = cond.shape
-        f = int(np.prod(self.unet.upsampling_ratios))
+        f = int(np.prod(self.unet.upsampling_ratios or ()))
         img = self._empty(B, Cc, F * f)
         s = self._enter()
         L.check(self.lib.ldc_cond_upsample(self._ctx, cond.data_ptr(), B, F, normalise, img.data_ptr(), s))
@@ -211,7 +220,7 @@ class Engine:
         cond = self._f32(cond)
         B, _, F = cond.shape
         if img is None:
-            Lx = int(length) if length is not None else F * int(np.prod(self.unet.upsampling_ratios))
+            Lx = int(length) if length is not None else F * int(np.prod(self.unet.upsampling_ratios or ()))
             img = self.torch.empty(B, self.unet.inp_channels, Lx, device=cond.device, dtype=self.torch.float32)
             fill = 1
         else:
@@ -375,6 +384,10 @@ class _Diffusion:
 
     def halfway_sampling(self, img=None, t=None, condition=None, noise=None):
         if tuple(img.shape) == tuple(condition.shape):       # ddpm_loss.py:376-378
+            if self._eng.unet.upsampling_ratios is None:
+                # the reference iterates model.upsampling_layers here, an attribute that does not exist without
+                # upsampling_ratios (unet.py:372): same error, same place
+                raise AttributeError("'Unet1D' object has no attribute 'upsampling_layers'")
             img = self._eng.cond_upsample(img, 0)
         return self._eng.denoise(img, condition, int(t), noise)
 

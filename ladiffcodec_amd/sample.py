@@ -1,11 +1,16 @@
 """`python -m srcs.sample` -- the synthesis CLI of the reference (srcs/sample.py:50-203) on the MI355X engine.
 
 Same flags, defaults and output naming as the reference.  What differs, by design:
-  * files are decoded in BATCHES of equal trimmed length (the reference walks them one by one,
+  * mono files are decoded in BATCHES of equal trimmed length (the reference walks them one by one,
     sample.py:73); every utterance is normalised on its own, which is what the reference computes for
-    a mono file (its "batch" is the channel axis of one file, sample.py:85,129,133-134);
+    a mono file (its "batch" is the channel axis of one file, sample.py:85,129,133-134).  A
+    multi-channel file is decoded as ONE batch of its channels with the reference's joint
+    (whole-tensor) normalisation, so its channels keep their relative levels exactly as in the reference;
   * `midway_t` (a literal 100 at sample.py:69) is a flag, `--midway_t`, default 100;
-  * under `torch.distributed.run` the file list is sharded over the ranks (one process per GPU).
+  * `--seed` (default 0) seeds the device noise stream (rank r uses seed + r); every decode call draws fresh noise,
+    as torch.randn_like does in the reference (ddpm_loss.py:249);
+  * under `torch.distributed.run` the FILE list is sharded over the ranks (one process per GPU; all channels of a
+    file stay on one rank, every output file has exactly one writer).
 Flags that are inert in the reference stay accepted and inert (`--sampling_timesteps`,
 `--cond_enc_ratios`: quirk Q1, the cond codec is always built with ratios [8,5,4,2]).
 """
@@ -65,6 +70,7 @@ _EXTRA: List[Tuple[str, dict]] = [
     ("--midway_t", dict(type=int, default=100, help="reverse-diffusion steps (literal 100 in the reference)")),
     ("--dtype", dict(type=str, default="bf16", choices=["bf16", "f32"], help="UNet compute dtype on the GPU")),
     ("--batch_size", dict(type=int, default=32, help="utterances decoded per engine call")),
+    ("--seed", dict(type=int, default=0, help="seed of the device noise stream (rank r uses seed + r)")),
 ]
 
 
@@ -76,15 +82,16 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def _unsupported(a) -> None:
-    bad = [n for n in ("train_time_diff", "self_condition", "qtz_condition", "use_film", "run_vae", "unet_scale_x") if getattr(a, n)]
+    bad = [n for n in ("train_time_diff", "self_condition", "qtz_condition", "use_film", "run_vae") if getattr(a, n)]
     if bad:
         raise SystemExit(f"flags {bad} select paths outside the decode path this implementation covers (SURVEY.md section 8)")
     if a.model_type != "unet":
         raise SystemExit("only --model_type unet is supported")
     if not a.model_for_cond:
         raise SystemExit("--model_for_cond is required: halfway sampling starts from the quantised condition (sample.py:125-130)")
-    if a.final_activation is not None:
-        raise SystemExit("--final_activation is not supported")
+    from .lib import FINAL_ACTIVATIONS
+    if a.final_activation not in FINAL_ACTIVATIONS:
+        raise SystemExit(f"--final_activation {a.final_activation}: supported are {sorted(k for k in FINAL_ACTIVATIONS if k)}")
 
 
 def read_wav_16k(path: str) -> np.ndarray:
@@ -123,51 +130,71 @@ def synthesis(inp_args) -> List[str]:
     rank, local_rank, world = parallel.init_process_group("nccl")
     main_codec = CodecConfig(rep_dims=inp_args.rep_dims, n_filters=inp_args.n_filters,
                              n_residual_layers=inp_args.n_residual_layers, lstm=inp_args.lstm,
-                             enc_ratios=tuple(inp_args.enc_ratios), quantization=False)
+                             enc_ratios=tuple(inp_args.enc_ratios), quantization=False,
+                             final_activation=inp_args.final_activation)
     cond_codec = CodecConfig(rep_dims=inp_args.rep_dims, n_filters=inp_args.n_filters,
                              n_residual_layers=inp_args.n_residual_layers, lstm=inp_args.lstm,
-                             enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=inp_args.cond_bandwidth)   # quirk Q1
+                             enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=inp_args.cond_bandwidth,
+                             final_activation=inp_args.final_activation)   # quirk Q1: ratios are always [8,5,4,2]
     unet = UnetConfig(dim=inp_args.diff_dims, inp_channels=inp_args.rep_dims, upsampling_ratios=tuple(inp_args.upsampling_ratios),
                       unet_scale_cond=inp_args.unet_scale_cond, unet_scale_x=inp_args.unet_scale_x)
-    eng = Engine(main_codec, unet, cond_codec, dtype=inp_args.dtype, device=local_rank)
+    eng = Engine(main_codec, unet, cond_codec, dtype=inp_args.dtype, device=local_rank, noise_seed=inp_args.seed + rank)
     eng.load_state_dict(L.MODEL_MAIN, checkpoint.read_amlt(inp_args.model_path))       # load_model(model, path, strict=True)
     eng.load_state_dict(L.MODEL_COND, checkpoint.read_amlt(inp_args.model_for_cond))
     eng.finalize(strict=True)
 
     files = sorted(glob.glob(os.path.join(inp_args.input_dir, "**/*.wav"), recursive=True))
-    items: List[Tuple[str, int, np.ndarray]] = []      # (file, channel, samples)
-    for f in files:
-        wav = read_wav_16k(f)
-        length = wav.shape[-1] // 640 * 640                                              # sample.py:87-88
-        if length == 0:
-            continue
-        for ch in range(wav.shape[0]):
-            items.append((f, ch, wav[ch, :length]))
-    mine = parallel.shard_utterances([len(it[2]) for it in items], rank, world)
+    written = decode_files(eng, files, inp_args, rank, world, local_rank)
+    eng.close()
+    return written
+
+
+def plan_batches(lengths: List[int], channels: List[int], rank: int, world: int, batch_size: int) -> List[Tuple[List[int], bool]]:
+    """Work list of one rank: [(file indices, joint)].  Files are dealt to ranks whole (parallel.shard_utterances over
+    FILES), so a file has one writer.  Mono files of equal trimmed length share batches (`joint` False: per-utterance
+    normalisation = the reference's result for a mono file); a multi-channel file is its own batch, normalised jointly
+    over its channels as sample.py:129,133-134 do."""
+    from . import parallel
+    mine = parallel.shard_utterances(lengths, rank, world)
+    work: List[Tuple[List[int], bool]] = []
     by_len: Dict[int, List[int]] = {}
     for i in mine:
-        by_len.setdefault(len(items[i][2]), []).append(i)
-    decoded: Dict[int, np.ndarray] = {}
-    for length, idxs in sorted(by_len.items(), reverse=True):
-        for s in range(0, len(idxs), inp_args.batch_size):
-            chunk = idxs[s:s + inp_args.batch_size]
-            batch = torch.from_numpy(np.stack([items[i][2] for i in chunk])[:, None, :])
-            out = eng.decode(batch.cuda(local_rank), inp_args.midway_t, noise=None, per_item=True)
-            out = out.cpu().numpy()
-            for k, i in enumerate(chunk):
-                decoded[i] = out[k, 0]
+        if channels[i] > 1:
+            work.append(([i], True))
+        else:
+            by_len.setdefault(lengths[i] // 640 * 640, []).append(i)
+    for _, idxs in sorted(by_len.items(), reverse=True):
+        for s in range(0, len(idxs), batch_size):
+            work.append((idxs[s:s + batch_size], False))
+    return work
+
+
+def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_rank: int) -> List[str]:
+    import torch
+    from scipy.io import wavfile
+    wavs = [read_wav_16k(f) for f in files]
+    keep = [i for i, w in enumerate(wavs) if w.shape[-1] // 640 * 640 > 0]                   # sample.py:87-88
+    files, wavs = [files[i] for i in keep], [wavs[i] for i in keep]
+    lengths = [w.shape[-1] for w in wavs]
+    channels = [w.shape[0] for w in wavs]
     written = []
-    per_file: Dict[str, List[Tuple[int, np.ndarray]]] = {}
-    for i, y in decoded.items():
-        per_file.setdefault(items[i][0], []).append((items[i][1], y))
-    for f, chans in per_file.items():
-        path = output_path(f, inp_args.input_dir, inp_args.output_dir)
-        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        chans.sort()
-        data = np.stack([y for _, y in chans], axis=1)
-        wavfile.write(path, 16000, data[:, 0] if data.shape[1] == 1 else data)
-        written.append(path)
-    eng.close()
+    dev = torch.device("cuda", local_rank)
+    for idxs, joint in plan_batches(lengths, channels, rank, world, inp_args.batch_size):
+        n = lengths[idxs[0]] // 640 * 640
+        if joint:
+            batch = torch.from_numpy(np.ascontiguousarray(wavs[idxs[0]][:, None, :n]))      # [channels, 1, T], as sample.py:85
+        else:
+            batch = torch.from_numpy(np.stack([wavs[i][0, :n] for i in idxs])[:, None, :])
+        out = eng.decode(batch.to(dev), inp_args.midway_t, noise=None, per_item=not joint)
+        if not bool(torch.isfinite(out).all()):
+            raise RuntimeError(f"non-finite audio decoded for {[files[i] for i in idxs]}")
+        out = out.cpu().numpy()
+        for k, i in enumerate(idxs):
+            path = output_path(files[i], inp_args.input_dir, inp_args.output_dir)
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            data = out[:, 0, :].T if joint else out[k, 0]                                     # [T, channels] | [T]
+            wavfile.write(path, 16000, np.ascontiguousarray(data))
+            written.append(path)
     return written
 
 

@@ -42,6 +42,7 @@ class CodecConfig:
     bandwidth: float = 3.0
     sample_rate: int = 16000
     bins: int = 1024
+    final_activation: Optional[str] = None     # nn module name applied after the encoder's last conv (seanet.py:144-149)
 
     @property
     def hop_length(self) -> int:

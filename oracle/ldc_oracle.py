@@ -147,6 +147,8 @@ def seanet_encode(sd: SD, c: CodecConfig, wav: torch.Tensor, prefix: str = "enco
             x = _resblock(x, sd, p, ly)
         elif ly.kind == "lstm":
             x = lstm_skip(x, sd, p, ly.layers)
+    if c.final_activation is not None:            # seanet.py:144-149: getattr(nn, final_activation)() after the last conv
+        x = getattr(torch.nn, c.final_activation)()(x)
     return x
 
 

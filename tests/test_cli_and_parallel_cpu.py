@@ -31,7 +31,7 @@ def test_cli_flags_and_defaults_match_reference():
         assert k in ns, k
         assert ns[k] == v, (k, ns[k], v)
     assert ns["midway_t"] == 100                      # the reference's literal (sample.py:69)
-    assert set(ns) - set(REFERENCE_DEFAULTS) == {"midway_t", "dtype", "batch_size"}
+    assert set(ns) - set(REFERENCE_DEFAULTS) == {"midway_t", "dtype", "batch_size", "seed"}
 
 
 def test_cli_readme_invocation_parses():
@@ -61,12 +61,12 @@ def test_shard_helpers():
 
 
 _WORKER = r'''
-import os, sys
+import json, os, sys
 import numpy as np
 import torch
 import torch.distributed as dist
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
-from ladiffcodec_amd import parallel, spec, synth
+from ladiffcodec_amd import parallel, sample, spec, synth
 from helpers import COND_CFG
 rank, local_rank, world = parallel.init_process_group("gloo")
 layout = spec.codec_keys(COND_CFG)
@@ -81,21 +81,74 @@ outs = parallel.gather_results(local, world)
 assert len(outs) == world and all(float(o.mean()) == float(r) for r, o in enumerate(outs))
 t = parallel.max_over_ranks(1.0 + rank)
 assert t == float(world)
+
+# synthesis()'s sharding / bucketing with a stub engine: every file decoded exactly once by exactly one rank,
+# multi-channel files whole and jointly normalised, mono files batched by equal trimmed length
+from scipy.io import wavfile
+ind, outd = sys.argv[2], sys.argv[3]
+class Stub:
+    calls = []
+    def decode(self, batch, n_steps, noise=None, per_item=False):
+        Stub.calls.append((tuple(batch.shape), bool(per_item)))
+        return batch * 0.5
+files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(ind) for f in fs if f.endswith(".wav"))
+class A: pass
+a = A(); a.batch_size = 2; a.midway_t = 3; a.input_dir = ind + "/"; a.output_dir = outd + "/"
+torch.Tensor.to = (lambda orig: (lambda self, *x, **k: self))(torch.Tensor.to)     # no GPU here: .to(device) is a no-op
+written = sample.decode_files(Stub(), files, a, rank, world, 0)
+with open(os.path.join(outd, f"rank{rank}.json"), "w") as f:
+    json.dump({"rank": rank, "shard": [lo, hi], "written": written, "calls": Stub.calls}, f)
 dist.barrier(); dist.destroy_process_group()
-print("ok", rank, lo, hi)
 '''
 
 
-def test_two_rank_gloo_broadcast_and_gather(tmp_path):
+def test_two_rank_gloo_broadcast_gather_and_cli_sharding(tmp_path):
+    # Each rank writes its own result file: nothing is asserted on interleaved stdout.
+    import json
+    import socket
+    from scipy.io import wavfile
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    import socket
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    (ind / "a").mkdir(parents=True); outd.mkdir()
+    rng = np.random.default_rng(0)
+    spec_files = {"a/m1.wav": (1, 1280), "a/m2.wav": (1, 1280 + 5), "a/m3.wav": (1, 1280), "m4.wav": (1, 640), "st.wav": (2, 1920),
+                  "a/short.wav": (1, 100), "m5.wav": (1, 1280)}
+    for name, (ch, n) in spec_files.items():
+        x = (rng.standard_normal((n, ch)) * 0.1).astype(np.float32)
+        wavfile.write(str(ind / name), 16000, x[:, 0] if ch == 1 else x)
     with socket.socket() as sk:          # a free port: back-to-back runs must not collide on a fixed one
         sk.bind(("127.0.0.1", 0))
         port = str(sk.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", port, str(script), ROOT], env=env, capture_output=True, text=True,
-                       timeout=240)
+                        "127.0.0.1", "--master-port", port, str(script), ROOT, str(ind), str(outd)], env=env, capture_output=True,
+                       text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert "ok 0 0 4" in r.stdout and "ok 1 4 7" in r.stdout
+    res = [json.load(open(outd / f"rank{k}.json")) for k in range(2)]
+    assert res[0]["shard"] == [0, 4] and res[1]["shard"] == [4, 7]
+    all_written = res[0]["written"] + res[1]["written"]
+    expect = sorted(str(outd / n) for n in spec_files if n != "a/short.wav")              # < 640 samples: skipped (sample.py:87)
+    assert sorted(all_written) == expect and len(set(all_written)) == len(all_written)     # one writer per file
+    assert abs(len(res[0]["written"]) - len(res[1]["written"])) <= 1
+    calls = [tuple(c) for k in range(2) for c in res[k]["calls"]]
+    assert ((2, 1, 1920), False) in [(tuple(c[0]), c[1]) for c in calls]                   # stereo: one joint batch of its channels
+    for shape, per_item in calls:
+        assert shape[0] <= 2 and (per_item or shape[0] == 2)
+    sr, st = wavfile.read(str(outd / "st.wav"))
+    assert sr == 16000 and st.shape == (1920, 2)
+    sr, m2 = wavfile.read(str(outd / "a/m2.wav"))
+    assert m2.shape == (1280,)
+
+
+def test_plan_batches_properties():
+    lengths = [1280, 1285, 1280, 640, 1920, 1280, 6400, 6400, 6400]
+    channels = [1, 1, 1, 1, 2, 1, 1, 1, 3]
+    seen = []
+    for rank in range(3):
+        for idxs, joint in sample.plan_batches(lengths, channels, rank, 3, batch_size=2):
+            assert len(idxs) <= 2
+            assert len({lengths[i] // 640 * 640 for i in idxs}) == 1
+            assert joint == (channels[idxs[0]] > 1) and (not joint or len(idxs) == 1)
+            seen += idxs
+    assert sorted(seen) == list(range(len(lengths)))

@@ -1,0 +1,282 @@
+"""GPU parity at the BENCHED shapes and dtypes, built so that a wrong UNet cannot pass.
+
+Round-1's chain tests compared latents after a few steps from t <= 3, where the sampler weights eps by
+sqrt_recipm1_alphas_cumprod ~ 0.006-0.018: a UNet returning zeros landed inside the bf16 tolerance.  Here
+  * eps itself (and interior taps) is compared at the exact bench grid (B = 32 as two 16-item parts, L = 1200,
+    dim 256: 128x64 tiles, split-K, MFMA LinearAttention) at t = 37 and t = 499;
+  * chains run where eps matters (t >= 200: sqrt_recipm1 >= 0.34) and every chain test asserts that the oracle's own
+    chain with eps == 0 (a dead UNet) is far outside the tolerance it uses;
+  * tolerances are 2x the drift measured on MI355X (tools/measure_drift.py, numbers in DESIGN.md section 2), not
+    round constants.
+Reference arithmetic: ddpm_loss.py:175-179 (x0 from eps), :244-251 (p_sample), unet.py:422-469.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ladiffcodec_amd import lib as L, synth  # noqa: E402
+from ladiffcodec_amd.model import Engine  # noqa: E402
+from ladiffcodec_amd.spec import CodecConfig, UnetConfig  # noqa: E402
+from oracle import ldc_oracle as O  # noqa: E402
+from helpers import CASES, COND_CFG, T, cond_sd_np, load_golden, main_sd_np  # noqa: E402
+from gpu_common import engine, rel  # noqa: E402
+from drift_tolerances import TOL, check  # noqa: E402
+
+
+def cu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+_FULL = {}
+
+
+def full_engine(layout: str, dtype: str, cond_bandwidth: float = 3.0):
+    """diff_dims = 256 engines: 'c2' = enc_ratios [8,4] / upsampling [5,2] (BASELINE configs[1]), 'c8' = the released
+    checkpoints' layout enc_ratios [8] / upsampling [5,4,2] (README.md:30,35)."""
+    key = (layout, dtype, cond_bandwidth)
+    if key not in _FULL:
+        mc = CodecConfig(enc_ratios=(8, 4) if layout == "c2" else (8,), quantization=False)
+        u = UnetConfig(dim=256, upsampling_ratios=(5, 2) if layout == "c2" else (5, 4, 2), unet_scale_cond=True)
+        cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=cond_bandwidth)
+        sd = synth.ladiff_state_dict(mc, u, seed=1)
+        sdc = synth.codec_state_dict(cc, seed=11)
+        e = Engine(mc, u, cc, dtype=dtype)
+        e.load_state_dict(L.MODEL_MAIN, {k: v for k, v in sd.items() if not k.startswith("diffusion.model.")})
+        e.load_state_dict(L.MODEL_COND, sdc)
+        e.finalize(strict=True)
+        _FULL[key] = (e, mc, u, cc, synth.to_torch(sd), synth.to_torch(sdc))
+    return _FULL[key]
+
+
+_ORACLE_CACHE = {}
+
+
+def cached(key, fn):
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]
+
+
+# ------------------------------------------------------------------------------------------- eps at the bench grid
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bench_grid_unet_eps_and_taps(dtype):
+    e, mc, u, cc, sd, _ = full_engine("c2", dtype)
+    B, Lz, F = 32, 1200, 120
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, 128, Lz, generator=g) * 0.7
+    cond = torch.randn(B, 128, F, generator=g)
+    items = (3, 29)                                   # one item of each 16-item batch part
+    for t in (37, 499):
+        got = e.unet_forward(x.cuda(), t, cond.cuda())
+        taps_got = {n: None for n in ("down4", "mid", "up0", "up4")}
+        for i in items:
+            def run(i=i, t=t):
+                taps = {}
+                eps = O.unet_forward(sd, u, x[i:i + 1], torch.full((1,), t, dtype=torch.long), cond[i:i + 1], taps=taps)
+                return eps, {n: taps[n] for n in taps_got}
+            ref_eps, ref_taps = cached(("eps", i, t), run)
+            err = rel(got[i:i + 1].cpu().numpy(), ref_eps.numpy())
+            check(dtype, "eps_bench", err, (t, i))
+            for n in taps_got:
+                shp = (B,) + tuple(ref_taps[n].shape[1:])
+                tg = e.debug_tap(n, shp)[i:i + 1].cpu().numpy()
+                terr = rel(tg, ref_taps[n].numpy())
+                check(dtype, "tap_bench", terr, (t, i, n))
+        # a dead UNet is nowhere near: eps has unit scale
+        assert rel(np.zeros_like(ref_eps.numpy()), ref_eps.numpy()) > 20 * TOL[dtype]["eps_bench"]
+
+
+# ------------------------------------------------------------------------------------------- N = 50 decode at the bench shape
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bench_decode_50_steps_against_oracle(dtype):
+    """The timed workload itself (B = 32 x 2.4 s, 50 steps, two parts, 5-step graphs) with injected noise: two utterances
+    against the CPU oracle decoding them alone, all 50 steps."""
+    e, mc, u, cc, sd, sdc = full_engine("c2", dtype)
+    B, Tn, n = 32, 38400, 50
+    Lz = Tn // mc.hop_length
+    wav = torch.from_numpy(synth.synthetic_wav(B, Tn, seed=1234))
+    items = (5, 22)
+    noise = torch.randn(n, B, 128, Lz, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    per_item = {}
+    for i in items:
+        per_item[i] = torch.randn(n, 1, 128, Lz, generator=torch.Generator().manual_seed(100 + i))
+        noise[:, i:i + 1] = per_item[i].cuda()
+    got = e.decode(wav.cuda(), n, noise, per_item=True, want_stages=True)
+    for i in items:
+        ref = cached(("dec50", i), lambda i=i: O.decode_utterances(sdc, cc, sd, mc, u, wav[i:i + 1], n, per_item[i], per_item=True))
+        assert torch.equal(got["codes"][:, i:i + 1].cpu(), ref["codes"]), "RVQ codes must be bit-exact"
+        lat = rel(got["latents"][i:i + 1].cpu().numpy(), ref["latents"].numpy())
+        wv = rel(got["wav"][i:i + 1].cpu().numpy(), ref["wav"].numpy())
+        check(dtype, "lat_50", lat, i)
+        check(dtype, "wav_50", wv, i)
+
+
+# ------------------------------------------------------------------------------------------- chains where eps matters + dead-UNet guard
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["r84", "r8"])
+def test_chain_from_high_t_and_dead_unet_guard(tag, dtype):
+    """halfway_sampling with t = 250 (ddpm_loss.py:370-385): 250 steps from t = 249, where sqrt_recipm1_alphas_cumprod
+    is 0.41 and eps drives the update.  The guard: the same chain with eps == 0 must miss by >= 10x the tolerance."""
+    g = load_golden("ladiff_" + tag)
+    mc, u, _ = CASES[tag]
+    e = engine(tag, dtype)
+    sd = synth.to_torch(main_sd_np(tag))
+    cond = T(g["cond"])
+    n = 250
+    gen = torch.Generator().manual_seed(77)
+    noises = torch.randn(n, *g["x"].shape, generator=gen)
+    img = T(g["img0"])
+    ref = cached(("chain250", tag), lambda: O.halfway_sampling(sd, u, img, cond, n, noises))
+
+    def dead_chain():
+        x = img.clone()
+        for j, t in enumerate(reversed(range(n))):
+            x = O.p_sample_update(sd, x, torch.zeros_like(x), t, noises[j])
+        return x
+    dead = cached(("dead250", tag), dead_chain)
+    got = e.denoise(img.cuda(), cond.cuda(), n, noises.cuda()).cpu()
+    err = rel(got.numpy(), ref.numpy())
+    tol = TOL[dtype]["chain_250"]
+    check(dtype, "chain_250", err, tag)
+    assert rel(dead.numpy(), ref.numpy()) > 10 * tol, "a UNet returning zeros would pass this test"
+
+
+# ------------------------------------------------------------------------------------------- C8: the released checkpoints' layout, full width
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_c8_full_width_unet_and_decoder(dtype):
+    """enc_ratios [8], latent L = 4800, upsampling 5-4-2, attention over n = 300, LSTM H = 64 over T = 4800
+    (README.md:30,35), dim 256: one UNet call (two batch parts) and the SEANet decoder against the oracle."""
+    e, mc, u, cc, sd, _ = full_engine("c8", dtype)
+    B, Lz, F = 2, 4800, 120
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(B, 128, Lz, generator=g) * 0.7
+    cond = torch.randn(B, 128, F, generator=g)
+    t = 211
+    ref = cached(("c8eps",), lambda: O.unet_forward(sd, u, x, torch.full((B,), t, dtype=torch.long), cond))
+    got = e.unet_forward(x.cuda(), t, cond.cuda()).cpu()
+    err = rel(got.numpy(), ref.numpy())
+    check(dtype, "eps_bench", err, "c8")
+    lat = torch.tanh(torch.randn(B, 128, Lz, generator=g))
+    want = cached(("c8dec",), lambda: O.seanet_decode(sd, mc, lat))
+    wav = e.decode_latents(L.MODEL_MAIN, lat.cuda()).cpu()
+    assert wav.shape == (B, 1, Lz * 8)
+    assert rel(wav.numpy(), want.numpy()) < 1e-4     # the codec runs exact fp32 in both engines
+
+
+# ------------------------------------------------------------------------------------------- C3: 1.5 kbps condition, 200 steps
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_c3_1p5kbps_200_steps(dtype):
+    """BASELINE configs[2]: cond_bandwidth 1.5 (3 codebooks built and used, model.py:64-66 / vq.py:86-98), 200 DDPM steps,
+    dim 256: one utterance of a 4-utterance batch against the oracle, end to end."""
+    e, mc, u, cc, sd, sdc = full_engine("c2", dtype, cond_bandwidth=1.5)
+    B, Tn, n = 4, 38400, 200
+    Lz = Tn // mc.hop_length
+    wav = torch.from_numpy(synth.synthetic_wav(B, Tn, seed=77))
+    noise = torch.randn(n, B, 128, Lz, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    mine = torch.randn(n, 1, 128, Lz, generator=torch.Generator().manual_seed(9))
+    noise[:, 2:3] = mine.cuda()
+    got = e.decode(wav.cuda(), n, noise, per_item=True, want_stages=True)
+    assert got["codes"].shape[0] == 3
+    ref = cached(("c3",), lambda: O.decode_utterances(sdc, cc, sd, mc, u, wav[2:3], n, mine, per_item=True))
+    assert torch.equal(got["codes"][:, 2:3].cpu(), ref["codes"])
+    check(dtype, "lat_200", rel(got["latents"][2:3].cpu().numpy(), ref["latents"].numpy()))
+    check(dtype, "wav_200", rel(got["wav"][2:3].cpu().numpy(), ref["wav"].numpy()))
+
+
+# ------------------------------------------------------------------------------------------- flag variants on the path
+def test_flag_variants_against_reference_vectors():
+    """--unet_scale_x, upsampling_ratios=None and --final_activation against the reference's outputs (variants.npz)."""
+    g = load_golden("variants")
+    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    for dtype in ("f32", "bf16"):
+        def small(v):
+            check(dtype, "eps_small", v)
+        u = UnetConfig(dim=32, upsampling_ratios=(5, 2), unet_scale_cond=True, unet_scale_x=True)
+        e = Engine(mc, u, COND_CFG, dtype=dtype)
+        e.load_state_dict(L.MODEL_MAIN, synth.ladiff_state_dict(mc, u, int(g["meta"][0])))
+        e.load_state_dict(L.MODEL_COND, cond_sd_np())
+        e.finalize(strict=True)
+        small(rel(e.unet_forward(cu(g["sx.x"]), 37, cu(g["sx.cond"])).cpu().numpy(), g["sx.eps_t37"]))
+        e.close()
+        u = UnetConfig(dim=32, upsampling_ratios=None, unet_scale_cond=True)
+        e = Engine(mc, u, COND_CFG, dtype=dtype)
+        e.load_state_dict(L.MODEL_MAIN, synth.ladiff_state_dict(mc, u, int(g["meta"][1])))
+        e.load_state_dict(L.MODEL_COND, cond_sd_np())
+        e.finalize(strict=True)
+        small(rel(e.unet_forward(cu(g["nu.x"]), 37, cu(g["nu.cond"])).cpu().numpy(), g["nu.eps_t37"]))
+        small(rel(e.p_sample(cu(g["nu.x"]), 0, cu(g["nu.cond"])).cpu().numpy(), g["nu.p_sample_t0"]))
+        with pytest.raises(L.LdcError):                        # F != L without upsampling layers
+            e.unet_forward(cu(g["nu.x"]), 37, cu(g["nu.cond"])[:, :, :16].contiguous())
+        from ladiffcodec_amd.model import DiffAudioRep
+        with pytest.raises(AttributeError):                    # the reference's halfway_sampling touches model.upsampling_layers
+            DiffAudioRep(e, L.MODEL_MAIN).diffusion.halfway_sampling(img=cu(g["nu.x"]), t=2, condition=cu(g["nu.cond"]))
+        e.close()
+    cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0, final_activation="Tanh")
+    mcf = CodecConfig(enc_ratios=(8, 4), quantization=False, final_activation="Tanh")
+    u = CASES["r84"][1]
+    e = Engine(mcf, u, cc, dtype="f32")
+    e.load_state_dict(L.MODEL_MAIN, main_sd_np("r84"))
+    e.load_state_dict(L.MODEL_COND, synth.codec_state_dict(cc, int(g["meta"][2])))
+    e.finalize(strict=True)
+    z = e.encode(L.MODEL_COND, cu(g["fa.wav"]))
+    assert rel(z.cpu().numpy(), g["fa.z"]) < 1e-4
+    cond, codes = e.get_cond(cu(g["fa.wav"]), return_codes=True)
+    _, _, margins = O.rvq_forward(synth.to_torch(synth.codec_state_dict(cc, int(g["meta"][2]))), T(g["fa.z"]), 6)
+    safe = margins.numpy() > 1e-3
+    assert np.array_equal(codes.cpu().numpy()[safe], g["fa.codes"][safe])
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------- device noise: fresh per call, reproducible by reseed
+def test_device_noise_advances_per_call_and_reseeds():
+    """ddpm_loss.py:249 draws torch.randn_like on every p_sample call; the device stream does the same: two calls differ,
+    ldc_reseed rewinds (torch.manual_seed's counterpart)."""
+    tag = "r84"
+    g = load_golden("ladiff_" + tag)
+    e = engine(tag, "f32")
+    cond, x0 = cu(g["cond"]), cu(g["img0"])
+    e.reseed(123)
+    a = e.denoise(x0, cond, 6, None)
+    b = e.denoise(x0, cond, 6, None)
+    assert rel(a.cpu().numpy(), b.cpu().numpy()) > 1e-2, "two calls must not share a noise realisation"
+    e.reseed(123)
+    a2 = e.denoise(x0, cond, 6, None)
+    b2 = e.denoise(x0, cond, 6, None)
+    assert rel(a2.cpu().numpy(), a.cpu().numpy()) < 1e-5 and rel(b2.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    # items of one call draw different noise
+    z = torch.zeros(2, *g["x"].shape[1:], device="cuda")
+    y = e.p_sample(z, 500, cond, None) - e.p_sample(z, 500, cond, torch.zeros_like(z))
+    assert rel(y[0].cpu().numpy(), y[1].cpu().numpy()) > 0.5
+    e.reseed(0)
+
+
+def test_plan_cache_is_bounded():
+    """Many distinct (B, L) shapes (a corpus of different lengths): the LRU plan cache evicts instead of growing; a
+    re-used shape still decodes identically after its plan was evicted and rebuilt."""
+    import os
+    mc, u, _ = CASES["r84"]
+    os.environ["LDC_PLAN_CACHE_N"] = "8"
+    try:
+        e = Engine(mc, u, COND_CFG, dtype="f32")
+    finally:
+        del os.environ["LDC_PLAN_CACHE_N"]
+    e.load_state_dict(L.MODEL_MAIN, main_sd_np("r84"))
+    e.load_state_dict(L.MODEL_COND, cond_sd_np())
+    e.finalize(strict=True)
+    wav0 = torch.from_numpy(synth.synthetic_wav(2, 5120, seed=3)).cuda()
+    first = e.decode(wav0, 3, per_item=True, noise=torch.zeros(3, 2, 128, 160, device="cuda"))
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(1, 13):
+        Tn = 5120 + 2560 * k
+        w = torch.from_numpy(synth.synthetic_wav(2, Tn, seed=k)).cuda()
+        out = e.decode(w, 3, per_item=True)
+        assert torch.isfinite(out).all()
+    again = e.decode(wav0, 3, per_item=True, noise=torch.zeros(3, 2, 128, 160, device="cuda"))
+    assert rel(again.cpu().numpy(), first.cpu().numpy()) < 1e-5
+    torch.cuda.synchronize()
+    # 12 more shapes did not leave 12 more workspaces behind (each is tens of MB at these sizes)
+    assert free0 - torch.cuda.mem_get_info()[0] < (1 << 30)
+    e.close()

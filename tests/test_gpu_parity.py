@@ -1,9 +1,10 @@
 """GPU parity tests: the HIP path, called through the C ABI (ctypes), against (a) the golden vectors
 made by running the reference (tests/golden/) and (b) the CPU oracle on fresh seeded inputs.
 
-Tolerances (relative to the max |reference|):
-  f32 engine (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32)    2e-4 per stage, 1e-3 after a chain
-  bf16 engine (bf16 storage + MFMA, fp32 accumulate/state)  6e-2 per UNet call, 0.2 after a chain
+Tolerances (relative to the max |reference|) are 2x the drift measured on MI355X (tests/drift_tolerances.py):
+  f32 engine (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32), bf16 engine (bf16 storage + MFMA, fp32 accumulate/state).
+  The short chains here start at t <= 3 where eps hardly matters (they pin the golden vectors and the plumbing);
+  tests/test_gpu_bench_shape.py holds the eps-sensitive and bench-shape checks.
   RVQ codes: bit-exact wherever the oracle's top-2 margin exceeds 1e-3 (all codec stages run fp32
   in both engines precisely so that the codes do not depend on the UNet dtype).
 """
@@ -17,17 +18,11 @@ from ladiffcodec_amd import lib as L, synth  # noqa: E402
 from oracle import ldc_oracle as O  # noqa: E402
 from helpers import CASES, COND_CFG, T, cond_sd_np, load_golden, main_sd_np  # noqa: E402
 from gpu_common import engine, rel  # noqa: E402
-
-F32_TOL, BF16_TOL = 2e-4, 6e-2
+from drift_tolerances import TOL, check  # noqa: E402
 
 
 def cu(x):
     return torch.from_numpy(np.ascontiguousarray(x)).cuda()
-
-
-def tol_for(dtype, chain=False):
-    base = F32_TOL if dtype == "f32" else BF16_TOL
-    return base * (5 if chain else 1) if dtype == "f32" else (0.2 if chain else base)
 
 
 # ------------------------------------------------------------------------------------------- L1 primitives
@@ -122,14 +117,13 @@ def test_unet_forward_and_taps(tag, dtype):
     g = load_golden("ladiff_" + tag)
     mc, u, _ = CASES[tag]
     e = engine(tag, dtype)
-    tol = tol_for(dtype)
     cond, x = cu(g["cond"]), cu(g["x"])
     for t in (0, 37):
-        assert rel(e.unet_forward(x, t, cond).cpu().numpy(), g[f"eps_t{t}"]) < tol, t
+        check(dtype, "eps_small", rel(e.unet_forward(x, t, cond).cpu().numpy(), g[f"eps_t{t}"]), (tag, t))
     taps = {}
     O.unet_forward(synth.to_torch(main_sd_np(tag)), u, T(g["x"]), torch.full((2,), 37, dtype=torch.long), T(g["cond"]), taps=taps)
     for name in ["cond_proc", "init", "down0", "down4", "mid", "up0", "up4"]:
-        assert rel(e.debug_tap(name, taps[name].shape).cpu().numpy(), taps[name].numpy()) < tol, name
+        check(dtype, "eps_small", rel(e.debug_tap(name, taps[name].shape).cpu().numpy(), taps[name].numpy()), (tag, name))
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -143,17 +137,17 @@ def test_sampler_chain_and_stage_tensors(tag, dtype):
     noises = cu(g["noises"])
     assert rel(e.cond_upsample(cond, 0).cpu().numpy(), g["img_up"]) < 1e-5
     assert rel(e.cond_upsample(cond, 1).cpu().numpy(), g["img0"]) < 1e-5
-    assert rel(e.p_sample(x, 5, cond, noises[n - 1]).cpu().numpy(), g["p_sample_t5"]) < tol_for(dtype)
+    check(dtype, "chain_small", rel(e.p_sample(x, 5, cond, noises[n - 1]).cpu().numpy(), g["p_sample_t5"]), tag)
     lat = e.denoise(cu(g["img0"]), cond, n, noises)                   # first call: eager step + graph capture
-    assert rel(lat.cpu().numpy(), g["latents"]) < tol_for(dtype, chain=True)
-    lat2 = e.denoise(cu(g["img0"]), cond, n, noises)                  # second call: may re-capture (new x buffer)
-    assert rel(lat2.cpu().numpy(), lat.cpu().numpy()) < (1e-6 if dtype == "f32" else 2e-2)
+    check(dtype, "chain_small", rel(lat.cpu().numpy(), g["latents"]), tag)
+    lat2 = e.denoise(cu(g["img0"]), cond, n, noises)                  # second call: graph replay
+    check(dtype, "repeat", rel(lat2.cpu().numpy(), lat.cpu().numpy()), tag)
     assert rel(e.decode_latents(L.MODEL_MAIN, cu(g["latents"])).cpu().numpy(), g["wav_raw"]) < 1e-4
     assert rel(e.output_normalise(cu(g["wav_raw"])).cpu().numpy(), g["wav_out"]) < 1e-5
     out = e.decode(cu(g["wav"]), n, noises, per_item=False, want_stages=True)
     assert rel(out["cond"].cpu().numpy(), g["cond"]) < 1e-4
-    assert rel(out["latents"].cpu().numpy(), g["latents"]) < tol_for(dtype, chain=True)
-    assert rel(out["wav"].cpu().numpy(), g["wav_out"]) < (5e-3 if dtype == "f32" else 0.5)
+    check(dtype, "chain_small", rel(out["latents"].cpu().numpy(), g["latents"]), tag)
+    check(dtype, "wav_small", rel(out["wav"].cpu().numpy(), g["wav_out"]), tag)
 
 
 def test_graph_replay_equals_eager_many_steps():
@@ -178,10 +172,12 @@ def test_philox_noise_is_standard_normal_and_seeded():
     e = engine(tag, "f32")
     cond = cu(g["cond"])
     x0 = cu(g["img0"])
+    e.reseed(0)
     a = e.denoise(x0, cond, 6, None)
+    e.reseed(0)
     b = e.denoise(x0, cond, 6, None)
-    # same seed, same step indices -> same draws (fp32 atomics in the GroupNorm / attention reductions make the
-    # two runs agree to rounding, not bit for bit)
+    # same seed, same call counter, same step indices -> same draws (fp32 atomics in the GroupNorm / attention
+    # reductions make the two runs agree to rounding, not bit for bit)
     assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
     assert torch.isfinite(a).all()
     # one step from zeros with eps-independent part removed: x_new - mean = sigma * z
@@ -284,14 +280,14 @@ def test_full_width_unet_step_against_oracle(dtype):
     t = 23
     ref = O.unet_forward(synth.to_torch(sd), u, x, torch.full((B,), t, dtype=torch.long), cond)
     got = e.unet_forward(x.cuda(), t, cond.cuda()).cpu()
-    assert rel(got.numpy(), ref.numpy()) < (2e-4 if dtype == "f32" else 6e-2)
+    check(dtype, "eps_bench", rel(got.numpy(), ref.numpy()), "B3_L320")
     # two sampler steps with injected noise through the captured-graph path (n >= 3 steps)
     n = 3
     noise = torch.randn(n, B, 128, Lz, generator=g)
     img = torch.randn(B, 128, Lz, generator=g).clamp(-1, 1) * 0.5
     want = O.halfway_sampling(synth.to_torch(sd), u, img, cond, n, noise)
     have = e.denoise(img.cuda(), cond.cuda(), n, noise.cuda()).cpu()
-    assert rel(have.numpy(), want.numpy()) < (1e-3 if dtype == "f32" else 0.2)
+    check(dtype, "chain_small", rel(have.numpy(), want.numpy()), "full width")
     e.close()
 
 
@@ -366,7 +362,6 @@ def test_bench_workload_items_against_oracle(dtype):
     for i in (3, 29):
         ref = O.decode_utterances(sdc_t, COND_CFG, sd_t, mc, u, wav[i:i + 1], n, noise[:, i:i + 1], per_item=True)
         assert torch.equal(got["codes"][:, i:i + 1].cpu(), ref["codes"]), "RVQ codes must be bit-exact"
-        lat_tol, wav_tol = (2e-4, 2e-3) if dtype == "f32" else (5e-2, 0.3)
-        assert rel(got["latents"][i:i + 1].cpu().numpy(), ref["latents"].numpy()) < lat_tol
-        assert rel(got["wav"][i:i + 1].cpu().numpy(), ref["wav"].numpy()) < wav_tol
+        check(dtype, "chain_small", rel(got["latents"][i:i + 1].cpu().numpy(), ref["latents"].numpy()), i)
+        check(dtype, "wav_small", rel(got["wav"][i:i + 1].cpu().numpy(), ref["wav"].numpy()), i)
     e.close()

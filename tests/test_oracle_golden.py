@@ -115,3 +115,26 @@ def test_alternative_samplers_match_reference():
     assert rel_err(out.numpy(), g["loop_out"]) < 2e-4      # 1000 chained steps
     img, _ = O.infilling(sd, u, T(g["fill_img0"]), T(g["fill_infill0"]), cond, midway_t, fill_noise, lam=0.8)
     assert rel_err(img.numpy(), g["fill_out"]) < TOL
+
+
+def test_flag_variants_match_reference():
+    """--unet_scale_x (unet.py:432-433), upsampling_ratios=None (unet.py:411) and --final_activation (seanet.py:144-149)
+    against the reference's own outputs (tests/golden/variants.npz)."""
+    from ladiffcodec_amd.spec import CodecConfig, UnetConfig
+    g = load_golden("variants")
+    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    t37 = torch.full((2,), 37, dtype=torch.long)
+    u = UnetConfig(dim=32, upsampling_ratios=(5, 2), unet_scale_cond=True, unet_scale_x=True)
+    sd = synth.to_torch(synth.ladiff_state_dict(mc, u, int(g["meta"][0])))
+    assert rel_err(O.unet_forward(sd, u, T(g["sx.x"]), t37, T(g["sx.cond"])).numpy(), g["sx.eps_t37"]) < 5e-5
+    u = UnetConfig(dim=32, upsampling_ratios=None, unet_scale_cond=True)
+    sd = synth.to_torch(synth.ladiff_state_dict(mc, u, int(g["meta"][1])))
+    assert not any("upsampling_layers" in k for k in sd)
+    assert rel_err(O.unet_forward(sd, u, T(g["nu.x"]), t37, T(g["nu.cond"])).numpy(), g["nu.eps_t37"]) < 5e-5
+    assert rel_err(O.p_sample(sd, u, T(g["nu.x"]), 0, T(g["nu.cond"]), None).numpy(), g["nu.p_sample_t0"]) < 5e-5
+    cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0, final_activation="Tanh")
+    sdc = synth.to_torch(synth.codec_state_dict(cc, int(g["meta"][2])))
+    q, codes, margins, z = O.get_cond(sdc, cc, T(g["fa.wav"]))
+    assert rel_err(z.numpy(), g["fa.z"]) < TOL and float(np.abs(g["fa.z"]).max()) <= 1.0
+    safe = margins.numpy() > 1e-3
+    assert np.array_equal(codes.numpy()[safe], g["fa.codes"][safe])

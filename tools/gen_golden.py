@@ -37,7 +37,7 @@ def build_cond_model(ref, cc: CodecConfig, seed: int):
     # exactly as reference srcs/sample.py:63 (the `ratios=` kwarg is swallowed: quirk Q1)
     m = ref.DiffAudioRep(rep_dims=cc.rep_dims, emb_dims=128, n_residual_layers=cc.n_residual_layers,
                          n_filters=cc.n_filters, lstm=cc.lstm, quantization=True, bandwidth=cc.bandwidth,
-                         ratios=[8, 5, 4, 2], final_activation=None)
+                         ratios=[8, 5, 4, 2], final_activation=cc.final_activation)
     sd = synth.to_torch(synth.codec_state_dict(cc, seed))
     m.load_state_dict(sd, strict=True)
     return m.eval()
@@ -47,7 +47,8 @@ def build_main_model(ref, mc: CodecConfig, u: UnetConfig, seed: int):
     # as reference srcs/sample.py:56 with the README flags (--run_diff --scaling_global --unet_scale_cond)
     m = ref.DiffAudioRep(other_cond=True, rep_dims=mc.rep_dims, emb_dims=128, diff_dims=u.dim, n_filters=mc.n_filters,
                          lstm=mc.lstm, n_residual_layers=mc.n_residual_layers, enc_ratios=list(mc.enc_ratios),
-                         upsampling_ratios=list(u.upsampling_ratios), run_diff=True, model_type="unet",
+                         upsampling_ratios=list(u.upsampling_ratios) if u.upsampling_ratios is not None else None,
+                         run_diff=True, model_type="unet",
                          scaling_global=True, unet_scale_cond=u.unet_scale_cond, unet_scale_x=u.unet_scale_x,
                          sampling_timesteps=1000, quantization=False, bandwidth=3.0, cond_global=3.0, seq_length=16000)
     sd = synth.to_torch(synth.ladiff_state_dict(mc, u, seed))
@@ -91,6 +92,7 @@ def main():
 
     # ---------------------------------------------------------------- primitive KATs (L1)
     g = torch.Generator().manual_seed(7)
+    torch.manual_seed(7)      # the modules below are default-initialised from the global generator: seed it (regenerable fixture)
     kat = {}
     cases = [  # name, cin, cout, k, stride, dilation, causal, length
         ("c_k7", 8, 16, 7, 1, 1, True, 37), ("c_k4s2", 8, 16, 4, 2, 1, True, 37), ("c_k10s5", 8, 8, 10, 5, 1, True, 43),
@@ -244,8 +246,45 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"drivers_{tag}.npz"), **out)
         print(f"drivers_{tag}: loop_out absmax", float(np.abs(out["loop_out"]).max()), "fill_out absmax", float(np.abs(out["fill_out"]).max()))
 
+    # ---------------------------------------------------------------- flag variants on the path: --unet_scale_x
+    # (unet.py:432-433), upsampling_ratios=None (unet.py:411), --final_activation (seanet.py:144-149)
+    def variants_case():
+        out = {}
+        gg = torch.Generator().manual_seed(2024)
+        mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+        with torch.no_grad():
+            u = UnetConfig(dim=32, upsampling_ratios=(5, 2), unet_scale_cond=True, unet_scale_x=True)
+            m = build_main_model(ref, mc, u, seed=31)
+            x = torch.randn(2, 128, 160, generator=gg) * 1.7
+            cond = torch.randn(2, 128, 16, generator=gg)
+            out["sx.x"], out["sx.cond"] = np32(x), np32(cond)
+            out["sx.eps_t37"] = np32(m.diff_model(x, torch.full((2,), 37, dtype=torch.long), cond))
+            u = UnetConfig(dim=32, upsampling_ratios=None, unet_scale_cond=True)
+            m = build_main_model(ref, mc, u, seed=32)
+            x = torch.randn(2, 128, 160, generator=gg) * 0.7
+            cond = torch.randn(2, 128, 160, generator=gg)
+            out["nu.x"], out["nu.cond"] = np32(x), np32(cond)
+            out["nu.eps_t37"] = np32(m.diff_model(x, torch.full((2,), 37, dtype=torch.long), cond))
+            # (halfway_sampling itself raises AttributeError for this configuration -- ddpm_loss.py:376-378 touches
+            # model.upsampling_layers, which does not exist when upsampling_ratios is None; p_sample works)
+            one, _ = m.diffusion.p_sample(x.clone(), 0, cond)
+            out["nu.p_sample_t0"] = np32(one)
+            ccf = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0, final_activation="Tanh")
+            cm = build_cond_model(ref, ccf, seed=11)
+            wav = torch.from_numpy(synth.synthetic_wav(2, 3200, seed=55)) * 0.5
+            z = cm.encoder(wav)
+            q = cm.quantizer(z, sample_rate=cm.frame_rate, bandwidth=cm.bandwidth)
+            out["fa.wav"], out["fa.z"], out["fa.codes"] = np32(wav), np32(z), q.codes.numpy().astype(np.int64)
+            out["fa.quantized"] = np32(q.quantized)
+        out["meta"] = np.array([31, 32, 11], np.int64)
+        np.savez_compressed(os.path.join(OUT, "variants.npz"), **out)
+        print("variants: sx eps absmax", float(np.abs(out["sx.eps_t37"]).max()), "fa z absmax", float(np.abs(out["fa.z"]).max()))
+
+    variants_case()
     mc84 = CodecConfig(enc_ratios=(8, 4), quantization=False)
     u84 = UnetConfig(dim=32, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    if os.environ.get("GOLDEN_ONLY") == "variants":
+        return
     if os.environ.get("GOLDEN_ONLY") == "drivers":
         drivers_case("r84", mc84, u84, T=2560, seed_w=21, seed_in=777, midway_t=5)
         return
