@@ -199,6 +199,10 @@ int ldc_profile_enable(ldc_ctx* ctx, int on);
 int ldc_gn_microbench(ldc_ctx* ctx, int dtype, int B, int L, int C, int with_residual, int iters, double* ms_per_launch);
 int ldc_conv_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups,
                         int iters, double* ms_per_launch);
+/* Tuning aid: times one strip-form ResnetBlock half (Conv1d k=3 + GroupNorm + scale/shift + SiLU, optionally followed by the
+ * 1x1 res_conv on the same accumulators; conv_strip.inc) on pseudo-random data. */
+int ldc_strip_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int with_res, int iters,
+                         double* ms_per_launch);
 int ldc_profile_read(ldc_ctx* ctx, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
 /* Per kernel class (LDC_CLASS_*) totals of the same profiling pass: event-timed milliseconds, launches, algorithmic
  * flops and algorithmic HBM bytes; arrays of n >= LDC_N_CLASSES entries (any may be NULL). */

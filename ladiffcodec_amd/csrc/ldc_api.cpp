@@ -135,6 +135,7 @@ struct Codec {
 };
 
 struct ResnetW {
+  StripLayer s1, s2, sres;      // the same three convs packed for the strip kernel (conv_strip.inc)
   ConvLayer c1, c2, res;
   bool has_res = false;
   float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
@@ -240,6 +241,8 @@ struct ldc_ctx {
   int fuse_kmax = 1;
   int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
   int fuse_gn_stats = 1;
+  int strip_mode = 1;           // LDC_STRIP: 0 never | 1 when the grid fills the chip (default) | 2 whenever eligible
+  int strip_min_wgs = 96;       // LDC_STRIP_MIN: workgroups (items x strips) from which mode 1 picks the strip form
   // knobs read from the environment once, at ldc_create (per context, not process-global)
   ConvTune tune;
   int lstm_stream_only = 0;     // LDC_LSTM_STREAM: never use the cooperative LSTM
@@ -418,6 +421,25 @@ static int make_convtr(ldc_ctx* c, int dt, int cin, int cout, int stride, int tr
     for (int p = 0; p < stride; ++p)
       for (int co = 0; co < cout; ++co) b[(size_t)p * cout + co] = bias[co];
   LDCCHK(c->wmem.upload(&ly.bias, b));
+  *out = ly;
+  return LDC_OK;
+}
+
+static int make_strip(ldc_ctx* c, int dt, int cin, int cout, int taps, const float* w_oik, const float* bias, StripLayer* out) {
+  StripLayer ly;
+  ly.dt = dt; ly.cin = cin; ly.n = cout; ly.taps = taps;
+  const int che = 64 / (int)dt_size(dt);
+  if (cin % che || cout % 32) return LDC_OK;   // not packable: the plan never picks the strip form for it (ly.w stays null)
+  std::vector<char> packed(strip_packed_weight_bytes(dt, cin, cout, taps));
+  pack_strip_weights(dt, cin, cout, taps, w_oik, packed.data());
+  void* dw = nullptr;
+  LDCCHK(c->wmem.alloc(&dw, packed.size()));
+  HIPCHK(hipMemcpy(dw, packed.data(), packed.size(), hipMemcpyHostToDevice));
+  ly.w = dw;
+  if (bias) {
+    std::vector<float> b(bias, bias + cout);
+    LDCCHK(c->wmem.upload(&ly.bias, b));
+  }
   *out = ly;
   return LDC_OK;
 }
@@ -647,17 +669,20 @@ static int build_resnet(ldc_ctx* c, WeightReader& wr, const std::string& p, int 
   {
     std::vector<float> w = fold_weight_std(*w1);
     LDCCHK(make_conv(c, sp, w.data(), b1->data.data(), &r->c1));
+    LDCCHK(make_strip(c, c->dt, cin, cout, 3, w.data(), b1->data.data(), &r->s1));
   }
   {
     std::vector<float> w = fold_weight_std(*w2);
     ConvSpec s2 = sp;
     s2.cin1 = cout; s2.cin2 = 0;
     LDCCHK(make_conv(c, s2, w.data(), b2->data.data(), &r->c2));
+    LDCCHK(make_strip(c, c->dt, cout, cout, 3, w.data(), b2->data.data(), &r->s2));
   }
   if (r->has_res) {
     ConvSpec s3 = sp;
     s3.k = 1; s3.pad_left = 0;
     LDCCHK(make_conv(c, s3, wr_->data.data(), br_->data.data(), &r->res));
+    LDCCHK(make_strip(c, c->dt, cin, cout, 1, wr_->data.data(), br_->data.data(), &r->sres));
   }
   LDCCHK(c->wmem.upload(&r->g1, g1->data));
   LDCCHK(c->wmem.upload(&r->b1, be1->data));
@@ -913,6 +938,8 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->tune.sk_u3 = env_int("LDC_SK_U3", c->tune.sk_u3);
   c->tune.m_fastest = env_int("LDC_CONV_MFAST", c->tune.m_fastest);
   c->tune.debug = env_int("LDC_CONV_DEBUG", 0);
+  c->strip_mode = env_int("LDC_STRIP", 1);
+  c->strip_min_wgs = env_int("LDC_STRIP_MIN", 96);
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
   c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
   c->graph_steps = std::max(1, env_int("LDC_GRAPH_STEPS", 5));
@@ -1438,6 +1465,53 @@ struct PlanBuilder {
     pl->conv_bytes += cbytes;
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out, LDC_CLASS_CONV, cbytes);
   }
+  // ResnetBlock as two strip launches (conv_strip.inc): conv1+GN+scale/shift+SiLU, then conv2+GN+SiLU+res_conv/identity
+  bool strip_ok(const ResnetW& r, int L) const {
+    if (c->strip_mode <= 0 || !r.s1.w || !r.s2.w || (r.has_res && !r.sres.w)) return false;
+    const int cin = r.cin1 + r.cin2;
+    if (!conv_strip_eligible(c->dt, r.cout, c->unet.groups, L, cin, 0)) return false;
+    if (!conv_strip_eligible(c->dt, r.cout, c->unet.groups, L, r.cout, r.has_res ? cin : 0)) return false;
+    if (c->strip_mode >= 2) return true;
+    const int cpg = r.cout / c->unet.groups;
+    return (long)B * (r.cout / std::max(32, cpg)) >= c->strip_min_wgs;
+  }
+  void* resnet_strip(const ResnetW& r, const void* x1, const void* x2, int L) {
+    const int rows = B * L;
+    const long long e = (long long)es;
+    void* h = act(rows, r.cout);
+    void* out = act(rows, r.cout);
+    const ResnetW* rp = &r;
+    const int cin = r.cin1 + r.cin2;
+    StripCall a;
+    a.conv = &rp->s1; a.x1 = x1; a.x2 = x2; a.C1 = r.cin1; a.C2 = r.cin2;
+    a.x1_rs = r.cin1 * e; a.x1_cs = 64; a.x2_rs = r.cin2 * e; a.x2_cs = 64;
+    a.gamma = r.g1; a.beta = r.b1; a.ss = pl->cur_ss + r.ss_off; a.groups = c->unet.groups;
+    a.y = h; a.y_rs = r.cout * e; a.y_cs = 64; a.B = B; a.L = L;
+    char buf[96];
+    snprintf(buf, sizeof(buf), "strip_k3_c%d+%d->%d_L%d_gn_ss", r.cin1, r.cin2, r.cout, L);
+    info = buf;
+    const double by1 = ((double)rows * (cin + r.cout)) * es + (double)strip_packed_weight_bytes(c->dt, cin, r.cout, 3);
+    pl->conv_bytes += by1;
+    add([a](hipStream_t s) { return launch_conv_strip(a, s); }, true, 2.0 * rows * r.cout * 3.0 * cin, LDC_CLASS_CONV, by1);
+    StripCall b;
+    b.conv = &rp->s2; b.x1 = h; b.C1 = r.cout; b.x1_rs = r.cout * e; b.x1_cs = 64;
+    b.gamma = r.g2; b.beta = r.b2; b.ss = nullptr; b.groups = c->unet.groups;
+    if (r.has_res) {
+      b.res = &rp->sres; b.r1 = x1; b.r2 = x2; b.RC1 = r.cin1; b.RC2 = r.cin2;
+      b.r1_rs = r.cin1 * e; b.r1_cs = 64; b.r2_rs = r.cin2 * e; b.r2_cs = 64;
+    } else {
+      b.res_id = x1; b.res_rs = r.cout * e; b.res_cs = 64;
+    }
+    b.y = out; b.y_rs = r.cout * e; b.y_cs = 64; b.B = B; b.L = L;
+    snprintf(buf, sizeof(buf), "strip_k3_c%d->%d_L%d_gn_%s", r.cout, r.cout, L, r.has_res ? "resconv" : "resid");
+    info = buf;
+    const double by2 = ((double)rows * (2 * r.cout + cin)) * es + (double)strip_packed_weight_bytes(c->dt, r.cout, r.cout, 3) +
+                       (r.has_res ? (double)strip_packed_weight_bytes(c->dt, cin, r.cout, 1) : 0.0);
+    pl->conv_bytes += by2;
+    add([b](hipStream_t s) { return launch_conv_strip(b, s); }, true, 2.0 * rows * r.cout * (3.0 * r.cout + (r.has_res ? cin : 0)),
+        LDC_CLASS_CONV, by2);
+    return out;
+  }
   float* next_stats() {
     const int g = c->unet.groups;
     return stats_pool + (size_t)(stats_used++) * B * g * 2;
@@ -1449,6 +1523,7 @@ struct PlanBuilder {
     const int rows = B * L, dt = c->dt, g = c->unet.groups, Bn = B;
     const UnetW* u = &c->unet;
     const float* cur_ss = pl->cur_ss;
+    if (strip_ok(r, L)) return resnet_strip(r, x1, x2, L);
     void* a = act(rows, r.cout);
     void* b = act(rows, r.cout);
     void* d = act(rows, r.cout);
@@ -2439,6 +2514,63 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     if (n) fprintf(stderr, "  stamps (shader cycles per workgroup): blocks=%d prologue=%.1f (tile+copy tables %.1f, first copies issued %.1f, fragment tables %.1f) loop=%.1f epilogue=%.1f\n",
                    n, pro / n, tab / n, dma / n, (pro - tab - dma) / n, loop / n, epi / n);
   }
+  return LDC_OK;
+}
+
+// Tuning aid: one ResnetBlock-half in strip form (conv k3 + GN + SiLU [+ 1x1 res_conv]) on random data.
+extern "C" int ldc_strip_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1, int cin2, int cout, int with_res, int iters,
+                                    double* ms_per_launch) {
+  if (!c || !ms_per_launch || iters < 1) return fail(LDC_E_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  const int dt = dtype == LDC_BF16 ? DT_BF16 : DT_F32;
+  const int cin = cin1 + cin2, g = 8;
+  if (!conv_strip_eligible(dt, cout, g, L, cin, 0) || (with_res && !conv_strip_eligible(dt, cout, g, L, cin, cin)))
+    return fail(LDC_E_INVALID, "shape not eligible for the strip kernel");
+  std::vector<float> w((size_t)cout * cin * 3), wr((size_t)cout * cin), bias(cout, 0.1f), gam(cout, 1.0f), bet(cout, 0.05f), ss(2 * cout, 0.1f);
+  unsigned seed = 12345u;
+  for (auto& v : w) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f; }
+  for (auto& v : wr) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f; }
+  DevMem keep;
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  StripLayer s1, sr;
+  int rc = make_strip(c, dt, cin, cout, 3, w.data(), bias.data(), &s1);
+  if (rc == LDC_OK && with_res) rc = make_strip(c, dt, cin, cout, 1, wr.data(), bias.data(), &sr);
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  LDCCHK(rc);
+  const size_t es = dt_size(dt);
+  void *x1 = nullptr, *x2 = nullptr, *y = nullptr;
+  float *dg = nullptr, *db = nullptr, *dss = nullptr;
+  LDCCHK(keep.alloc(&x1, (size_t)B * L * cin1 * es));
+  if (cin2) LDCCHK(keep.alloc(&x2, (size_t)B * L * cin2 * es));
+  LDCCHK(keep.alloc(&y, (size_t)B * L * cout * es));
+  LDCCHK(keep.upload(&dg, gam)); LDCCHK(keep.upload(&db, bet)); LDCCHK(keep.upload(&dss, ss));
+  {   // pseudo-random activations (a constant fill would flatter the clock: guide rule 25)
+    std::vector<unsigned short> hx((size_t)B * L * std::max(cin1, cin2) * (es / 2));
+    for (auto& v : hx) { seed = seed * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((seed >> 20) & 0x3ffu) + ((seed >> 3) & 0x8000u)); }
+    HIPCHK(hipMemcpy(x1, hx.data(), (size_t)B * L * cin1 * es, hipMemcpyHostToDevice));
+    if (cin2) HIPCHK(hipMemcpy(x2, hx.data(), (size_t)B * L * cin2 * es, hipMemcpyHostToDevice));
+  }
+  StripCall sc;
+  sc.conv = &s1; sc.x1 = x1; sc.x2 = x2; sc.C1 = cin1; sc.C2 = cin2;
+  sc.x1_rs = (long long)cin1 * es; sc.x1_cs = 64; sc.x2_rs = (long long)cin2 * es; sc.x2_cs = 64;
+  sc.gamma = dg; sc.beta = db; sc.ss = dss; sc.groups = g;
+  if (with_res) {
+    sc.res = &sr; sc.r1 = x1; sc.r2 = x2; sc.RC1 = cin1; sc.RC2 = cin2;
+    sc.r1_rs = sc.x1_rs; sc.r1_cs = 64; sc.r2_rs = sc.x2_rs; sc.r2_cs = 64;
+  }
+  sc.y = y; sc.y_rs = (long long)cout * es; sc.y_cs = 64; sc.B = B; sc.L = L;
+  hipStream_t s = c->own_stream;
+  for (int i = 0; i < 3; ++i) HIPCHK(launch_conv_strip(sc, s));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) HIPCHK(launch_conv_strip(sc, s));
+  HIPCHK(hipEventRecord(e1, s));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / iters;
   return LDC_OK;
 }
 

@@ -80,6 +80,40 @@ void pack_convtr_weights(const ConvLayer& ly, const float* w_iok, int cin, int c
 int conv_pick_bn(int n);
 
 // ------------------------------------------------------------------------------------------------
+// conv_strip_{bf16,f32}.hip : ResnetBlock convs in "strip" form -- Conv1d(k=3, pad 1) + GroupNorm + timestep
+// scale/shift + SiLU (+ 1x1 res_conv / identity residual) in ONE launch, one workgroup per (item, group strip)
+// ------------------------------------------------------------------------------------------------
+struct StripLayer {
+  int dt = DT_F32;
+  int cin = 0, n = 0, taps = 3;
+  void* w = nullptr;          // pack_strip_weights image
+  float* bias = nullptr;      // [n] fp32
+};
+struct StripCall {
+  const StripLayer* conv = nullptr;   // the k=3 conv
+  const void* x1 = nullptr; const void* x2 = nullptr;   // its (concatenated) inputs
+  int C1 = 0, C2 = 0;
+  long long x1_rs = 0, x1_cs = 0, x2_rs = 0, x2_cs = 0; // byte strides: row / 64-byte channel chunk
+  const float* gamma = nullptr; const float* beta = nullptr;
+  const float* ss = nullptr;          // [2n] timestep scale | shift, or null
+  int groups = 8;
+  const StripLayer* res = nullptr;    // optional 1x1 res_conv over cat(r1, r2), added after the activation
+  const void* r1 = nullptr; const void* r2 = nullptr;
+  int RC1 = 0, RC2 = 0;
+  long long r1_rs = 0, r1_cs = 0, r2_rs = 0, r2_cs = 0;
+  const void* res_id = nullptr;       // optional identity residual [rows][n]
+  long long res_rs = 0, res_cs = 0;
+  void* y = nullptr;
+  long long y_rs = 0, y_cs = 0;
+  int B = 0, L = 0;
+};
+// cin: channels of the k=3 conv's input, cres: of the res_conv's (0: none)
+bool conv_strip_eligible(int dt, int N, int groups, int L, int cin, int cres);
+hipError_t launch_conv_strip(const StripCall& sc, hipStream_t s);
+size_t strip_packed_weight_bytes(int dt, int cin, int n, int taps);
+void pack_strip_weights(int dt, int cin, int n, int taps, const float* w_oik, void* dst_host);
+
+// ------------------------------------------------------------------------------------------------
 // norm_act.hip
 // ------------------------------------------------------------------------------------------------
 // GroupNorm statistics of x [B][L][C]: stats[b][g] = (sum, sumsq) accumulated with fp32 atomics into a

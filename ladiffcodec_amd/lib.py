@@ -22,7 +22,7 @@ EXPORTS = [
     "ldc_seanet_encode", "ldc_seanet_decode", "ldc_rvq_encode", "ldc_rvq_decode", "ldc_get_cond",
     "ldc_cond_upsample", "ldc_unet_forward", "ldc_p_sample", "ldc_denoise", "ldc_p_sample_loop", "ldc_infilling", "ldc_output_normalise", "ldc_decode",
     "ldc_sconv1d", "ldc_sconvtr1d", "ldc_slstm", "ldc_unet_debug_tap", "ldc_unet_step_cost", "ldc_profile_enable",
-    "ldc_profile_read", "ldc_profile_read_classes", "ldc_conv_microbench", "ldc_gn_microbench",
+    "ldc_profile_read", "ldc_profile_read_classes", "ldc_conv_microbench", "ldc_gn_microbench", "ldc_strip_microbench",
 ]
 
 
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     lib.ldc_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.ldc_profile_read_classes.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ldc_conv_microbench.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
+    lib.ldc_strip_microbench.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     lib.ldc_gn_microbench.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     for name in EXPORTS:
         fn = getattr(lib, name)

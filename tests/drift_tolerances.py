@@ -8,13 +8,15 @@ quotes the same numbers.  f32 = exact-fp32 MFMA engine, bf16 = bf16 storage + MF
 import json
 import os
 
-MEASURED = {   # worst value seen over items / timesteps / layouts on MI355X (filled from gpurun_out/drift.json)
-    "f32": {"eps_bench": 1e-4, "tap_bench": 1e-4, "lat_50": 5e-4, "wav_50": 1e-3, "chain_250": 5e-4,
-            "lat_200": 5e-4, "wav_200": 1e-3, "eps_small": 1e-4, "chain_small": 2e-4, "wav_small": 2.5e-3, "repeat": 5e-6},
-    "bf16": {"eps_bench": 1.5e-2, "tap_bench": 1.5e-2, "lat_50": 2.5e-2, "wav_50": 0.15, "chain_250": 2.5e-2,
-             "lat_200": 2.5e-2, "wav_200": 0.15, "eps_small": 3e-2, "chain_small": 1e-2, "wav_small": 0.1, "repeat": 1e-2},
+MEASURED = {   # worst value seen over items / timesteps / layouts on MI355X, round 2 (gpurun_out/drift.json, rounded up)
+    "f32": {"eps_bench": 2.3e-6, "tap_bench": 3.2e-6, "lat_50": 1.6e-6, "wav_50": 1.0e-6, "chain_250": 1.8e-6, "lat_200": 2.8e-6,
+            "wav_200": 1.2e-6, "eps_small": 2.2e-6, "chain_small": 8e-7, "wav_small": 1.2e-6, "repeat": 2e-7},
+    "bf16": {"eps_bench": 1.13e-2, "tap_bench": 1.39e-2, "lat_50": 1.2e-3, "wav_50": 2.4e-4, "chain_250": 8.3e-3, "lat_200": 4.9e-3,
+             "wav_200": 8.8e-4, "eps_small": 2.12e-2, "chain_small": 3.1e-4, "wav_small": 1.3e-4, "repeat": 1.8e-4},
 }
-TOL = {dt: {k: 2.0 * v for k, v in d.items()} for dt, d in MEASURED.items()}
+# f32: 2x a 1e-6-class number would trip on a different reduction order; the floor keeps the f32 bar at 1e-5
+_FLOOR = {"f32": 1e-5, "bf16": 0.0}
+TOL = {dt: {k: max(2.0 * v, _FLOOR[dt]) for k, v in d.items()} for dt, d in MEASURED.items()}
 
 _RECORD = os.environ.get("LDC_RECORD_DRIFT")
 

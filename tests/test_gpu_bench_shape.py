@@ -280,3 +280,34 @@ def test_plan_cache_is_bounded():
     # 12 more shapes did not leave 12 more workspaces behind (each is tens of MB at these sizes)
     assert free0 - torch.cuda.mem_get_info()[0] < (1 << 30)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------- strip-form ResnetBlock kernels
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["r84", "r8"])
+def test_strip_form_resnet_blocks_small_widths(tag, dtype):
+    """conv_strip.inc forced on (LDC_STRIP=2) at dim 32 (groups of 4/8/16 channels packed into 32-wide strips, ragged
+    L = 160/320 row tiles, concatenated inputs, res_conv and identity residuals): eps and taps against the reference's
+    golden vectors.  (At the bench width the default engine takes this path by itself: test_bench_grid_* cover it.)"""
+    import os
+    g = load_golden("ladiff_" + tag)
+    mc, u, _ = CASES[tag]
+    os.environ["LDC_STRIP"] = "2"
+    try:
+        e = Engine(mc, u, COND_CFG, dtype=dtype)
+    finally:
+        del os.environ["LDC_STRIP"]
+    e.load_state_dict(L.MODEL_MAIN, main_sd_np(tag))
+    e.load_state_dict(L.MODEL_COND, cond_sd_np())
+    e.finalize(strict=True)
+    cond, x = cu(g["cond"]), cu(g["x"])
+    for t in (0, 37):
+        check(dtype, "eps_small", rel(e.unet_forward(x, t, cond).cpu().numpy(), g[f"eps_t{t}"]), (tag, t, "strip"))
+    taps = {}
+    O.unet_forward(synth.to_torch(main_sd_np(tag)), u, T(g["x"]), torch.full((2,), 37, dtype=torch.long), T(g["cond"]), taps=taps)
+    for name in ["down0", "down4", "mid", "up0", "up4"]:
+        check(dtype, "eps_small", rel(e.debug_tap(name, taps[name].shape).cpu().numpy(), taps[name].numpy()), (tag, name, "strip"))
+    n = int(g["meta"][2])
+    lat = e.denoise(cu(g["img0"]), cond, n, cu(g["noises"]))
+    check(dtype, "chain_small", rel(lat.cpu().numpy(), g["latents"]), (tag, "strip"))
+    e.close()

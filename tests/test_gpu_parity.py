@@ -311,7 +311,9 @@ def test_p_sample_loop_and_infilling_drivers():
     same = m.diffusion.infilling(cu(g["fill_infill0"]), cond, midway_t=midway_t, lam=0.8, img=cu(g["fill_img0"]), noises=fill_noise.cuda())
     assert torch.equal(same, img) or rel(same.cpu().numpy(), img.cpu().numpy()) < 1e-5
     # device-side start images and draws
+    e.reseed(5)
     a = e.infilling(cu(g["fill_infill0"]), cond, 4)[0]
+    e.reseed(5)
     b = e.infilling(cu(g["fill_infill0"]), cond, 4)[0]
     assert torch.isfinite(a).all() and rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
     m.diffusion.seq_length = g["loop_img0"].shape[2]
