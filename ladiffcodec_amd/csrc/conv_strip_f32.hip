@@ -19,10 +19,10 @@ bool conv_strip_eligible(int dt, int N, int groups, int L, int cin, int cres) {
   if (groups <= 0 || N % groups || L < 1) return false;
   const int che = kRowBytes / (int)dt_size(dt);
   if (cin % che || cres % che) return false;
-  int bn, wr, rtw, ctw, nch, plane;
+  int bn, wr, rtw, ctw, nch, plane, nbuf;
   size_t lds;
   const int g = cres ? gcd_int(cin / che, cres / che) : cin / che;
-  return strip_geom_f32(dt, N, N / groups, L, g, &bn, &wr, &rtw, &ctw, &nch, &plane, &lds);
+  return strip_geom_f32(dt, N, N / groups, L, g, &bn, &wr, &rtw, &ctw, &nch, &plane, &nbuf, &lds);
 }
 
 hipError_t launch_conv_strip(const StripCall& sc, hipStream_t s) {

@@ -241,7 +241,7 @@ struct ldc_ctx {
   int fuse_kmax = 1;
   int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
   int fuse_gn_stats = 1;
-  int strip_mode = 1;           // LDC_STRIP: 0 never | 1 when the grid fills the chip (default) | 2 whenever eligible
+  int strip_mode = 0;           // LDC_STRIP: 0 never (default: measured 5 % slower end to end) | 1 when the grid fills the chip | 2 whenever eligible
   int strip_min_wgs = 96;       // LDC_STRIP_MIN: workgroups (items x strips) from which mode 1 picks the strip form
   // knobs read from the environment once, at ldc_create (per context, not process-global)
   ConvTune tune;
@@ -938,7 +938,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->tune.sk_u3 = env_int("LDC_SK_U3", c->tune.sk_u3);
   c->tune.m_fastest = env_int("LDC_CONV_MFAST", c->tune.m_fastest);
   c->tune.debug = env_int("LDC_CONV_DEBUG", 0);
-  c->strip_mode = env_int("LDC_STRIP", 1);
+  c->strip_mode = env_int("LDC_STRIP", 0);
   c->strip_min_wgs = env_int("LDC_STRIP_MIN", 96);
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
   c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
@@ -2559,6 +2559,12 @@ extern "C" int ldc_strip_microbench(ldc_ctx* c, int dtype, int B, int L, int cin
     sc.r1_rs = sc.x1_rs; sc.r1_cs = 64; sc.r2_rs = sc.x2_rs; sc.r2_cs = 64;
   }
   sc.y = y; sc.y_rs = (long long)cout * es; sc.y_cs = 64; sc.B = B; sc.L = L;
+  sc.debug = getenv("LDC_STRIP_DEBUG") ? atoi(getenv("LDC_STRIP_DEBUG")) : 0;
+  if (getenv("LDC_STRIP_PLANES")) {   // plane-major operands [chunk][row][64 B] (timing experiment: contents do not matter)
+    sc.x1_rs = 64; sc.x1_cs = (long long)B * L * 64; sc.x2_rs = 64; sc.x2_cs = (long long)B * L * 64;
+    sc.r1_rs = 64; sc.r1_cs = sc.x1_cs; sc.r2_rs = 64; sc.r2_cs = sc.x1_cs;
+    sc.y_rs = 64; sc.y_cs = (long long)B * L * 64;
+  }
   hipStream_t s = c->own_stream;
   for (int i = 0; i < 3; ++i) HIPCHK(launch_conv_strip(sc, s));
   hipEvent_t e0, e1;
@@ -2571,6 +2577,28 @@ extern "C" int ldc_strip_microbench(ldc_ctx* c, int dtype, int B, int L, int cin
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *ms_per_launch = ms / iters;
+  if (getenv("LDC_CONV_STAMPS")) {
+    const int nblk = B * 64;
+    void* st = nullptr;
+    LDCCHK(keep.alloc(&st, (size_t)nblk * 8 * 8));
+    HIPCHK(hipMemset(st, 0, (size_t)nblk * 8 * 8));
+    sc.stamps = (unsigned long long*)st;
+    HIPCHK(launch_conv_strip(sc, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h((size_t)nblk * 8);
+    HIPCHK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+    double d[5] = {0, 0, 0, 0, 0};
+    unsigned long long tmin = ~0ull, tmax = 0;
+    int n = 0;
+    for (int b = 0; b < nblk; ++b) {
+      if (!h[8 * b + 5]) continue;
+      for (int k = 0; k < 5; ++k) d[k] += (double)(h[8 * b + k + 1] - h[8 * b + k]);
+      tmin = std::min(tmin, h[8 * b]); tmax = std::max(tmax, h[8 * b + 5]);
+      ++n;
+    }
+    if (n) fprintf(stderr, "  stamps (s_memtime ticks per workgroup, %d WGs): prologue %.0f  conv loop %.0f  GN+SiLU %.0f  res loop %.0f  store %.0f | first start -> last end %.0f\n",
+                   n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, (double)(tmax - tmin));
+  }
   return LDC_OK;
 }
 

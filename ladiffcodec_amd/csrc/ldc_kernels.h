@@ -106,6 +106,8 @@ struct StripCall {
   void* y = nullptr;
   long long y_rs = 0, y_cs = 0;
   int B = 0, L = 0;
+  int debug = 0;                      // tuning aid, see conv_strip.inc
+  unsigned long long* stamps = nullptr;
 };
 // cin: channels of the k=3 conv's input, cres: of the res_conv's (0: none)
 bool conv_strip_eligible(int dt, int N, int groups, int L, int cin, int cres);
