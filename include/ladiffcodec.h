@@ -171,6 +171,29 @@ int ldc_output_normalise(ldc_ctx* ctx, float* wav_inout, int B, int T, int per_i
 int ldc_decode(ldc_ctx* ctx, const float* wav, int B, int T, int n_steps, const float* noise, int per_item,
                float* wav_out, float* latents_out, float* cond_out, int64_t* codes_out, void* stream);
 
+/* bit-stream layer: the on-wire format between ldc_rvq_encode and ldc_rvq_decode -- SURVEY.md section 8(f) row 3 ------------
+ * Every batch item is an independent stream.  All results are bit-exact with the reference classes.  These calls need no
+ * weights (any context of the device).
+ * BitPacker / BitUnpacker (srcs/encodec/binary.py:55-118) over a frame's codes in compress.py's push order
+ * (srcs/encodec/compress.py:74-84: for t: for k: codes[k][t]); `bits` per code (10 for the 1024-entry codebooks).
+ * codes [n_q,B,F] int64 (device) <-> out [B][out_stride] bytes (device), ldc_packed_bytes() of them used per item. */
+int64_t ldc_packed_bytes(int n_q, int F, int bits);
+int ldc_pack_codes(ldc_ctx* ctx, const int64_t* codes, int n_q, int B, int F, int bits, uint8_t* out, int64_t out_stride, void* stream);
+int ldc_unpack_codes(ldc_ctx* ctx, const uint8_t* in, int64_t in_stride, int n_q, int B, int F, int bits, int64_t* codes_out,
+                     void* stream);
+/* build_stable_quantized_cdf (srcs/quantization/ac.py:18-53): pdf [rows][card] float32 -> cdf [rows][card] int32. */
+int ldc_ac_build_cdf(ldc_ctx* ctx, const float* pdf, int rows, int card, int total_range_bits, float roundoff, int min_range,
+                     int32_t* cdf_out, void* stream);
+/* ArithmeticCoder.push ... flush (ac.py:131-174) of S symbols per stream.  symbols [B][S] int32.  n_static == 0: cdf is
+ * [B][S][card] (a table per step, as an LM would provide, compress.py:79-82); n_static > 0: cdf is [n_static][card] and
+ * symbol s uses table s % n_static (one static table per codebook).  nbytes_out[b] = bytes written, -1 = out_stride too
+ * small or a symbol outside its table. */
+int ldc_ac_encode(ldc_ctx* ctx, const int32_t* symbols, const int32_t* cdf, int B, int S, int card, int n_static, int total_range_bits,
+                  uint8_t* out, int64_t out_stride, int64_t* nbytes_out, void* stream);
+/* ArithmeticDecoder.pull x S (ac.py:218-260).  status_out[b]: 0 ok, 1 stream exhausted (pull returned None), 2 search failed. */
+int ldc_ac_decode(ldc_ctx* ctx, const uint8_t* in, int64_t in_stride, const int64_t* nbytes, const int32_t* cdf, int B, int S, int card,
+                  int n_static, int total_range_bits, int32_t* symbols_out, int32_t* status_out, void* stream);
+
 /* L1 primitives (reference srcs/modules/conv.py, lstm.py), exposed for the parity tests ---------- */
 /* SConv1d.forward (conv.py:217-232), reflect padding.  w [Cout,Cin,k] (already weight-norm folded),
  * all HOST float32; x/y DEVICE [B,Cin,L] / [B,Cout,Lout].  pre_elu applies ELU to the input. */
@@ -193,6 +216,10 @@ int ldc_unet_step_cost(ldc_ctx* ctx, int B, int L, double* flops, double* bytes)
 /* Timing of the dominant kernel class, measured with hipEvents on the launch stream when enabled.
  * ldc_profile_enable(ctx, 1) makes ldc_denoise bracket every conv-GEMM launch (eager, no graph). */
 int ldc_profile_enable(ldc_ctx* ctx, int on);
+/* Device-side timeline of the timed (graph-replayed, multi-stream) mode: every step of every batch part stamps a 100 MHz
+ * clock at its first and last kernel.  ldc_timeline_read: ticks[2j], ticks[2j+1] = begin / end of step j of `part`. */
+int ldc_timeline_enable(ldc_ctx* ctx, int on);
+int ldc_timeline_read(ldc_ctx* ctx, int part, int n, uint64_t* ticks);
 /* Tuning aid: times `iters` launches of one conv-GEMM (random weights/inputs) of the given shape with
  * hipEvents on the context's stream; dtype LDC_F32 | LDC_BF16; ups = 1 folds nearest x2 upsampling. */
 /* Tuning aid: times the GroupNorm-apply kernel on [B,L,C] (random data, fixed statistics). */

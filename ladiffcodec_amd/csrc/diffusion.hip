@@ -321,7 +321,10 @@ hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const fl
   return hipGetLastError();
 }
 
-__global__ void step_advance_kernel(int* st) {
+// tl (optional): device-side timeline of the timed (graph-replayed, multi-stream) mode: constant-rate clock (100 MHz,
+// s_memrealtime) at the begin and the end of every step of this batch part, slot = the step's iteration index
+__global__ void step_advance_kernel(int* st, unsigned long long* tl) {
+  if (tl) tl[2 * (st[1] & 2047) + 1] = wall_clock64();
   st[0] -= 1;
   st[1] += 1;
 }
@@ -331,16 +334,18 @@ __global__ void step_set_kernel(int* st, int t, int j, unsigned key_lo, unsigned
   st[2] = (int)key_lo;
   st[3] = (int)key_hi;
 }
-__global__ __launch_bounds__(256) void step_begin_kernel(const float* table, int stride, const int* st, float* cur) {
+__global__ __launch_bounds__(256) void step_begin_kernel(const float* table, int stride, const int* st, float* cur,
+                                                         unsigned long long* tl) {
+  if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[2 * (st[1] & 2047)] = wall_clock64();
   const float* row = table + (size_t)st[0] * stride;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < stride; i += gridDim.x * 256) cur[i] = row[i];
 }
-hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, hipStream_t s) {
-  hipLaunchKernelGGL(step_begin_kernel, dim3(std::max(1, std::min(64, (stride + 255) / 256))), dim3(256), 0, s, table, stride, st, cur);
+hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, unsigned long long* tl, hipStream_t s) {
+  hipLaunchKernelGGL(step_begin_kernel, dim3(std::max(1, std::min(64, (stride + 255) / 256))), dim3(256), 0, s, table, stride, st, cur, tl);
   return hipGetLastError();
 }
-hipError_t launch_step_advance(int* st, hipStream_t s) {
-  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, st);
+hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s) {
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, st, tl);
   return hipGetLastError();
 }
 hipError_t launch_step_set(int* st, int t, int j, uint64_t noise_key, hipStream_t s) {

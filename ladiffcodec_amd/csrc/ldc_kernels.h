@@ -178,10 +178,10 @@ hipError_t launch_scale_by_maxabs(int dt, void* x, int B, int64_t n_per_item, co
                                   float eps, hipStream_t s);
 hipError_t launch_scale_copy(int dt, const void* x, void* y, int B, int64_t n_per_item, const float* maxabs, float eps,
                              hipStream_t s);
-hipError_t launch_step_advance(int* st, hipStream_t s);      // t -= 1, j += 1
+hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s);      // t -= 1, j += 1 (tl: timeline slot or null)
 // cur[0..stride) = table[st[0]][0..stride): the current timestep's scale/shift row, so that consumers need no
 // dependent load through the step counter
-hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, hipStream_t s);
+hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, unsigned long long* tl, hipStream_t s);
 hipError_t launch_step_set(int* st, int t, int j, uint64_t noise_key, hipStream_t s);
 // output normalisation (sample.py:133-134); ws: double [B][2] + float [B] zeroed by the launcher
 hipError_t launch_output_normalise(float* x, int B, int64_t n_per_item, int per_item, void* ws, hipStream_t s);
@@ -217,5 +217,18 @@ hipError_t launch_rvq(const float* z_rows, int rows, int D, const float* codeboo
 hipError_t launch_rvq_decode(const int64_t* codes, int rows, int D, const float* codebooks, int bins, int n_q,
                              float* quantized_rows, hipStream_t s);
 hipError_t launch_sqnorm_rows(const float* x, int rows, int D, float* out, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// bitstream.hip : index packing + range coder (bit-exact with srcs/encodec/binary.py, srcs/quantization/ac.py)
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_pack_codes(const int64_t* codes, int n_q, int B, int F, int bits, uint8_t* out, int64_t out_stride, hipStream_t s);
+hipError_t launch_unpack_codes(const uint8_t* in, int64_t in_stride, int n_q, int B, int F, int bits, int64_t* codes, hipStream_t s);
+hipError_t launch_build_cdf(const float* pdf, int rows, int card, int total_range_bits, float roundoff, int min_range, int* cdf,
+                            hipStream_t s);
+// mode 0: cdf table per (stream, step) [B*S][card]; mode 1: `period` static tables, symbol s uses table s % period
+hipError_t launch_ac_encode(const int* symbols, const int* cdf, int B, int S, int card, int mode, int period, int total_range_bits,
+                            uint8_t* out, int64_t out_stride, int64_t cap, int64_t* nbytes, hipStream_t s);
+hipError_t launch_ac_decode(const uint8_t* in, int64_t in_stride, const int64_t* nbytes, const int* cdf, int B, int S, int card, int mode,
+                            int period, int total_range_bits, int* symbols, int* status, hipStream_t s);
 
 }  // namespace ldc

@@ -22,7 +22,8 @@ EXPORTS = [
     "ldc_seanet_encode", "ldc_seanet_decode", "ldc_rvq_encode", "ldc_rvq_decode", "ldc_get_cond",
     "ldc_cond_upsample", "ldc_unet_forward", "ldc_p_sample", "ldc_denoise", "ldc_p_sample_loop", "ldc_infilling", "ldc_output_normalise", "ldc_decode",
     "ldc_sconv1d", "ldc_sconvtr1d", "ldc_slstm", "ldc_unet_debug_tap", "ldc_unet_step_cost", "ldc_profile_enable",
-    "ldc_profile_read", "ldc_profile_read_classes", "ldc_conv_microbench", "ldc_gn_microbench", "ldc_strip_microbench",
+    "ldc_profile_read", "ldc_profile_read_classes", "ldc_conv_microbench", "ldc_gn_microbench", "ldc_strip_microbench", "ldc_timeline_enable", "ldc_timeline_read", "ldc_packed_bytes", "ldc_pack_codes", "ldc_unpack_codes",
+    "ldc_ac_build_cdf", "ldc_ac_encode", "ldc_ac_decode",
 ]
 
 
@@ -102,10 +103,20 @@ def load() -> C.CDLL:
     lib.ldc_profile_read_classes.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ldc_conv_microbench.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     lib.ldc_strip_microbench.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
+    lib.ldc_timeline_enable.argtypes = [vp, i32]
+    lib.ldc_timeline_read.argtypes = [vp, i32, i32, C.POINTER(C.c_uint64)]
+    lib.ldc_packed_bytes.argtypes = [i32, i32, i32]
+    lib.ldc_pack_codes.argtypes = [vp, vp, i32, i32, i32, i32, vp, C.c_int64, vp]
+    lib.ldc_unpack_codes.argtypes = [vp, vp, C.c_int64, i32, i32, i32, i32, vp, vp]
+    lib.ldc_ac_build_cdf.argtypes = [vp, vp, i32, i32, i32, C.c_float, i32, vp, vp]
+    lib.ldc_ac_encode.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, C.c_int64, vp, vp]
+    lib.ldc_ac_decode.argtypes = [vp, vp, C.c_int64, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.ldc_gn_microbench.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("ldc_last_error", "ldc_version"):
+        if name == "ldc_packed_bytes":
+            fn.restype = C.c_int64
+        elif name not in ("ldc_last_error", "ldc_version"):
             fn.restype = C.c_int
     _lib = lib
     return lib

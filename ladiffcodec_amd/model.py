@@ -285,6 +285,20 @@ class Engine:
         L.check(self.lib.ldc_unet_step_cost(self._ctx, B, Lz, C.byref(fl), C.byref(by)))
         return fl.value, by.value
 
+    def timeline(self, n_steps: int, parts: int = 2):
+        """Device-side timeline of the last sampler call (after timeline_enable(True)): per batch part an array
+        [n_steps, 2] of begin / end times in microseconds relative to the earliest stamp."""
+        out = []
+        for k in range(parts):
+            buf = (C.c_uint64 * (2 * n_steps))()
+            L.check(self.lib.ldc_timeline_read(self._ctx, k, n_steps, buf))
+            out.append(np.array(buf, dtype=np.float64).reshape(n_steps, 2))
+        t0 = min(float(a[a > 0].min()) for a in out if (a > 0).any())
+        return [(a - t0) / 100.0 for a in out]      # 100 MHz ticks -> us
+
+    def timeline_enable(self, on: bool):
+        L.check(self.lib.ldc_timeline_enable(self._ctx, int(on)))
+
     def profile(self, on: bool):
         L.check(self.lib.ldc_profile_enable(self._ctx, int(on)))
 
