@@ -27,7 +27,7 @@ from ladiffcodec_amd import lib as L, parallel, spec, synth  # noqa: E402
 from ladiffcodec_amd.spec import CodecConfig, UnetConfig  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 2500.0}   # fp8 WEIGHTS are expanded to bf16 in registers: the MFMA is the bf16 one     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def log(msg):
@@ -90,19 +90,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c8"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c8", "c5"],
                     help="c2 = BASELINE configs[1] (the metric's config: 3 kbps, enc_ratios 8 4, 50 steps); c3 = configs[2] per GPU "
                          "(1.5 kbps condition, 200 steps); c8 = the released checkpoints' layout (enc_ratios 8, latent L = 4800, "
-                         "upsampling 5 4 2; README.md:30,35), 3 kbps, 50 steps")
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+                         "upsampling 5 4 2; README.md:30,35), 3 kbps, 50 steps; c5 = configs[4]: one 30 s recording as 13 chunks of "
+                         "2.4 s (batch items), fp8 UNet weights")
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (0 = the config's own: 32; c5: 13)")
     ap.add_argument("--seconds", type=float, default=2.4)
     ap.add_argument("--denoise-steps", type=int, default=0, help="0 = the config's own (50; c3: 200)")
     ap.add_argument("--diff-dims", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="", choices=["", "bf16", "f32", "fp8"], help="UNet dtype (default bf16; c5: fp8 weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the CPU-oracle sample (SURVEY 8d: B = 4)")
     args = ap.parse_args()
+    args.batch = args.batch or (13 if args.config == "c5" else 32)
+    args.dtype = args.dtype or ("fp8" if args.config == "c5" else "bf16")
 
     # stdout carries exactly ONE line, the JSON result: RCCL prints a banner (version / hostname / library path) on
     # file descriptor 1 when the process group comes up, so route fd 1 to stderr until the result is written
@@ -179,7 +182,7 @@ def main():
         "metric": f"audio-sec decoded / wall-sec, 16kHz {kbps:g}kbps {N}-step DDPM",
         "value": audio_s / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio)",
+        "dtype": "bf16 activations x fp8 (e4m3) weights" if args.dtype == "fp8" else args.dtype, "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio)",
         "config": {"workload": f"LaDiffCodec {kbps:g} kbps, diff_dims={args.diff_dims}, enc_ratios {' '.join(map(str, mc.enc_ratios))}, "
                                f"{N}-step DDPM, batch={B}x{T / 16000.0:.1f} s utterances per GPU", "name": args.config,
                    "global_batch": world * B, "latent_len": T // mc.hop_length, "denoise_steps": N,

@@ -51,6 +51,8 @@ extern "C" {
 
 #define LDC_F32 0
 #define LDC_BF16 1
+#define LDC_BF16_W8 2   /* bf16 activations, UNet conv weights stored as OCP fp8 e4m3 + one fp32 scale per output channel
+                          (BASELINE config 5); codec stages stay fp32 */
 
 /* which of the two DiffAudioRep instances a call addresses (srcs/sample.py:56 and :63) */
 #define LDC_MODEL_MAIN 0   /* --model_path      : autoencoder [enc_ratios] + Unet1D + diffusion */
@@ -62,7 +64,7 @@ typedef struct ldc_ctx ldc_ctx;
 
 /* Mirrors the argparse flags of srcs/sample.py:141-201 that shape the two models. */
 typedef struct ldc_config {
-  int32_t compute_dtype;                 /* LDC_F32 | LDC_BF16 */
+  int32_t compute_dtype;                 /* LDC_F32 | LDC_BF16 | LDC_BF16_W8 */
   /* shared SEANet hyper-parameters (model.py:52-55) */
   int32_t rep_dims;                      /* --rep_dims            (128) */
   int32_t n_filters;                     /* --n_filters           (32)  */
@@ -107,6 +109,8 @@ int ldc_destroy(ldc_ctx* ctx);
  * draws advances the counter, as every torch.randn_like of the reference (ddpm_loss.py:249) advances the global
  * generator.  ldc_reseed sets the seed and rewinds the counter (the counterpart of torch.manual_seed). */
 int ldc_reseed(ldc_ctx* ctx, uint64_t seed);
+/* The fp8 weight packer's rounding (OCP e4m3fn, nearest even, saturating at 448), host-side: codes and/or decoded values. */
+void ldc_quantize_e4m3(const float* in, int64_t n, uint8_t* out_codes, float* out_values);
 
 /* load_model(model, path, strict) -- srcs/utils.py:98-108.  One call per state-dict entry (after
  * the caller stripped any `module.` prefix).  `data` is a host float32 buffer of prod(shape)

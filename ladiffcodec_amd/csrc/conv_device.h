@@ -37,6 +37,8 @@ struct ConvKArgs {
   unsigned* sk_count;
   long long sk_part_cap;   // floats
   int sk_count_cap;        // tiles
+  int w8;                  // weights are fp8 (generic kernel expands them while staging)
+  const float* wscale;     // fp8 weights: per-output-channel scale applied to the accumulator before the bias (else null)
   const ConvTune* tune;    // host-only (never read on the device)
   long long* sk_need;      // host-only: dry run
 };
@@ -130,6 +132,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvKArgs& a, f32x16 (&acc)
     const int col = col0 + j * 32;
     const bool col_ok = col < a.n;
     const float bv = (a.bias && col_ok) ? a.bias[col] : 0.0f;
+    const float sc = (a.wscale && col_ok) ? a.wscale[col] : 1.0f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int mb = mrow0 + i * 32;
@@ -144,7 +147,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvKArgs& a, f32x16 (&acc)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mb + (r & 3) + 8 * (r >> 2);
-        float v = acc[i][j][r] + bv;
+        float v = fmaf(acc[i][j][r], sc, bv);
         if (RES) v += rv[r];
         if (ACT) v = act_apply(v, a.post_act);
         if (col_ok && m < M) store_out<T>(a.y, (size_t)m * a.y_ld + col, v);
@@ -173,6 +176,7 @@ __device__ __forceinline__ void epilogue_colmax(const ConvKArgs& a, f32x16 (&acc
     const int col = col0 + j * 32;
     const bool in = col >= a.colmax_lo && col < a.colmax_hi;     // uniform over the 32 lanes of a sub-tile
     const float bv = (a.bias && col < a.n) ? a.bias[col] : 0.0f;
+    const float sc = (a.wscale && col < a.n) ? a.wscale[col] : 1.0f;
     for (int bb = b_first; bb <= b_last; ++bb) {
       const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
       float mx = -INFINITY;
@@ -182,7 +186,7 @@ __device__ __forceinline__ void epilogue_colmax(const ConvKArgs& a, f32x16 (&acc
         for (int r = 0; r < 16; ++r) {
           const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
           if (m >= lo && m < hi) {
-            float v = acc[i][j][r] + bv;
+            float v = fmaf(acc[i][j][r], sc, bv);
             if (sizeof(T) == 2) v = bf16_to_f32(f32_to_bf16(v));
             mx = fmaxf(mx, v);
           }
@@ -211,6 +215,7 @@ __device__ __forceinline__ void epilogue_gn_stats(const ConvKArgs& a, f32x16 (&a
     const int col = col0 + j * 32;
     const bool col_ok = col < a.n;
     const float bv = (a.bias && col_ok) ? a.bias[col] : 0.0f;
+    const float sc = (a.wscale && col_ok) ? a.wscale[col] : 1.0f;
     const int g = col_ok ? col / cpg : 0;
     for (int bb = b_first; bb <= b_last; ++bb) {
       const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
@@ -222,7 +227,7 @@ __device__ __forceinline__ void epilogue_gn_stats(const ConvKArgs& a, f32x16 (&a
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = acc[i][j][r] + bv;
+              const float v = fmaf(acc[i][j][r], sc, bv);
               s += v;
               ss = fmaf(v, v, ss);
             }
@@ -234,7 +239,7 @@ __device__ __forceinline__ void epilogue_gn_stats(const ConvKArgs& a, f32x16 (&a
           for (int r = 0; r < 16; ++r) {
             const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
             if (col_ok && m >= lo && m < hi) {
-              const float v = acc[i][j][r] + bv;
+              const float v = fmaf(acc[i][j][r], sc, bv);
               s += v;
               ss += v * v;
             }
@@ -288,6 +293,7 @@ __device__ __forceinline__ void epilogue_rows(const ConvKArgs& a, f32x16 (&acc)[
     const int col = col_wave0 + j * 32 + (lane & 31);
     const bool col_ok = col < a.n;
     const float bv = (a.bias && col_ok) ? a.bias[col] : 0.0f;
+    const float sc = (a.wscale && col_ok) ? a.wscale[col] : 1.0f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float rv[16];
@@ -301,7 +307,7 @@ __device__ __forceinline__ void epilogue_rows(const ConvKArgs& a, f32x16 (&acc)[
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = acc[i][j][r] + bv;
+        float v = fmaf(acc[i][j][r], sc, bv);
         if (RES) v += rv[r];
         if (ACT) v = act_apply(v, a.post_act);
         store_out<T>(wave_lds, (size_t)(row * PITCH) / sizeof(T) + j * 32 + (lane & 31), v);
@@ -339,5 +345,6 @@ __device__ __forceinline__ void epilogue_rows_dispatch(const ConvKArgs& a, f32x1
 extern unsigned long long* g_conv_stamps;   // tuning aid, set by ldc_conv_microbench when LDC_CONV_STAMPS is on
 bool conv_fast_eligible(const ConvLayer& ly);
 hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, hipStream_t s, bool* launched);
+hipError_t launch_conv_fast_bf16w8(const ConvLayer& ly, const ConvKArgs& a_in, int M, int span_rows, hipStream_t s, bool* launched);
 
 }  // namespace ldc

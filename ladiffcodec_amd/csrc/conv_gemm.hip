@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <math.h>
+
 #include "conv_device.h"
 
 namespace ldc {
@@ -53,6 +55,15 @@ __device__ __forceinline__ uint4 elu16<__bf16>(uint4 v) {
     u[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
   }
   return v;
+}
+
+__device__ __forceinline__ uint4 expand_fp8x8_generic(const uint2& v) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, false);
+  const f32x2 b = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, false);
+  const f32x2 d = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, true);
+  return make_uint4(hw_bf16x2(a[0], a[1]), hw_bf16x2(b[0], b[1]), hw_bf16x2(c[0], c[1]), hw_bf16x2(d[0], d[1]));
 }
 
 template <typename T, int WM, int WN, int TM, int TN>
@@ -142,7 +153,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
             const int idx = min(base + q * NT + tid, total - 1);
             const int t = idx / (BN * 4);
             const int rem = idx - t * (BN * 4);
-            v[q] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)t * a.n_pad + n0 + (rem >> 2)) * kRowBytes + (rem & 3) * 16);
+            if (a.w8) {   // fp8 row of 32 B: logical 16-byte slot `rem & 3` = 8 values = the (permuted) 8-byte slot, expanded to bf16
+              const int nn = n0 + (rem >> 2);
+              const uint2 raw = *reinterpret_cast<const uint2*>(a.w + (((size_t)(c * a.taps + tg0 + t) * a.n_pad + nn) * 32) + (((rem & 3) ^ ((nn >> 3) & 3)) << 3));
+              v[q] = expand_fp8x8_generic(raw);
+            } else {
+              v[q] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)t * a.n_pad + n0 + (rem >> 2)) * kRowBytes + (rem & 3) * 16);
+            }
           }
 #pragma unroll
           for (int q = 0; q < B_MAX; ++q) {
@@ -224,7 +241,40 @@ int conv_pick_bn(int n) {
 size_t conv_packed_weight_bytes(const ConvLayer& ly) {
   const int bke = kRowBytes / (int)dt_size(ly.dt);
   const int nchunks = (ly.cin1 + ly.cin2) / bke;
-  return (size_t)nchunks * ly.taps * ly.n_pad * kRowBytes;
+  return (size_t)nchunks * ly.taps * ly.n_pad * (ly.w8 ? 32 : kRowBytes);
+}
+
+// OCP fp8 e4m3fn (1-4-3, bias 7, no infinities, max 448): round to nearest even, saturate
+uint8_t host_f32_to_e4m3(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+  float a = fabsf(f);
+  if (!(a == a)) return (uint8_t)(sign | 0x7f);          // NaN
+  if (a >= 448.0f) return (uint8_t)(sign | 0x7e);        // saturate (448 = 0x7e)
+  if (a <= 0.0009765625f) return sign;                   // <= 2^-10 = half of the smallest subnormal 2^-9: rounds to zero (tie -> even)
+  int e;
+  const float m = frexpf(a, &e);                          // a = m * 2^e, m in [0.5, 1)
+  int exp = e - 1;                                        // a = (2m) * 2^exp, 2m in [1, 2)
+  if (exp < -6) {                                         // subnormal: multiples of 2^-9
+    const float q = a * 512.0f;                           // in units of 2^-9
+    float r = nearbyintf(q);                              // default rounding mode: nearest even
+    if (r >= 8.0f) return (uint8_t)(sign | 0x08);         // rounds up into the smallest normal 2^-6
+    return (uint8_t)(sign | (uint8_t)r);
+  }
+  const float frac = (2.0f * m - 1.0f) * 8.0f;            // mantissa in eighths, [0, 8)
+  float r = nearbyintf(frac);
+  if (r >= 8.0f) { r = 0.0f; ++exp; }
+  if (exp > 8 || (exp == 8 && r > 6.0f)) return (uint8_t)(sign | 0x7e);
+  return (uint8_t)(sign | (uint8_t)((exp + 7) << 3) | (uint8_t)r);
+}
+float host_e4m3_to_f32(uint8_t v) {
+  const int sign = v & 0x80, e = (v >> 3) & 0xf, m = v & 7;
+  float a;
+  if (e == 0) a = (float)m * 0.001953125f;                // m * 2^-9
+  else if (e == 15 && m == 7) a = NAN;
+  else a = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+  return sign ? -a : a;
 }
 
 static inline uint16_t host_f32_to_bf16(float f) {
@@ -260,6 +310,29 @@ static void pack_generic(const ConvLayer& ly, void* dst, F value) {
 void pack_conv_weights(const ConvLayer& ly, const float* w, void* dst) {
   const int cin = ly.cin1 + ly.cin2, k = ly.taps;
   pack_generic(ly, dst, [&](int n, int ci, int t) { return w[((size_t)n * cin + ci) * k + t]; });
+}
+
+// fp8 image [chunk][tap][n_pad][32 B]: the four 8-byte slots of a row are stored permuted, slot ^ ((n >> 3) & 3), so that the
+// 32 lanes of a ds_read_b64 fragment read (rows n..n+31, one slot each) touch all 64 LDS banks once
+void pack_conv_weights_fp8(const ConvLayer& ly, const float* w, void* dst, float* scales) {
+  const int cin = ly.cin1 + ly.cin2, k = ly.taps, bke = 32;
+  const int nchunks = cin / bke;
+  uint8_t* out = reinterpret_cast<uint8_t*>(dst);
+  memset(out, 0, conv_packed_weight_bytes(ly));
+  for (int n = 0; n < ly.n; ++n) {
+    float amax = 0.f;
+    for (int i = 0; i < cin * k; ++i) amax = std::max(amax, fabsf(w[(size_t)n * cin * k + i]));
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    scales[n] = sc;
+    for (int c = 0; c < nchunks; ++c)
+      for (int t = 0; t < k; ++t) {
+        uint8_t* row = out + (((size_t)c * k + t) * ly.n_pad + n) * 32;
+        for (int kk = 0; kk < bke; ++kk) {
+          const int slot = kk >> 3, phys = slot ^ ((n >> 3) & 3);
+          row[phys * 8 + (kk & 7)] = host_f32_to_e4m3(w[((size_t)n * cin + c * bke + kk) * k + t] / sc);
+        }
+      }
+  }
 }
 
 void pack_convtr_weights(const ConvLayer& ly, const float* w, int cin, int cout, int stride, void* dst) {
@@ -304,6 +377,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   if (ly.tr_stride) a.colmax = nullptr;
   a.ksplit = 1; a.sk_part = c.sk_part; a.sk_count = c.sk_count; a.sk_part_cap = c.sk_part_cap; a.sk_count_cap = c.sk_count_cap;
   a.tune = c.tune; a.sk_need = c.sk_need;
+  a.wscale = ly.w8 ? ly.wscale : nullptr; a.w8 = ly.w8;
   if (c.sk_need) *c.sk_need = 0;
   if (c.gn_sum && c.gn_groups > 0 && !ly.tr_stride) {
     const int cpg = ly.n / c.gn_groups;

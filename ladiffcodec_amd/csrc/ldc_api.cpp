@@ -222,6 +222,7 @@ struct ldc_ctx {
   ldc_config cfg;
   int device = 0;
   int dt = DT_F32;              // UNet compute dtype; the codec (SEANet/LSTM/RVQ/upsampler) is always fp32
+  bool w8 = false;              // LDC_BF16_W8: UNet conv weights stored as fp8 e4m3 + per-channel scale (activations bf16)
   bool finalized = false;
   std::map<std::string, HostTensor> raw[2];
   DevMem wmem;                  // weights, tables
@@ -369,6 +370,7 @@ struct ConvSpec {
   int dt = DT_F32;
   int cin1 = 0, cin2 = 0, cout = 0, k = 1, stride = 1, dil = 1, pad_left = 0, ups = 0, pad_mode = PAD_ZERO;
   int pre_act = ACT_NONE, post_act = ACT_NONE;
+  int no_w8 = 0;               // keep this layer's weights in bf16 even in an fp8-weight context
 };
 
 static int make_conv(ldc_ctx* c, const ConvSpec& sp, const float* w_oik, const float* bias, ConvLayer* out) {
@@ -384,8 +386,15 @@ static int make_conv(ldc_ctx* c, const ConvSpec& sp, const float* w_oik, const f
   ly.taps = sp.k; ly.stride = sp.stride; ly.dil = sp.dil; ly.pad_left = sp.pad_left; ly.ups = sp.ups;
   ly.pad_mode = sp.pad_mode; ly.pre_act = sp.pre_act; ly.post_act = sp.post_act;
   ly.flops_per_row = 2.0 * (sp.cin1 + sp.cin2) * sp.k * sp.cout;
+  ly.w8 = (c->w8 && sp.dt == DT_BF16 && !sp.no_w8) ? 1 : 0;
   std::vector<char> packed(conv_packed_weight_bytes(ly));
-  pack_conv_weights(ly, w_oik, packed.data());
+  if (ly.w8) {
+    std::vector<float> scales((size_t)sp.cout);
+    pack_conv_weights_fp8(ly, w_oik, packed.data(), scales.data());
+    LDCCHK(c->wmem.upload(&ly.wscale, scales));
+  } else {
+    pack_conv_weights(ly, w_oik, packed.data());
+  }
   void* dw = nullptr;
   LDCCHK(c->wmem.alloc(&dw, packed.size()));
   HIPCHK(hipMemcpy(dw, packed.data(), packed.size(), hipMemcpyHostToDevice));
@@ -893,7 +902,8 @@ static int build_time_table(ldc_ctx* c, WeightReader& wr) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   if (!cfg || !out) return fail(LDC_E_INVALID, "null argument");
-  if (cfg->compute_dtype != LDC_F32 && cfg->compute_dtype != LDC_BF16) return fail(LDC_E_INVALID, "compute_dtype must be LDC_F32 or LDC_BF16");
+  if (cfg->compute_dtype != LDC_F32 && cfg->compute_dtype != LDC_BF16 && cfg->compute_dtype != LDC_BF16_W8)
+    return fail(LDC_E_INVALID, "compute_dtype must be LDC_F32, LDC_BF16 or LDC_BF16_W8");
   if (cfg->n_enc_ratios < 1 || cfg->n_enc_ratios > LDC_MAX_RATIOS || cfg->n_upsampling_ratios < 0 ||
       cfg->n_upsampling_ratios > LDC_MAX_RATIOS)
     return fail(LDC_E_INVALID, "bad ratio counts");
@@ -911,7 +921,8 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   std::unique_ptr<ldc_ctx> c(new ldc_ctx());
   c->cfg = *cfg;
   c->device = device;
-  c->dt = cfg->compute_dtype == LDC_BF16 ? DT_BF16 : DT_F32;
+  c->dt = cfg->compute_dtype == LDC_F32 ? DT_F32 : DT_BF16;
+  c->w8 = cfg->compute_dtype == LDC_BF16_W8;
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   for (int k = 1; k < kMaxParts; ++k) {
@@ -1014,6 +1025,15 @@ extern "C" int ldc_destroy(ldc_ctx* c) {
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return LDC_OK;
+}
+
+// OCP e4m3 quantisation exactly as the fp8 weight packer applies it (host function: testable without a GPU)
+extern "C" void ldc_quantize_e4m3(const float* in, int64_t n, uint8_t* out_codes, float* out_values) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint8_t q = host_f32_to_e4m3(in[i]);
+    if (out_codes) out_codes[i] = q;
+    if (out_values) out_values[i] = host_e4m3_to_f32(q);
+  }
 }
 
 extern "C" int ldc_reseed(ldc_ctx* c, uint64_t seed) {
@@ -1471,7 +1491,7 @@ struct PlanBuilder {
   }
   // ResnetBlock as two strip launches (conv_strip.inc): conv1+GN+scale/shift+SiLU, then conv2+GN+SiLU+res_conv/identity
   bool strip_ok(const ResnetW& r, int L) const {
-    if (c->strip_mode <= 0 || !r.s1.w || !r.s2.w || (r.has_res && !r.sres.w)) return false;
+    if (c->strip_mode <= 0 || c->w8 || !r.s1.w || !r.s2.w || (r.has_res && !r.sres.w)) return false;
     const int cin = r.cin1 + r.cin2;
     if (!conv_strip_eligible(c->dt, r.cout, c->unet.groups, L, cin, 0)) return false;
     if (!conv_strip_eligible(c->dt, r.cout, c->unet.groups, L, r.cout, r.has_res ? cin : 0)) return false;
@@ -2550,7 +2570,9 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
                                    int ups, int iters, double* ms_per_launch) {
   if (!c || !ms_per_launch || iters < 1) return fail(LDC_E_INVALID, "bad arguments");
   HIPCHK(hipSetDevice(c->device));
-  const int dt = dtype == LDC_BF16 ? DT_BF16 : DT_F32;
+  const int dt = dtype == LDC_F32 ? DT_F32 : DT_BF16;
+  const bool saved_w8 = c->w8;
+  c->w8 = dtype == LDC_BF16_W8;
   const int cin = cin1 + cin2;
   std::vector<float> w((size_t)cout * cin * k), bias(cout, 0.1f);
   unsigned seed = 12345u;
@@ -2563,6 +2585,7 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
   sp.pad_left = (k == 4 && stride == 2) ? 1 : (k - 1) / 2;
   int rc = make_conv(c, sp, w.data(), bias.data(), &ly);
   std::swap(keep.ptrs, c->wmem.ptrs);
+  c->w8 = saved_w8;
   LDCCHK(rc);
   const int L_out = ups ? 2 * L : (stride == 2 ? (L + 2 * sp.pad_left - k) / 2 + 1 : L);
   const size_t es = dt_size(dt);

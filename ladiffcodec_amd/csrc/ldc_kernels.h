@@ -34,8 +34,10 @@ struct ConvLayer {
   int taps = 1, stride = 1, dil = 1, pad_left = 0, ups = 0, pad_mode = PAD_ZERO;
   int pre_act = ACT_NONE, post_act = ACT_NONE;
   int tr_stride = 0, tr_cout = 0, tr_trim_left = 0;   // transposed-conv scatter (tr_stride = 0: plain)
-  void* w = nullptr;          // packed [chunk][tap][n_pad][64 B of K]
+  void* w = nullptr;          // packed [chunk][tap][n_pad][64 B of K]  (w8: [chunk][tap][n_pad][32 B], 8-byte slots permuted)
   float* bias = nullptr;      // [n] fp32 or null
+  int w8 = 0;                 // weights are OCP fp8 e4m3 (dt must be DT_BF16): value = fp8 * wscale[n]
+  float* wscale = nullptr;    // [n] fp32 per-output-channel scale (w8)
   double flops_per_row = 0;   // 2*K*N, for accounting
 };
 
@@ -76,6 +78,11 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
 size_t conv_packed_weight_bytes(const ConvLayer& ly);
 // host-side packers (fp32 [Cout][Cin][k] or, transposed, [Cin][Cout][k]) -> packed image in ly.dt
 void pack_conv_weights(const ConvLayer& ly, const float* w_oik, void* dst_host);
+// w8: also fills scales[n] (max |w| of the output channel / 448)
+void pack_conv_weights_fp8(const ConvLayer& ly, const float* w_oik, void* dst_host, float* scales);
+// OCP e4m3fn, round to nearest even, saturating at +-448 (host)
+uint8_t host_f32_to_e4m3(float f);
+float host_e4m3_to_f32(uint8_t v);
 void pack_convtr_weights(const ConvLayer& ly, const float* w_iok, int cin, int cout, int stride, void* dst_host);
 int conv_pick_bn(int n);
 

@@ -13,12 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libladiffcodec.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-LDC_F32, LDC_BF16 = 0, 1
+LDC_F32, LDC_BF16, LDC_BF16_W8 = 0, 1, 2
+DTYPES = {"f32": LDC_F32, "bf16": LDC_BF16, "fp8": LDC_BF16_W8}
 MODEL_MAIN, MODEL_COND = 0, 1
 MAX_RATIOS = 8
 
 EXPORTS = [
-    "ldc_last_error", "ldc_version", "ldc_create", "ldc_destroy", "ldc_reseed", "ldc_set_weight", "ldc_finalize_weights",
+    "ldc_last_error", "ldc_version", "ldc_create", "ldc_destroy", "ldc_reseed", "ldc_quantize_e4m3", "ldc_set_weight", "ldc_finalize_weights",
     "ldc_seanet_encode", "ldc_seanet_decode", "ldc_rvq_encode", "ldc_rvq_decode", "ldc_get_cond",
     "ldc_cond_upsample", "ldc_unet_forward", "ldc_p_sample", "ldc_denoise", "ldc_p_sample_loop", "ldc_infilling", "ldc_output_normalise", "ldc_decode",
     "ldc_sconv1d", "ldc_sconvtr1d", "ldc_slstm", "ldc_unet_debug_tap", "ldc_unet_step_cost", "ldc_profile_enable",
@@ -78,6 +79,7 @@ def load() -> C.CDLL:
     lib.ldc_create.argtypes = [C.POINTER(LdcConfig), i32, C.POINTER(vp)]
     lib.ldc_destroy.argtypes = [vp]
     lib.ldc_reseed.argtypes = [vp, C.c_uint64]
+    lib.ldc_quantize_e4m3.argtypes = [vp, C.c_int64, vp, vp]
     lib.ldc_set_weight.argtypes = [vp, i32, C.c_char_p, vp, i64p, i32]
     lib.ldc_finalize_weights.argtypes = [vp, i32]
     lib.ldc_seanet_encode.argtypes = [vp, i32, fp, i32, i32, fp, vp]
@@ -116,6 +118,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name == "ldc_packed_bytes":
             fn.restype = C.c_int64
+        elif name == "ldc_quantize_e4m3":
+            fn.restype = None
         elif name not in ("ldc_last_error", "ldc_version"):
             fn.restype = C.c_int
     _lib = lib

@@ -29,7 +29,8 @@ class QuantizedResult:            # reference srcs/quantization/vq.py:19-25
 
 
 class Engine:
-    """Owns the ldc_ctx.  dtype: 'bf16' (throughput) or 'f32' (exact-fp32 MFMA path, parity)."""
+    """Owns the ldc_ctx.  dtype: 'bf16' (throughput), 'f32' (exact-fp32 MFMA path, parity) or 'fp8' (bf16 activations,
+    UNet conv weights as OCP fp8 e4m3 with per-output-channel scales)."""
 
     def __init__(self, main_codec: CodecConfig, unet: UnetConfig, cond_codec: Optional[CodecConfig] = None,
                  dtype: str = "bf16", device: int = 0, noise_seed: int = 0):
@@ -41,7 +42,9 @@ class Engine:
         self.device = torch.device("cuda", device)
         self.main_codec, self.unet, self.cond_codec = main_codec, unet, cond_codec
         cfg = L.LdcConfig()
-        cfg.compute_dtype = L.LDC_BF16 if dtype == "bf16" else L.LDC_F32
+        if dtype not in L.DTYPES:
+            raise ValueError(f"dtype {dtype!r}: one of {sorted(L.DTYPES)}")
+        cfg.compute_dtype = L.DTYPES[dtype]
         self.dtype = dtype
         cfg.rep_dims, cfg.n_filters = main_codec.rep_dims, main_codec.n_filters
         cfg.n_residual_layers, cfg.lstm = main_codec.n_residual_layers, main_codec.lstm

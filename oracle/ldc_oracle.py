@@ -225,8 +225,13 @@ def get_cond(sd: SD, c: CodecConfig, wav: torch.Tensor, bandwidth: Optional[floa
 # L2 Unet1D  (reference srcs/modules/unet.py)
 # ----------------------------------------------------------------------------------------------
 
+WS_PREFOLDED = False    # tests of the fp8-weight engine hand the oracle weights that are already standardised (and quantised)
+
+
 def ws_fold(w: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """WeightStandardizedConv2d.forward weight path, unet.py:73-78 (fp32 -> eps 1e-5, biased var)."""
+    if WS_PREFOLDED:
+        return w
     flat = w.flatten(1)
     mean = flat.mean(1).view(-1, 1, 1)
     var = flat.var(1, unbiased=False).view(-1, 1, 1)

@@ -311,3 +311,62 @@ def test_strip_form_resnet_blocks_small_widths(tag, dtype):
     lat = e.denoise(cu(g["img0"]), cond, n, cu(g["noises"]))
     check(dtype, "chain_small", rel(lat.cpu().numpy(), g["latents"]), (tag, "strip"))
     e.close()
+
+
+# ------------------------------------------------------------------------------------------- fp8 UNet weights (BASELINE config 5)
+def fake_quantise_unet(sd_np, u):
+    """What the library does to every UNet conv weight in an fp8-weight context: weight-standardise the Block convs
+    (unet.py:73-78), then per output channel scale = max|w| / 448 and OCP e4m3 round-to-nearest-even; returns the state
+    dict with the dequantised values (Block convs stay standardised: the oracle runs with WS_PREFOLDED)."""
+    out = {}
+    for k, v in sd_np.items():
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        is_conv = k.startswith("diff_model.") and t.dim() == 3 and "upsampling_layers" not in k and not k.endswith(".g")
+        if is_conv:
+            if ".block1.proj.weight" in k or ".block2.proj.weight" in k:
+                t = O.ws_fold(t)
+            amax = t.abs().amax(dim=(1, 2), keepdim=True)
+            sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+            t = (t / sc).to(torch.float8_e4m3fn).float() * sc
+        out[k] = t
+    return out
+
+
+@pytest.mark.parametrize("layout", ["small", "bench"])
+def test_fp8_weight_engine(layout):
+    """dtype 'fp8': the kernels must reproduce the oracle run on the SAME quantised weights to the bf16 tolerance (kernel
+    correctness), and stay close to the unquantised model (what the quantisation costs, recorded in DESIGN.md)."""
+    if layout == "small":
+        mc, u, _ = CASES["r84"]
+        sd_np = main_sd_np("r84")
+        B, Lz, F = 2, 160, 16
+    else:
+        mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+        u = UnetConfig(dim=256, upsampling_ratios=(5, 2), unet_scale_cond=True)
+        sd_np = synth.ladiff_state_dict(mc, u, seed=1)
+        B, Lz, F = 32, 1200, 120
+    e = Engine(mc, u, COND_CFG, dtype="fp8")
+    e.load_state_dict(L.MODEL_MAIN, {k: v for k, v in sd_np.items() if not k.startswith("diffusion.model.")})
+    e.load_state_dict(L.MODEL_COND, cond_sd_np())
+    e.finalize(strict=True)
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(B, 128, Lz, generator=g) * 0.7
+    cond = torch.randn(B, 128, F, generator=g)
+    t = 211
+    got = e.unet_forward(x.cuda(), t, cond.cuda()).cpu()
+    items = (0, B - 1)
+    sd_q = fake_quantise_unet(sd_np, u)
+    sd_f = synth.to_torch(sd_np)
+    for i in items:
+        O.WS_PREFOLDED = True
+        try:
+            ref_q = O.unet_forward(sd_q, u, x[i:i + 1], torch.full((1,), t, dtype=torch.long), cond[i:i + 1])
+        finally:
+            O.WS_PREFOLDED = False
+        ref_f = O.unet_forward(sd_f, u, x[i:i + 1], torch.full((1,), t, dtype=torch.long), cond[i:i + 1])
+        check("bf16", "eps_bench" if layout == "bench" else "eps_small", rel(got[i:i + 1].numpy(), ref_q.numpy()), ("fp8 vs quantised oracle", layout, i))
+        check("fp8", "eps_vs_unquantised", rel(got[i:i + 1].numpy(), ref_f.numpy()), (layout, i))
+    # the sampler runs (graph capture included) and stays finite
+    out = e.denoise(torch.tanh(x).cuda(), cond.cuda(), 5)
+    assert torch.isfinite(out).all()
+    e.close()
