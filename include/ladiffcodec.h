@@ -198,6 +198,25 @@ int ldc_ac_encode(ldc_ctx* ctx, const int32_t* symbols, const int32_t* cdf, int 
 int ldc_ac_decode(ldc_ctx* ctx, const uint8_t* in, int64_t in_stride, const int64_t* nbytes, const int32_t* cdf, int B, int S, int card,
                   int n_static, int total_range_bits, int32_t* symbols_out, int32_t* status_out, void* stream);
 
+/* training step, first slice -- SURVEY.md section 8(f) row 2 (BASELINE config 4); fp32, reference layouts [B,C,L] --------------
+ * diffusion.q_sample(x_start, t, noise) (ddpm_loss.py:386-392); t [B] int64 (device). */
+int ldc_train_q_sample(ldc_ctx* ctx, const float* x_start, const int64_t* t, const float* noise, int B, int C, int L, float* x_t,
+                       void* stream);
+/* The objective of p_losses (ddpm_loss.py:434-438, loss_type l1): loss = mean_b(p2_loss_weight[t_b] * mean_{c,l}|out - target|);
+ * loss_out [1]; grad_out (nullable) = d loss / d model_out. */
+int ldc_train_l1_loss(ldc_ctx* ctx, const float* model_out, const float* target, const int64_t* t, int B, int C, int L, float* loss_out,
+                      float* grad_out, void* stream);
+/* Block (unet.py:137-154): y = SiLU(GroupNorm(conv_k3(x; WS(w), bias)) * (scale + 1) + shift), weights as trained (raw `w`
+ * [Cout,Cin,3]: the weight standardisation of unet.py:73-78 is part of the graph).  scale_shift [B][2*Cout] (scale | shift)
+ * or NULL.  `ws`: ldc_train_block_ws_floats() floats of device scratch that carry the saved tensors from forward to backward. */
+int64_t ldc_train_block_ws_floats(int B, int Cin, int Cout, int L, int groups);
+int ldc_train_block_forward(ldc_ctx* ctx, const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                            const float* scale_shift, int B, int Cin, int Cout, int L, int groups, float* y, float* ws, void* stream);
+/* gradients of everything: dx [B,Cin,L] (nullable), dw [Cout,Cin,3], db / dgamma / dbeta [Cout], dscale_shift [B][2*Cout]. */
+int ldc_train_block_backward(ldc_ctx* ctx, const float* dy, const float* x, const float* gamma, const float* beta,
+                             const float* scale_shift, int B, int Cin, int Cout, int L, int groups, float* ws, float* dx, float* dw,
+                             float* db, float* dgamma, float* dbeta, float* dscale_shift, void* stream);
+
 /* L1 primitives (reference srcs/modules/conv.py, lstm.py), exposed for the parity tests ---------- */
 /* SConv1d.forward (conv.py:217-232), reflect padding.  w [Cout,Cin,k] (already weight-norm folded),
  * all HOST float32; x/y DEVICE [B,Cin,L] / [B,Cout,Lout].  pre_elu applies ELU to the input. */

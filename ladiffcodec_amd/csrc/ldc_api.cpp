@@ -229,6 +229,10 @@ struct ldc_ctx {
   Codec codec[2];
   UnetW unet;
   StepTables sched{};
+  // training-side schedule buffers (q_sample, loss weights; ddpm_loss.py:150-168)
+  const float* sqrt_alphas_cumprod = nullptr;
+  const float* sqrt_one_minus_alphas_cumprod = nullptr;
+  const float* p2_loss_weight = nullptr;
   int* step_state = nullptr;    // device int[2]: t, j
   std::vector<std::unique_ptr<Plan>> plans;
   std::vector<StepGraph> graphs;
@@ -819,6 +823,9 @@ static int build_unet(ldc_ctx* c, std::string* missing) {
   c->sched.posterior_mean_coef1 = dev["posterior_mean_coef1"];
   c->sched.posterior_mean_coef2 = dev["posterior_mean_coef2"];
   c->sched.posterior_log_variance_clipped = dev["posterior_log_variance_clipped"];
+  c->sqrt_alphas_cumprod = dev["sqrt_alphas_cumprod"];
+  c->sqrt_one_minus_alphas_cumprod = dev["sqrt_one_minus_alphas_cumprod"];
+  c->p2_loss_weight = dev["p2_loss_weight"];
   if (wr.missing.empty()) LDCCHK(build_time_table(c, wr));
   *missing += wr.missing;
   return LDC_OK;
@@ -2325,6 +2332,58 @@ extern "C" int ldc_ac_decode(ldc_ctx* c, const uint8_t* in, int64_t in_stride, c
   hipStream_t s = pick_stream(c, stream);
   HIPCHK(launch_ac_decode(in, in_stride, nbytes, cdf, B, S, card, n_static ? 1 : 0, std::max(1, n_static), total_range_bits, symbols_out,
                           status_out, s));
+  return finish_stream(c, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// training step, first slice
+// ------------------------------------------------------------------------------------------------
+extern "C" int ldc_train_q_sample(ldc_ctx* c, const float* x0, const int64_t* t, const float* noise, int B, int C, int L, float* x_t,
+                                  void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!x0 || !t || !noise || !x_t || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_q_sample(x0, noise, t, c->sqrt_alphas_cumprod, c->sqrt_one_minus_alphas_cumprod, B, (int64_t)C * L, x_t, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_l1_loss(ldc_ctx* c, const float* model_out, const float* target, const int64_t* t, int B, int C, int L,
+                                 float* loss_out, float* grad_out, void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!model_out || !target || !t || !loss_out || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    void* ws = ar.alloc(l1_loss_ws_bytes(B));
+    if (!dry) HIPCHK(launch_l1_loss(model_out, target, t, c->p2_loss_weight, B, (int64_t)C * L, loss_out, grad_out, ws, s));
+    return LDC_OK;
+  }));
+  return finish_stream(c, stream);
+}
+
+extern "C" int64_t ldc_train_block_ws_floats(int B, int Cin, int Cout, int L, int groups) {
+  return (int64_t)train_block_ws_floats(B, Cin, Cout, L, groups);
+}
+
+extern "C" int ldc_train_block_forward(ldc_ctx* c, const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                                       const float* scale_shift, int B, int Cin, int Cout, int L, int groups, float* y, float* ws,
+                                       void* stream) {
+  LDCCHK(check_dev(c));
+  if (!x || !w || !gamma || !beta || !y || !ws || B < 1 || Cin < 1 || Cout < 1 || L < 1 || groups < 1 || Cout % groups)
+    return fail(LDC_E_INVALID, "bad arguments (Cout must be a multiple of groups)");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_block_forward(x, w, bias, gamma, beta, scale_shift, B, Cin, Cout, L, groups, y, ws, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_block_backward(ldc_ctx* c, const float* dy, const float* x, const float* gamma, const float* beta,
+                                        const float* scale_shift, int B, int Cin, int Cout, int L, int groups, float* ws, float* dx,
+                                        float* dw, float* db, float* dgamma, float* dbeta, float* dscale_shift, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!dy || !x || !gamma || !beta || !ws || !dw || !db || !dgamma || !dbeta || B < 1 || Cout % groups) return fail(LDC_E_INVALID, "bad arguments");
+  if (scale_shift && !dscale_shift) return fail(LDC_E_INVALID, "dscale_shift is required when scale_shift was given");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_block_backward(dy, x, gamma, beta, scale_shift, B, Cin, Cout, L, groups, ws, dx, dw, db, dgamma, dbeta,
+                                     scale_shift ? dscale_shift : nullptr, s));
   return finish_stream(c, stream);
 }
 

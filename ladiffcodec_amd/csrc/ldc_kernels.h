@@ -226,6 +226,21 @@ hipError_t launch_rvq_decode(const int64_t* codes, int rows, int D, const float*
 hipError_t launch_sqnorm_rows(const float* x, int rows, int D, float* out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
+// train.hip : first slice of the training step (q_sample, L1 objective, Block forward / backward), fp32, [B, C, L]
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, int B,
+                           int64_t n_per_item, float* out, hipStream_t s);
+size_t l1_loss_ws_bytes(int B);
+hipError_t launch_l1_loss(const float* pred, const float* target, const int64_t* t, const float* p2w, int B, int64_t n_per_item,
+                          float* loss, float* grad, void* ws, hipStream_t s);
+size_t train_block_ws_floats(int B, int Cin, int Cout, int L, int groups);
+hipError_t launch_train_block_forward(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                                      const float* ss, int B, int Cin, int Cout, int L, int groups, float* y, float* ws, hipStream_t s);
+hipError_t launch_train_block_backward(const float* dy, const float* x, const float* gamma, const float* beta, const float* ss, int B,
+                                       int Cin, int Cout, int L, int groups, float* ws, float* dx, float* dw, float* db, float* dgamma,
+                                       float* dbeta, float* dss, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
 // bitstream.hip : index packing + range coder (bit-exact with srcs/encodec/binary.py, srcs/quantization/ac.py)
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_pack_codes(const int64_t* codes, int n_q, int B, int F, int bits, uint8_t* out, int64_t out_stride, hipStream_t s);

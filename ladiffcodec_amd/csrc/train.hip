@@ -1,0 +1,311 @@
+// train.hip -- first slice of the diffusion TRAINING step (BASELINE config 4):
+//
+//   q_sample                      srcs/losses/ddpm_loss.py:386-392   x_t = sqrt(abar_t) x0 + sqrt(1 - abar_t) eps
+//   loss of p_losses              ddpm_loss.py:434-438               mean_b( p2w[t_b] * mean_{c,l} |out - target| ), and d/d out
+//   Block forward / backward      srcs/modules/unet.py:137-154 with WeightStandardizedConv2d (:67-80), GroupNorm(8), SiLU:
+//                                 y = SiLU( GN(conv_k3(x; WS(W), b)) * (scale + 1) + shift )
+//                                 backward: dx, dW (THROUGH the weight standardisation), db, dgamma, dbeta, dscale, dshift
+//
+// fp32 throughout, reference layouts [B, C, L].  This slice is the correctness baseline of the training path (gradients
+// pinned to the reference's autograd, tests/golden/train_block.npz); the three GEMM-shaped pieces (conv forward, dX, dW)
+// are plain tiled VALU kernels here -- the MFMA forms (the dX conv is conv_fast with flipped taps, dW is a
+// [Cout x Cin*3] x [B*L] contraction) are the next step and are not claimed.
+#include <algorithm>
+
+#include "ldc_kernels.h"
+#include "ldc_math.h"
+
+namespace ldc {
+
+// ---------------------------------------------------------------------------------------------
+// q_sample and the L1 objective
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* x0, const float* noise, const int64_t* t, const float* sa,
+                                                       const float* s1ma, int64_t n_per_item, float* out) {
+  const int b = blockIdx.y;
+  const float a = sa[t[b]], c = s1ma[t[b]];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256) {
+    const size_t k = (size_t)b * n_per_item + i;
+    out[k] = a * x0[k] + c * noise[k];
+  }
+}
+hipError_t launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, int B,
+                           int64_t n_per_item, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)std::min<int64_t>((n_per_item + 255) / 256, 256), B), dim3(256), 0, s, x0, noise, t,
+                     sqrt_ac, sqrt_1mac, n_per_item, out);
+  return hipGetLastError();
+}
+
+// per item: sum |d| in double (deterministic two-stage: block partials, then one block)
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* pred, const float* target, int64_t n_per_item, double* part) {
+  const int b = blockIdx.y;
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256)
+    s += (double)fabsf(pred[(size_t)b * n_per_item + i] - target[(size_t)b * n_per_item + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void l1_final_kernel(const double* part, int nblk, int B, int64_t n_per_item, const int64_t* t, const float* p2w, float* loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double tot = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += part[(size_t)b * nblk + k];
+    tot += (double)(float)(s / (double)n_per_item) * (double)p2w[t[b]];
+  }
+  loss[0] = (float)(tot / (double)B);
+}
+__global__ __launch_bounds__(256) void l1_grad_kernel(const float* pred, const float* target, const int64_t* t, const float* p2w,
+                                                      int B, int64_t n_per_item, float* grad) {
+  const int b = blockIdx.y;
+  const float w = p2w[t[b]] / ((float)n_per_item * (float)B);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256) {
+    const size_t k = (size_t)b * n_per_item + i;
+    const float d = pred[k] - target[k];
+    grad[k] = d > 0.f ? w : (d < 0.f ? -w : 0.f);        // torch: sign(0) = 0
+  }
+}
+size_t l1_loss_ws_bytes(int B) { return (size_t)B * 64 * sizeof(double); }
+hipError_t launch_l1_loss(const float* pred, const float* target, const int64_t* t, const float* p2w, int B, int64_t n_per_item,
+                          float* loss, float* grad, void* ws, hipStream_t s) {
+  const int nblk = (int)std::min<int64_t>((n_per_item + 255) / 256, 64);
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(nblk, B), dim3(256), 0, s, pred, target, n_per_item, (double*)ws);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, nblk, B, n_per_item, t, p2w, loss);
+  if (grad) hipLaunchKernelGGL(l1_grad_kernel, dim3(nblk, B), dim3(256), 0, s, pred, target, t, p2w, B, n_per_item, grad);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight standardisation: forward (with saved per-channel 1/std) and backward
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threads
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void ws_forward_kernel(const float* w, int inner, float* wn, float* rstd) {
+  __shared__ float red[4];
+  const int o = blockIdx.x;
+  const float* p = w + (size_t)o * inner;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < inner; i += 256) s += p[i];
+  const float mean = block_sum(s, red) / (float)inner;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < inner; i += 256) { const float d = p[i] - mean; q += d * d; }
+  const float r = rsqrtf(block_sum(q, red) / (float)inner + 1e-5f);
+  for (int i = threadIdx.x; i < inner; i += 256) wn[(size_t)o * inner + i] = (p[i] - mean) * r;
+  if (threadIdx.x == 0) rstd[o] = r;
+}
+// dW = r * (dWn - mean(dWn) - Wn * mean(dWn * Wn))
+__global__ __launch_bounds__(256) void ws_backward_kernel(const float* dwn, const float* wn, const float* rstd, int inner, float* dw) {
+  __shared__ float red[4];
+  const int o = blockIdx.x;
+  float s = 0.f, sx = 0.f;
+  for (int i = threadIdx.x; i < inner; i += 256) {
+    const float g = dwn[(size_t)o * inner + i];
+    s += g; sx += g * wn[(size_t)o * inner + i];
+  }
+  const float ms = block_sum(s, red) / (float)inner;
+  const float msx = block_sum(sx, red) / (float)inner;
+  const float r = rstd[o];
+  for (int i = threadIdx.x; i < inner; i += 256) {
+    const size_t k = (size_t)o * inner + i;
+    dw[k] = r * (dwn[k] - ms - wn[k] * msx);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Conv1d k = 3, padding 1: forward, dX, dW, db  ([B, C, L] fp32)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3_forward_kernel(const float* x, const float* w, const float* bias, int Cin, int Cout, int L,
+                                                            float* y) {
+  const int b = blockIdx.z, o = blockIdx.y;
+  const float* wr = w + (size_t)o * Cin * 3;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < L; l += gridDim.x * 256) {
+    float acc = bias ? bias[o] : 0.f;
+    for (int i = 0; i < Cin; ++i) {
+      const float* xr = x + ((size_t)b * Cin + i) * L;
+      const float xm = l > 0 ? xr[l - 1] : 0.f, xc = xr[l], xp = l + 1 < L ? xr[l + 1] : 0.f;
+      acc = fmaf(wr[3 * i], xm, acc); acc = fmaf(wr[3 * i + 1], xc, acc); acc = fmaf(wr[3 * i + 2], xp, acc);
+    }
+    y[((size_t)b * Cout + o) * L + l] = acc;
+  }
+}
+// dx[b,i,l] = sum_{o,t} w[o,i,t] * dh[b,o,l - t + 1]
+__global__ __launch_bounds__(256) void conv3_dx_kernel(const float* dh, const float* w, int Cin, int Cout, int L, float* dx) {
+  const int b = blockIdx.z, i = blockIdx.y;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < L; l += gridDim.x * 256) {
+    float acc = 0.f;
+    for (int o = 0; o < Cout; ++o) {
+      const float* dr = dh + ((size_t)b * Cout + o) * L;
+      const float* wr = w + ((size_t)o * Cin + i) * 3;
+      const float dp = l + 1 < L ? dr[l + 1] : 0.f, dc = dr[l], dm = l > 0 ? dr[l - 1] : 0.f;
+      acc = fmaf(wr[0], dp, acc); acc = fmaf(wr[1], dc, acc); acc = fmaf(wr[2], dm, acc);
+    }
+    dx[((size_t)b * Cin + i) * L + l] = acc;
+  }
+}
+// dw[o,i,t] = sum_{b,l} dh[b,o,l] * x[b,i,l + t - 1];  one block per (o, i), fixed-order reduction
+__global__ __launch_bounds__(256) void conv3_dw_kernel(const float* dh, const float* x, int B, int Cin, int Cout, int L, float* dw) {
+  __shared__ float red[4];
+  const int o = blockIdx.y, i = blockIdx.x;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* dr = dh + ((size_t)b * Cout + o) * L;
+    const float* xr = x + ((size_t)b * Cin + i) * L;
+    for (int l = threadIdx.x; l < L; l += 256) {
+      const float d = dr[l];
+      if (l > 0) a0 = fmaf(d, xr[l - 1], a0);
+      a1 = fmaf(d, xr[l], a1);
+      if (l + 1 < L) a2 = fmaf(d, xr[l + 1], a2);
+    }
+  }
+  const float s0 = block_sum(a0, red), s1 = block_sum(a1, red), s2 = block_sum(a2, red);
+  if (threadIdx.x == 0) {
+    float* p = dw + ((size_t)o * Cin + i) * 3;
+    p[0] = s0; p[1] = s1; p[2] = s2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm + (scale + 1, shift) + SiLU: forward and backward.  One block per (item, group).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_silu_forward_kernel(const float* h, const float* gamma, const float* beta, const float* ss,
+                                                              int C, int L, int groups, float* y, float* stats) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, g = blockIdx.x, cpg = C / groups, n = cpg * L;
+  const float* p = h + ((size_t)b * C + (size_t)g * cpg) * L;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+  const float mean = block_sum(s, red) / (float)n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { const float d = p[i] - mean; q += d * d; }
+  const float rstd = rsqrtf(block_sum(q, red) / (float)n + 1e-5f);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = g * cpg + i / L;
+    float v = (p[i] - mean) * rstd * gamma[c] + beta[c];
+    if (ss) v = v * (ss[(size_t)b * 2 * C + c] + 1.0f) + ss[(size_t)b * 2 * C + C + c];
+    y[((size_t)b * C + (size_t)g * cpg) * L + i] = v / (1.0f + expf(-v));
+  }
+  if (threadIdx.x == 0) { stats[((size_t)b * groups + g) * 2] = mean; stats[((size_t)b * groups + g) * 2 + 1] = rstd; }
+}
+
+// pass 1: per (item, channel): dz -> dn = dz * (scale + 1); writes dxhat = dn * gamma into `tmp`, the per-(b,c) sums
+// dscale = sum dz * nval, dshift = sum dz, and pgam[b][c] = sum dn * xhat, pbet[b][c] = sum dn
+__global__ __launch_bounds__(256) void gn_silu_backward1_kernel(const float* dy, const float* h, const float* gamma, const float* beta,
+                                                                const float* ss, const float* stats, int C, int L, int groups,
+                                                                float* tmp, float* dss, float* pgam, float* pbet) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, c = blockIdx.x, g = c / (C / groups);
+  const float mean = stats[((size_t)b * groups + g) * 2], rstd = stats[((size_t)b * groups + g) * 2 + 1];
+  const float sc = ss ? ss[(size_t)b * 2 * C + c] + 1.0f : 1.0f, sh = ss ? ss[(size_t)b * 2 * C + C + c] : 0.0f;
+  const float ga = gamma[c], be = beta[c];
+  const size_t base = ((size_t)b * C + c) * L;
+  float s_dz = 0.f, s_dzn = 0.f, s_dnx = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const float xh = (h[base + l] - mean) * rstd;
+    const float nv = xh * ga + be;
+    const float z = nv * sc + sh;
+    const float sg = 1.0f / (1.0f + expf(-z));
+    const float dz = dy[base + l] * (sg * (1.0f + z * (1.0f - sg)));
+    const float dn = dz * sc;
+    s_dz += dz; s_dzn += dz * nv; s_dnx += dn * xh;
+    tmp[base + l] = dn * ga;
+  }
+  const float t_dz = block_sum(s_dz, red), t_dzn = block_sum(s_dzn, red), t_dnx = block_sum(s_dnx, red);
+  if (threadIdx.x == 0) {
+    if (dss) { dss[(size_t)b * 2 * C + c] = t_dzn; dss[(size_t)b * 2 * C + C + c] = t_dz; }
+    pgam[(size_t)b * C + c] = t_dnx;
+    pbet[(size_t)b * C + c] = t_dz * sc;
+  }
+}
+// pass 2: per (item, group): dh = rstd / n * (n * dxhat - sum dxhat - xhat * sum(dxhat * xhat))
+__global__ __launch_bounds__(256) void gn_silu_backward2_kernel(const float* h, const float* stats, int C, int L, int groups, float* tmp_dh) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, g = blockIdx.x, cpg = C / groups, n = cpg * L;
+  const float mean = stats[((size_t)b * groups + g) * 2], rstd = stats[((size_t)b * groups + g) * 2 + 1];
+  const size_t base = ((size_t)b * C + (size_t)g * cpg) * L;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = tmp_dh[base + i];
+    s1 += d; s2 += d * (h[base + i] - mean) * rstd;
+  }
+  const float t1 = block_sum(s1, red), t2 = block_sum(s2, red);
+  const float inv_n = 1.0f / (float)n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float xh = (h[base + i] - mean) * rstd;
+    tmp_dh[base + i] = rstd * (tmp_dh[base + i] - t1 * inv_n - xh * t2 * inv_n);
+  }
+}
+// dgamma[c] = sum_b pgam[b][c], dbeta likewise; db[o] = sum_{b,l} dh[b,o,l]
+__global__ __launch_bounds__(256) void reduce_items_kernel(const float* p, int B, int C, float* out) {
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += p[(size_t)b * C + c];
+    out[c] = s;
+  }
+}
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dh, int B, int C, int L, float* db) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int l = threadIdx.x; l < L; l += 256) s += dh[((size_t)b * C + c) * L + l];
+  const float t = block_sum(s, red);
+  if (threadIdx.x == 0) db[c] = t;
+}
+
+size_t train_block_ws_floats(int B, int Cin, int Cout, int L, int groups) {
+  // wn [Cout*Cin*3] | rstd_w [Cout] | h [B*Cout*L] | gn stats [B*groups*2] | tmp [B*Cout*L] | dwn [Cout*Cin*3] | pgam, pbet [B*Cout] x 2
+  return (size_t)2 * Cout * Cin * 3 + Cout + (size_t)2 * B * Cout * L + (size_t)B * groups * 2 + (size_t)2 * B * Cout + 64;
+}
+
+struct BlockWs { float *wn, *rstd_w, *h, *stats, *tmp, *dwn, *pgam, *pbet; };
+static BlockWs carve(float* ws, int B, int Cin, int Cout, int L, int groups) {
+  BlockWs w;
+  float* p = ws;
+  w.wn = p; p += (size_t)Cout * Cin * 3;
+  w.rstd_w = p; p += Cout;
+  w.h = p; p += (size_t)B * Cout * L;
+  w.stats = p; p += (size_t)B * groups * 2;
+  w.tmp = p; p += (size_t)B * Cout * L;
+  w.dwn = p; p += (size_t)Cout * Cin * 3;
+  w.pgam = p; p += (size_t)B * Cout;
+  w.pbet = p;
+  return w;
+}
+
+hipError_t launch_train_block_forward(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                                      const float* ss, int B, int Cin, int Cout, int L, int groups, float* y, float* ws, hipStream_t s) {
+  const BlockWs k = carve(ws, B, Cin, Cout, L, groups);
+  hipLaunchKernelGGL(ws_forward_kernel, dim3(Cout), dim3(256), 0, s, w, Cin * 3, k.wn, k.rstd_w);
+  hipLaunchKernelGGL(conv3_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, k.wn, bias, Cin, Cout, L, k.h);
+  hipLaunchKernelGGL(gn_silu_forward_kernel, dim3(groups, B), dim3(256), 0, s, k.h, gamma, beta, ss, Cout, L, groups, y, k.stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_train_block_backward(const float* dy, const float* x, const float* gamma, const float* beta, const float* ss, int B,
+                                       int Cin, int Cout, int L, int groups, float* ws, float* dx, float* dw, float* db, float* dgamma,
+                                       float* dbeta, float* dss, hipStream_t s) {
+  const BlockWs k = carve(ws, B, Cin, Cout, L, groups);
+  hipLaunchKernelGGL(gn_silu_backward1_kernel, dim3(Cout, B), dim3(256), 0, s, dy, k.h, gamma, beta, ss, k.stats, Cout, L, groups, k.tmp,
+                     dss, k.pgam, k.pbet);
+  hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pgam, B, Cout, dgamma);
+  hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pbet, B, Cout, dbeta);
+  hipLaunchKernelGGL(gn_silu_backward2_kernel, dim3(groups, B), dim3(256), 0, s, k.h, k.stats, Cout, L, groups, k.tmp);   // tmp := dh
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, k.tmp, B, Cout, L, db);
+  hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, k.tmp, x, B, Cin, Cout, L, k.dwn);
+  hipLaunchKernelGGL(ws_backward_kernel, dim3(Cout), dim3(256), 0, s, k.dwn, k.wn, k.rstd_w, Cin * 3, dw);
+  if (dx) hipLaunchKernelGGL(conv3_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, k.tmp, k.wn, Cin, Cout, L, dx);
+  return hipGetLastError();
+}
+
+}  // namespace ldc

@@ -24,7 +24,8 @@ EXPORTS = [
     "ldc_cond_upsample", "ldc_unet_forward", "ldc_p_sample", "ldc_denoise", "ldc_p_sample_loop", "ldc_infilling", "ldc_output_normalise", "ldc_decode",
     "ldc_sconv1d", "ldc_sconvtr1d", "ldc_slstm", "ldc_unet_debug_tap", "ldc_unet_step_cost", "ldc_profile_enable",
     "ldc_profile_read", "ldc_profile_read_classes", "ldc_conv_microbench", "ldc_gn_microbench", "ldc_strip_microbench", "ldc_timeline_enable", "ldc_timeline_read", "ldc_packed_bytes", "ldc_pack_codes", "ldc_unpack_codes",
-    "ldc_ac_build_cdf", "ldc_ac_encode", "ldc_ac_decode",
+    "ldc_ac_build_cdf", "ldc_ac_encode", "ldc_ac_decode", "ldc_train_q_sample", "ldc_train_l1_loss", "ldc_train_block_ws_floats",
+    "ldc_train_block_forward", "ldc_train_block_backward",
 ]
 
 
@@ -113,10 +114,15 @@ def load() -> C.CDLL:
     lib.ldc_ac_build_cdf.argtypes = [vp, vp, i32, i32, i32, C.c_float, i32, vp, vp]
     lib.ldc_ac_encode.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, C.c_int64, vp, vp]
     lib.ldc_ac_decode.argtypes = [vp, vp, C.c_int64, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.ldc_train_q_sample.argtypes = [vp, fp, vp, fp, i32, i32, i32, fp, vp]
+    lib.ldc_train_l1_loss.argtypes = [vp, fp, fp, vp, i32, i32, i32, fp, fp, vp]
+    lib.ldc_train_block_ws_floats.argtypes = [i32, i32, i32, i32, i32]
+    lib.ldc_train_block_forward.argtypes = [vp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, fp, fp, vp]
+    lib.ldc_train_block_backward.argtypes = [vp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, vp]
     lib.ldc_gn_microbench.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name == "ldc_packed_bytes":
+        if name in ("ldc_packed_bytes", "ldc_train_block_ws_floats"):
             fn.restype = C.c_int64
         elif name == "ldc_quantize_e4m3":
             fn.restype = None

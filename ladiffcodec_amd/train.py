@@ -1,0 +1,89 @@
+"""Host-side mirror of the training-step slice: `diffusion.q_sample`, the objective of
+`diffusion.p_losses` and `Block` forward / backward (srcs/losses/ddpm_loss.py:386-438, srcs/modules/unet.py:137-154)
+as calls into libladiffcodec.so on torch device tensors.  Weights are the TRAINED tensors (raw `proj.weight`: the weight
+standardisation is differentiated through), layouts are the reference's [B, C, L] fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import lib as L
+
+
+class Block:
+    """unet.py:137-154.  forward(x, scale_shift) keeps what backward needs in a device workspace."""
+
+    def __init__(self, eng, weight, bias, norm_weight, norm_bias, groups: int = 8):
+        self.eng, self.lib, self.torch = eng, eng.lib, eng.torch
+        f = lambda v: v.to(eng.device, self.torch.float32).contiguous()
+        self.weight, self.bias, self.gamma, self.beta = f(weight), f(bias), f(norm_weight), f(norm_bias)
+        self.groups = groups
+        self._saved = None
+
+    def forward(self, x, scale_shift=None):
+        t = self.torch
+        x = x.to(self.eng.device, t.float32).contiguous()
+        B, Cin, Lx = x.shape
+        Cout = self.weight.shape[0]
+        ss = None
+        if scale_shift is not None:
+            scale, shift = scale_shift
+            ss = t.cat([scale.reshape(B, Cout), shift.reshape(B, Cout)], dim=1).to(self.eng.device, t.float32).contiguous()
+        ws = t.empty(int(self.lib.ldc_train_block_ws_floats(B, Cin, Cout, Lx, self.groups)), dtype=t.float32, device=self.eng.device)
+        y = t.empty(B, Cout, Lx, dtype=t.float32, device=self.eng.device)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_block_forward(self.eng._ctx, x.data_ptr(), self.weight.data_ptr(), self.bias.data_ptr(),
+                                                 self.gamma.data_ptr(), self.beta.data_ptr(), ss.data_ptr() if ss is not None else None,
+                                                 B, Cin, Cout, Lx, self.groups, y.data_ptr(), ws.data_ptr(), s))
+        self.eng._exit()
+        self._saved = (x, ss, ws)
+        return y
+
+    def backward(self, dy):
+        """-> dict(dx, dw, db, dgamma, dbeta[, dscale, dshift])"""
+        t = self.torch
+        x, ss, ws = self._saved
+        B, Cin, Lx = x.shape
+        Cout = self.weight.shape[0]
+        dy = dy.to(self.eng.device, t.float32).contiguous()
+        e = lambda *shape: t.empty(*shape, dtype=t.float32, device=self.eng.device)
+        dx, dw, db, dg, dbt = e(B, Cin, Lx), e(Cout, Cin, 3), e(Cout), e(Cout), e(Cout)
+        dss = e(B, 2 * Cout) if ss is not None else None
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_block_backward(self.eng._ctx, dy.data_ptr(), x.data_ptr(), self.gamma.data_ptr(), self.beta.data_ptr(),
+                                                  ss.data_ptr() if ss is not None else None, B, Cin, Cout, Lx, self.groups, ws.data_ptr(),
+                                                  dx.data_ptr(), dw.data_ptr(), db.data_ptr(), dg.data_ptr(), dbt.data_ptr(),
+                                                  dss.data_ptr() if dss is not None else None, s))
+        self.eng._exit()
+        out = {"dx": dx, "dw": dw, "db": db, "dgamma": dg, "dbeta": dbt}
+        if dss is not None:
+            out["dscale"], out["dshift"] = dss[:, :Cout].reshape(B, Cout, 1), dss[:, Cout:].reshape(B, Cout, 1)
+        return out
+
+
+def q_sample(eng, x_start, t, noise):
+    """diffusion.q_sample (ddpm_loss.py:386-392)."""
+    tt = eng.torch
+    x_start, noise = eng._f32(x_start), eng._f32(noise)
+    t = t.to(eng.device, tt.int64).contiguous()
+    B, Cc, Lx = x_start.shape
+    out = tt.empty_like(x_start)
+    s = eng._enter()
+    L.check(eng.lib.ldc_train_q_sample(eng._ctx, x_start.data_ptr(), t.data_ptr(), noise.data_ptr(), B, Cc, Lx, out.data_ptr(), s))
+    eng._exit()
+    return out
+
+
+def p_losses_objective(eng, model_out, target, t, want_grad: bool = True):
+    """The loss of diffusion.p_losses (ddpm_loss.py:434-438, l1) and its gradient w.r.t. the model output."""
+    tt = eng.torch
+    model_out, target = eng._f32(model_out), eng._f32(target)
+    t = t.to(eng.device, tt.int64).contiguous()
+    B, Cc, Lx = model_out.shape
+    loss = tt.empty(1, dtype=tt.float32, device=eng.device)
+    grad = tt.empty_like(model_out) if want_grad else None
+    s = eng._enter()
+    L.check(eng.lib.ldc_train_l1_loss(eng._ctx, model_out.data_ptr(), target.data_ptr(), t.data_ptr(), B, Cc, Lx, loss.data_ptr(),
+                                      grad.data_ptr() if grad is not None else None, s))
+    eng._exit()
+    return (loss, grad) if want_grad else loss

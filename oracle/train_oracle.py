@@ -1,0 +1,31 @@
+"""CPU restatement (differentiable, torch autograd) of the training-step slice -- TEST INFRASTRUCTURE ONLY.
+
+  block_forward      srcs/modules/unet.py:137-154 (Block) with the weight path of WeightStandardizedConv2d, :67-80
+  q_sample           srcs/losses/ddpm_loss.py:386-392
+  p_losses_objective ddpm_loss.py:434-438 (loss_type 'l1', objective 'pred_noise')
+Pinned by tests/golden/train_block.npz: outputs AND gradients of the reference's own Block / p_losses under autograd
+(tools/gen_golden.py, GOLDEN_ONLY=train).
+"""
+import torch
+import torch.nn.functional as F
+
+from oracle.ldc_oracle import ws_fold
+
+
+def block_forward(x, w, b, gamma, beta, scale=None, shift=None, groups: int = 8):
+    h = F.conv1d(x, ws_fold(w), b, padding=1)
+    h = F.group_norm(h, groups, gamma, beta, eps=1e-5)
+    if scale is not None:
+        h = h * (scale + 1) + shift
+    return F.silu(h)
+
+
+def q_sample(sd, x_start, t, noise):
+    a = sd["diffusion.sqrt_alphas_cumprod"][t].view(-1, 1, 1)
+    c = sd["diffusion.sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1)
+    return a * x_start + c * noise
+
+
+def p_losses_objective(sd, model_out, target, t):
+    loss = F.l1_loss(model_out, target, reduction="none").flatten(1).mean(dim=1)
+    return (loss * sd["diffusion.p2_loss_weight"][t]).mean()

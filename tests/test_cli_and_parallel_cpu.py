@@ -81,6 +81,9 @@ outs = parallel.gather_results(local, world)
 assert len(outs) == world and all(float(o.mean()) == float(r) for r, o in enumerate(outs))
 t = parallel.max_over_ranks(1.0 + rank)
 assert t == float(world)
+grads = torch.arange(10, dtype=torch.float32) * (rank + 1)          # training-step gradient reduction (flat buffer)
+parallel.allreduce_gradients(grads)
+assert torch.allclose(grads, torch.arange(10, dtype=torch.float32) * (1 + 2) / 2)
 
 # synthesis()'s sharding / bucketing with a stub engine: every file decoded exactly once by exactly one rank,
 # multi-channel files whole and jointly normalised, mono files batched by equal trimmed length

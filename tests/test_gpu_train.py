@@ -1,0 +1,60 @@
+"""GPU training-step slice through the C ABI: q_sample, the p_losses objective and Block forward / backward against the
+reference's own autograd results (tests/golden/train_block.npz) and, at a wider shape, against autograd of the oracle.
+Tolerance 1e-4 relative (fp32 kernels; different reduction orders only)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ladiffcodec_amd import train as TR  # noqa: E402
+from oracle import train_oracle as TO  # noqa: E402
+from helpers import T, load_golden  # noqa: E402
+from gpu_common import engine, rel  # noqa: E402
+
+TOL = 1e-4
+
+
+def test_block_forward_backward_reference_vectors():
+    g = load_golden("train_block")
+    e = engine("r84", "f32")
+    for tag, with_ss in (("a", True), ("b", False)):
+        blk = TR.Block(e, T(g[f"{tag}.w"]), T(g[f"{tag}.b"]), T(g[f"{tag}.gamma"]), T(g[f"{tag}.beta"]))
+        ss = (T(g[f"{tag}.scale"]), T(g[f"{tag}.shift"])) if with_ss else None
+        y = blk.forward(T(g[f"{tag}.x"]), ss)
+        assert rel(y.cpu().numpy(), g[f"{tag}.y"]) < TOL
+        grads = blk.backward(T(g[f"{tag}.dy"]))
+        for name, val in grads.items():
+            assert rel(val.cpu().numpy(), g[f"{tag}.{name}"]) < TOL, (tag, name)
+
+
+def test_block_gradients_wide_against_oracle_autograd():
+    """diff_dims = 256 widths of the first level (256 -> 256 channels, L = 300), B = 3."""
+    e = engine("r84", "f32")
+    gen = torch.Generator().manual_seed(12)
+    B, Cin, Cout, Lx = 3, 256, 256, 300
+    leaf = lambda *s, k=1.0: (torch.randn(*s, generator=gen) * k).requires_grad_()
+    x, w, b = leaf(B, Cin, Lx), leaf(Cout, Cin, 3, k=0.05), leaf(Cout, k=0.1)
+    gamma, beta = (torch.rand(Cout, generator=gen) + 0.5).requires_grad_(), leaf(Cout, k=0.1)
+    scale, shift = leaf(B, Cout, 1, k=0.3), leaf(B, Cout, 1, k=0.3)
+    y = TO.block_forward(x, w, b, gamma, beta, scale, shift)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    blk = TR.Block(e, w.detach(), b.detach(), gamma.detach(), beta.detach())
+    got_y = blk.forward(x.detach(), (scale.detach(), shift.detach()))
+    assert rel(got_y.cpu().numpy(), y.detach().numpy()) < TOL
+    grads = blk.backward(dy)
+    want = {"dx": x.grad, "dw": w.grad, "db": b.grad, "dgamma": gamma.grad, "dbeta": beta.grad, "dscale": scale.grad, "dshift": shift.grad}
+    for name, val in grads.items():
+        assert rel(val.cpu().numpy(), want[name].numpy()) < TOL, name
+
+
+def test_q_sample_and_objective_reference_vectors():
+    g = load_golden("train_block")
+    e = engine("r84", "f32")
+    t = torch.from_numpy(g["q.t"])
+    x_t = TR.q_sample(e, T(g["q.x0"]), t, T(g["q.noise"]))
+    assert rel(x_t.cpu().numpy(), g["q.x_t"]) < 1e-6
+    loss, grad = TR.p_losses_objective(e, T(g["q.model_out"]), T(g["q.noise"]), t)
+    assert abs(float(loss.cpu()[0]) - float(g["q.loss"][0])) < 1e-5
+    assert rel(grad.cpu().numpy(), g["q.grad"]) < 1e-6

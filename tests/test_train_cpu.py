@@ -1,0 +1,33 @@
+"""Pins oracle/train_oracle.py (training-step slice) to the reference's own autograd results (tests/golden/train_block.npz)."""
+import numpy as np
+import torch
+
+from ladiffcodec_amd import synth
+from oracle import train_oracle as TO
+from helpers import T, load_golden, rel_err
+
+
+def test_block_forward_and_gradients_match_reference_autograd():
+    g = load_golden("train_block")
+    for tag, with_ss in (("a", True), ("b", False)):
+        leaf = lambda k: T(g[f"{tag}.{k}"]).clone().requires_grad_()
+        x, w, b, gamma, beta = leaf("x"), leaf("w"), leaf("b"), leaf("gamma"), leaf("beta")
+        scale = leaf("scale") if with_ss else None
+        shift = leaf("shift") if with_ss else None
+        y = TO.block_forward(x, w, b, gamma, beta, scale, shift)
+        assert rel_err(y.detach().numpy(), g[f"{tag}.y"]) < 2e-5
+        y.backward(T(g[f"{tag}.dy"]))
+        for name, t in (("dx", x), ("dw", w), ("db", b), ("dgamma", gamma), ("dbeta", beta)) + ((("dscale", scale), ("dshift", shift)) if with_ss else ()):
+            assert rel_err(t.grad.numpy(), g[f"{tag}.{name}"]) < 5e-5, (tag, name)
+
+
+def test_q_sample_and_objective_match_reference():
+    g = load_golden("train_block")
+    sd = {"diffusion." + k: torch.from_numpy(v) for k, v in synth.cosine_schedule_buffers(1000).items()}
+    t = torch.from_numpy(g["q.t"])
+    assert rel_err(TO.q_sample(sd, T(g["q.x0"]), t, T(g["q.noise"])).numpy(), g["q.x_t"]) < 1e-6
+    out = T(g["q.model_out"]).clone().requires_grad_()
+    loss = TO.p_losses_objective(sd, out, T(g["q.noise"]), t)
+    assert abs(float(loss) - float(g["q.loss"][0])) < 1e-6
+    loss.backward()
+    assert rel_err(out.grad.numpy(), g["q.grad"]) < 1e-6

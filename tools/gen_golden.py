@@ -280,6 +280,55 @@ def main():
         np.savez_compressed(os.path.join(OUT, "variants.npz"), **out)
         print("variants: sx eps absmax", float(np.abs(out["sx.eps_t37"]).max()), "fa z absmax", float(np.abs(out["fa.z"]).max()))
 
+    # ---------------------------------------------------------------- training step, first slice
+    def train_case():
+        from srcs.modules.unet import Block
+        out = {}
+        torch.manual_seed(4040)
+        gg = torch.Generator().manual_seed(4041)
+        for tag, cin, cout, L, with_ss in (("a", 32, 64, 160, True), ("b", 64, 64, 75, False)):
+            blk = Block(cin, cout, groups=8)
+            with torch.no_grad():
+                blk.norm.weight.copy_(torch.rand(cout, generator=gg) + 0.5)
+                blk.norm.bias.copy_(torch.randn(cout, generator=gg) * 0.1)
+            x = torch.randn(2, cin, L, generator=gg, requires_grad=True)
+            ss = None
+            if with_ss:
+                scale = (torch.randn(2, cout, 1, generator=gg) * 0.3).requires_grad_()
+                shift = (torch.randn(2, cout, 1, generator=gg) * 0.3).requires_grad_()
+                ss = (scale, shift)
+            y = blk(x, scale_shift=ss)
+            dy = torch.randn(y.shape, generator=gg)
+            y.backward(dy)
+            out.update({f"{tag}.x": np32(x), f"{tag}.w": np32(blk.proj.weight), f"{tag}.b": np32(blk.proj.bias),
+                        f"{tag}.gamma": np32(blk.norm.weight), f"{tag}.beta": np32(blk.norm.bias), f"{tag}.y": np32(y), f"{tag}.dy": np32(dy),
+                        f"{tag}.dx": np32(x.grad), f"{tag}.dw": np32(blk.proj.weight.grad), f"{tag}.db": np32(blk.proj.bias.grad),
+                        f"{tag}.dgamma": np32(blk.norm.weight.grad), f"{tag}.dbeta": np32(blk.norm.bias.grad)})
+            if with_ss:
+                out.update({f"{tag}.scale": np32(scale), f"{tag}.shift": np32(shift), f"{tag}.dscale": np32(scale.grad),
+                            f"{tag}.dshift": np32(shift.grad)})
+        # q_sample and the objective of p_losses (ddpm_loss.py:386-392, 404-438) with the model output as the leaf
+        model_out = (torch.randn(3, 128, 80, generator=gg) * 0.8).requires_grad_()
+
+        class Fixed(torch.nn.Module):
+            channels, self_condition = 128, False
+
+            def forward(self, x, t, c=None):
+                return model_out
+        diff = ref_ddpm.GaussianDiffusion1D(Fixed(), seq_length=80, sampling_timesteps=1000)
+        x0 = torch.randn(3, 128, 80, generator=gg).clamp(-1, 1)
+        noise = torch.randn(3, 128, 80, generator=gg)
+        t = torch.tensor([3, 500, 999])
+        loss, _, x_t = diff.p_losses(x0, t, cond=None, noise=noise)
+        loss.backward()
+        out.update({"q.x0": np32(x0), "q.noise": np32(noise), "q.t": t.numpy().astype(np.int64), "q.x_t": np32(x_t),
+                    "q.model_out": np32(model_out), "q.loss": np32(loss.reshape(1)), "q.grad": np32(model_out.grad)})
+        np.savez_compressed(os.path.join(OUT, "train_block.npz"), **out)
+        print("train_block: loss", float(loss), "dw absmax", float(np.abs(out["a.dw"]).max()))
+
+    train_case()
+    if os.environ.get("GOLDEN_ONLY") == "train":
+        return
     variants_case()
     mc84 = CodecConfig(enc_ratios=(8, 4), quantization=False)
     u84 = UnetConfig(dim=32, upsampling_ratios=(5, 2), unet_scale_cond=True)
