@@ -198,6 +198,11 @@ int ldc_ac_encode(ldc_ctx* ctx, const int32_t* symbols, const int32_t* cdf, int 
 int ldc_ac_decode(ldc_ctx* ctx, const uint8_t* in, int64_t in_stride, const int64_t* nbytes, const int32_t* cdf, int B, int S, int card,
                   int n_static, int total_range_bits, int32_t* symbols_out, int32_t* status_out, void* stream);
 
+/* audio front end -- SURVEY.md section 8(f) row 4: torchaudio.functional.resample(wav, orig_freq, new_freq) with its defaults
+ * (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99), the call at srcs/sample.py:84.  wav [C][T] -> out [C][ldc_resample_out_len]. */
+int64_t ldc_resample_out_len(int64_t T, int orig_freq, int new_freq);
+int ldc_resample(ldc_ctx* ctx, const float* wav, int C, int64_t T, int orig_freq, int new_freq, float* out, void* stream);
+
 /* training step, first slice -- SURVEY.md section 8(f) row 2 (BASELINE config 4); fp32, reference layouts [B,C,L] --------------
  * diffusion.q_sample(x_start, t, noise) (ddpm_loss.py:386-392); t [B] int64 (device). */
 int ldc_train_q_sample(ldc_ctx* ctx, const float* x_start, const int64_t* t, const float* noise, int B, int C, int L, float* x_t,

@@ -413,3 +413,35 @@ hipError_t launch_output_normalise(float* x, int B, int64_t n_per_item, int per_
 }
 
 }  // namespace ldc
+
+// ---------------------------------------------------------------------------------------------
+// Front end: torchaudio.functional.resample (sinc_interp_hann), the call at srcs/sample.py:84.  Polyphase form: output sample
+// i * new + p = sum_k kernel[p][k] * padded[i * orig + k] with the [new][2 width + orig] filter bank built on the host in
+// float64 (torchaudio 0.13 _get_sinc_resample_kernel) -- one thread per output sample, HBM/L2-bound streaming.
+// ---------------------------------------------------------------------------------------------
+namespace ldc {
+__global__ __launch_bounds__(256) void resample_kernel(const float* wav, int64_t T, const float* bank, int orig, int nnew, int width,
+                                                       int K, int64_t target, float* out) {
+  const int c = blockIdx.y;
+  const float* x = wav + (size_t)c * T;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < target; j += (int64_t)gridDim.x * 256) {
+    const int64_t i = j / nnew;
+    const int p = (int)(j - i * nnew);
+    const float* kr = bank + (size_t)p * K;
+    const int64_t s0 = i * orig - width;          // index into the unpadded signal of tap 0
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int64_t s = s0 + k;
+      if (s >= 0 && s < T) acc = fmaf(x[s], kr[k], acc);
+    }
+    out[(size_t)c * target + j] = acc;
+  }
+}
+hipError_t launch_resample(const float* wav, int C, int64_t T, const float* bank, int orig, int nnew, int width, int64_t target, float* out,
+                           hipStream_t s) {
+  if (target <= 0 || C <= 0) return hipSuccess;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)std::min<int64_t>((target + 255) / 256, 2048), C), dim3(256), 0, s, wav, T, bank, orig,
+                     nnew, width, 2 * width + orig, target, out);
+  return hipGetLastError();
+}
+}  // namespace ldc

@@ -2336,6 +2336,59 @@ extern "C" int ldc_ac_decode(ldc_ctx* c, const uint8_t* in, int64_t in_stride, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// audio front end: torchaudio.functional.resample as srcs/sample.py:84 calls it
+// ------------------------------------------------------------------------------------------------
+static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+extern "C" int64_t ldc_resample_out_len(int64_t T, int orig_freq, int new_freq) {
+  if (orig_freq <= 0 || new_freq <= 0 || T < 0) return -1;
+  const int g = gcd_i(orig_freq, new_freq);
+  const int64_t orig = orig_freq / g, nnew = new_freq / g;
+  return (nnew * T + orig - 1) / orig;       // ceil(new * T / orig), torchaudio's target_length
+}
+
+extern "C" int ldc_resample(ldc_ctx* c, const float* wav, int C, int64_t T, int orig_freq, int new_freq, float* out, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!wav || !out || C < 1 || T < 1 || orig_freq <= 0 || new_freq <= 0) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  if (orig_freq == new_freq) {
+    HIPCHK(hipMemcpyAsync(out, wav, (size_t)C * T * 4, hipMemcpyDeviceToDevice, s));
+    return finish_stream(c, stream);
+  }
+  const int g = gcd_i(orig_freq, new_freq);
+  const int orig = orig_freq / g, nnew = new_freq / g;
+  // torchaudio 0.13 _get_sinc_resample_kernel: lowpass_filter_width 6, rolloff 0.99, Hann window, built in float64
+  const double lpw = 6.0, rolloff = 0.99, pi = 3.14159265358979323846;
+  const double base_freq = std::min(orig, nnew) * rolloff;
+  const int width = (int)ceil(lpw * orig / base_freq);
+  const int K = 2 * width + orig;
+  if ((double)nnew * K > 64e6) return fail(LDC_E_INVALID, "resampling %d -> %d needs a %d x %d filter bank: rates too incommensurate", orig_freq, new_freq, nnew, K);
+  std::vector<float> bank((size_t)nnew * K);
+  const double scale = base_freq / orig;
+  for (int p = 0; p < nnew; ++p)
+    for (int k = 0; k < K; ++k) {
+      double t = ((double)(-p) / nnew + (double)(k - width) / orig) * base_freq;
+      t = std::max(-lpw, std::min(lpw, t));
+      const double win = cos(t * pi / lpw / 2.0);
+      const double tp = t * pi;
+      const double sinc = tp == 0.0 ? 1.0 : sin(tp) / tp;
+      bank[(size_t)p * K + k] = (float)(sinc * win * win * scale);
+    }
+  const int64_t target = ldc_resample_out_len(T, orig_freq, new_freq);
+  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
+    float* dbank = (float*)ar.alloc(bank.size() * 4);
+    if (!dry) {
+      // (pageable host memory: the copy is staged before the call returns, `bank` may go out of scope)
+      HIPCHK(hipMemcpyAsync(dbank, bank.data(), bank.size() * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(launch_resample(wav, C, T, dbank, orig, nnew, width, target, out, s));
+    }
+    return LDC_OK;
+  }));
+  return finish_stream(c, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
 // training step, first slice
 // ------------------------------------------------------------------------------------------------
 extern "C" int ldc_train_q_sample(ldc_ctx* c, const float* x0, const int64_t* t, const float* noise, int B, int C, int L, float* x_t,

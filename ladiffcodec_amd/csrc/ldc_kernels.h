@@ -183,6 +183,9 @@ hipError_t launch_p_sample_update(int dt, float* x, const void* eps_cl, const fl
 // x /= (maxabs[b or 0] + eps) in place on a raw element stream (n_per_item elements per item)
 hipError_t launch_scale_by_maxabs(int dt, void* x, int B, int64_t n_per_item, const float* maxabs, int per_item,
                                   float eps, hipStream_t s);
+// torchaudio-style polyphase sinc resampling; bank [nnew][2*width+orig] fp32 (device)
+hipError_t launch_resample(const float* wav, int C, int64_t T, const float* bank, int orig, int nnew, int width, int64_t target, float* out,
+                           hipStream_t s);
 hipError_t launch_scale_copy(int dt, const void* x, void* y, int B, int64_t n_per_item, const float* maxabs, float eps,
                              hipStream_t s);
 hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s);      // t -= 1, j += 1 (tl: timeline slot or null)

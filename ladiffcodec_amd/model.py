@@ -154,6 +154,16 @@ class Engine:
         self._exit()
         return q
 
+    def resample(self, wav, orig_freq: int, new_freq: int = 16000):
+        """torchaudio.functional.resample(wav, orig_freq, new_freq) (sample.py:84); wav [C, T] -> [C, ceil(T * new / orig)]."""
+        wav = self._f32(wav)
+        Cc, T = wav.shape
+        out = self._empty(Cc, int(self.lib.ldc_resample_out_len(T, int(orig_freq), int(new_freq))))
+        s = self._enter()
+        L.check(self.lib.ldc_resample(self._ctx, wav.data_ptr(), Cc, T, int(orig_freq), int(new_freq), out.data_ptr(), s))
+        self._exit()
+        return out
+
     def get_cond(self, wav, bandwidth: float = 0.0, return_codes: bool = False):
         wav = self._f32(wav)
         B, _, T = wav.shape

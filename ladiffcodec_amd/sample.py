@@ -94,10 +94,9 @@ def _unsupported(a) -> None:
         raise SystemExit(f"--final_activation {a.final_activation}: supported are {sorted(k for k in FINAL_ACTIVATIONS if k)}")
 
 
-def read_wav_16k(path: str) -> np.ndarray:
-    """-> float32 [channels, T] at 16 kHz (torchaudio.load + functional.resample in the reference, sample.py:83-84)."""
+def read_wav(path: str):
+    """torchaudio.load (sample.py:83): -> (float32 [channels, T] in [-1, 1), sample rate)."""
     from scipy.io import wavfile
-    from scipy.signal import resample_poly
     sr, x = wavfile.read(path)
     if x.dtype.kind == "i":
         x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
@@ -105,9 +104,18 @@ def read_wav_16k(path: str) -> np.ndarray:
         x = (x.astype(np.float32) - 128.0) / 128.0
     x = x.astype(np.float32)
     x = x[None, :] if x.ndim == 1 else x.T
+    return np.ascontiguousarray(x), int(sr)
+
+
+def read_wav_16k(path: str, eng=None) -> np.ndarray:
+    """-> float32 [channels, T] at 16 kHz: torchaudio.load + torchaudio.functional.resample(wav, sr, 16000) of the reference
+    (sample.py:83-84); the resampling runs on the GPU (ldc_resample, the same windowed-sinc filter bank)."""
+    x, sr = read_wav(path)
     if sr != 16000:
-        g = int(np.gcd(int(sr), 16000))
-        x = resample_poly(x, 16000 // g, int(sr) // g, axis=1).astype(np.float32)
+        import torch
+        if eng is None:
+            raise RuntimeError(f"{path}: {sr} Hz input needs the engine's resampler")
+        x = eng.resample(torch.from_numpy(x), sr, 16000).cpu().numpy()
     return x
 
 
@@ -172,7 +180,7 @@ def plan_batches(lengths: List[int], channels: List[int], rank: int, world: int,
 def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_rank: int) -> List[str]:
     import torch
     from scipy.io import wavfile
-    wavs = [read_wav_16k(f) for f in files]
+    wavs = [read_wav_16k(f, eng if hasattr(eng, "resample") else None) for f in files]
     keep = [i for i, w in enumerate(wavs) if w.shape[-1] // 640 * 640 > 0]                   # sample.py:87-88
     files, wavs = [files[i] for i in keep], [wavs[i] for i in keep]
     lengths = [w.shape[-1] for w in wavs]

@@ -1,0 +1,49 @@
+"""Audio front end on the GPU: ldc_resample against the oracle's restatement of
+torchaudio.functional.resample (srcs/sample.py:84), and the CLI on a non-16 kHz file."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ladiffcodec_amd import synth  # noqa: E402
+from oracle import ldc_oracle as O, resample_oracle as RO  # noqa: E402
+from helpers import CASES, COND_CFG, T, cond_sd_np, main_sd_np  # noqa: E402
+from gpu_common import engine, rel  # noqa: E402
+
+
+@pytest.mark.parametrize("sr", [8000, 22050, 44100, 48000, 16000])
+def test_resample_matches_oracle(sr):
+    e = engine("r84", "f32")
+    x = np.random.default_rng(sr).standard_normal((2, 20000)).astype(np.float32) * 0.3
+    got = e.resample(torch.from_numpy(x), sr, 16000).cpu().numpy()
+    want = RO.resample(x, sr, 16000)
+    assert got.shape == want.shape
+    assert rel(got, want) < 1e-5            # same fp32 filter bank; only the summation order differs
+
+
+def test_cli_resamples_non_16k_input(tmp_path):
+    from scipy.io import wavfile
+    from ladiffcodec_amd import sample as cli
+    mc, u, _ = CASES["r84"]
+    synth.save_amlt(main_sd_np("r84"), str(tmp_path / "ladiff.amlt"))
+    synth.save_amlt(cond_sd_np(), str(tmp_path / "codec.amlt"))
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    sr = 22050
+    n = 7500          # -> 5443 samples at 16 kHz -> trimmed to 5120 = a latent length (160) that survives the four halvings
+    x = (0.3 * np.sin(2 * np.pi * 220.0 * np.arange(n) / sr) + 0.05 * np.random.default_rng(1).standard_normal(n)).astype(np.float32)
+    wavfile.write(str(ind / "a.wav"), sr, x)
+    args = cli.build_parser().parse_args([
+        "--model_for_cond", str(tmp_path / "codec.amlt"), "--model_path", str(tmp_path / "ladiff.amlt"), "--run_diff", "--scaling_global",
+        "--cond_bandwidth", "3", "--unet_scale_cond", "--enc_ratios", "8", "4", "--upsampling_ratios", "5", "2", "--diff_dims", "32",
+        "--input_dir", str(ind) + "/", "--output_dir", str(outd) + "/", "--midway_t", "1", "--dtype", "f32"])
+    written = cli.synthesis(args)
+    assert len(written) == 1
+    sr_out, y = wavfile.read(str(outd / "a.wav"))
+    x16 = RO.resample(x[None], sr, 16000)[0]
+    m = len(x16) // 640 * 640
+    assert sr_out == 16000 and y.shape == (m,)
+    ref = O.decode_utterances(synth.to_torch(cond_sd_np()), COND_CFG, synth.to_torch(main_sd_np("r84")), mc, u,
+                              T(x16[:m]).reshape(1, 1, m), 1, None)
+    assert rel(y, ref["wav"].numpy().reshape(-1)) < 5e-3
