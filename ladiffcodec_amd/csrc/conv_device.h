@@ -26,7 +26,7 @@ struct ConvKArgs {
   int win_rows;        // generic kernel: LDS window capacity (rows); the zero row lives at index win_rows
   int tg;              // taps staged per weight slab
   int reflect_back, reflect_fwd;
-  float* gn_sum;       // fused GroupNorm statistics target [B][gn_groups][2] (pre-zeroed) or null
+  float* gn_sum;       // fused GroupNorm statistics target [B][gn_groups][kGnPad] (pre-zeroed; [0] sum, [1] sum of squares) or null
   int gn_groups, gn_cpg;
   unsigned* colmax;    // fused column max over positions (LinearAttention k softmax): ordered-uint keys, pre-zeroed
   int colmax_lo, colmax_hi, colmax_stride;   // columns [lo, hi) -> colmax[b * stride + col - lo]
@@ -192,7 +192,7 @@ __device__ __forceinline__ void epilogue_colmax(const ConvKArgs& a, f32x16 (&acc
           }
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      if (in && lane < 32 && mx > -INFINITY) atomicMax(a.colmax + (size_t)bb * a.colmax_stride + (col - a.colmax_lo), float_order_key(mx));
+      if (in && lane < 32 && mx > -INFINITY) atomicMax(a.colmax + (size_t)bb * a.colmax_stride + (size_t)(col - a.colmax_lo), float_order_key(mx));
     }
   }
 }
@@ -255,8 +255,8 @@ __device__ __forceinline__ void epilogue_gn_stats(const ConvKArgs& a, f32x16 (&a
         }
       }
       if (col_ok && lane < 32 && (lane & (seg - 1)) == 0) {
-        atomicAdd(&a.gn_sum[((size_t)bb * a.gn_groups + g) * 2], s);
-        atomicAdd(&a.gn_sum[((size_t)bb * a.gn_groups + g) * 2 + 1], ss);
+        atomicAdd(&a.gn_sum[((size_t)bb * a.gn_groups + g) * kGnPad], s);
+        atomicAdd(&a.gn_sum[((size_t)bb * a.gn_groups + g) * kGnPad + 1], ss);
       }
     }
   }

@@ -1545,7 +1545,7 @@ struct PlanBuilder {
   }
   float* next_stats() {
     const int g = c->unet.groups;
-    return stats_pool + (size_t)(stats_used++) * B * g * 2;
+    return stats_pool + (size_t)(stats_used++) * B * g * kGnPad;
   }
   // ResnetBlock.forward (unet.py:176-192)
   // ln_g != null: the block's last kernel also writes LayerNorm(out) * ln_g to *xn_out (the PreNorm of the attention
@@ -1642,7 +1642,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const int Cc = u.cond_channels, Cx = u.channels;
   PlanBuilder pb{c, pl, &ar, B, es};
   const int n_gn = 2 * (int)(2 * u.downs.size() + 2 + 2 * u.ups.size() + 1);
-  const size_t gn_bytes = (size_t)n_gn * B * u.groups * 2 * 4;
+  const size_t gn_bytes = (size_t)n_gn * B * u.groups * kGnPad * 4;
   const size_t n_lin = c->fuse_kmax ? u.downs.size() + u.ups.size() : 1;
   const size_t lin_bytes = n_lin * B * linattn_ws_floats_per_item(u.heads, u.dim_head) * 4;
   const int sk_tiles_cap = 1024;
@@ -2744,14 +2744,16 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     std::vector<unsigned long long> h((size_t)nblk * 8);
     HIPCHK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
     double pro = 0, loop = 0, epi = 0, tab = 0, dma = 0; int n = 0;
+    unsigned long long t_first = ~0ull, t_last = 0;
     for (int b = 0; b < nblk; ++b) {
       if (!h[8 * b + 3]) continue;
+      t_first = std::min(t_first, h[8 * b]); t_last = std::max(t_last, h[8 * b + 3]);
       pro += (double)(h[8 * b + 1] - h[8 * b]); loop += (double)(h[8 * b + 2] - h[8 * b + 1]); epi += (double)(h[8 * b + 3] - h[8 * b + 2]);
       tab += (double)(h[8 * b + 4] - h[8 * b]); dma += (double)(h[8 * b + 5] - h[8 * b + 4]);
       ++n;
     }
-    if (n) fprintf(stderr, "  stamps (shader cycles per workgroup): blocks=%d prologue=%.1f (tile+copy tables %.1f, first copies issued %.1f, fragment tables %.1f) loop=%.1f epilogue=%.1f\n",
-                   n, pro / n, tab / n, dma / n, (pro - tab - dma) / n, loop / n, epi / n);
+    if (n) fprintf(stderr, "  stamps (s_memtime ticks per workgroup): blocks=%d prologue=%.1f (tile+copy tables %.1f, first copies issued %.1f, fragment tables %.1f) loop=%.1f epilogue=%.1f | first start -> last end %.0f\n",
+                   n, pro / n, tab / n, dma / n, (pro - tab - dma) / n, loop / n, epi / n, (double)(t_last - t_first));
   }
   return LDC_OK;
 }
@@ -2849,10 +2851,10 @@ extern "C" int ldc_gn_microbench(ldc_ctx* c, int dtype, int B, int L, int C, int
   DevMem keep;
   void *x = nullptr, *y = nullptr, *r = nullptr, *st = nullptr, *gb = nullptr;
   LDCCHK(keep.alloc(&x, n * es)); LDCCHK(keep.alloc(&y, n * es)); LDCCHK(keep.alloc(&r, n * es));
-  LDCCHK(keep.alloc(&st, (size_t)B * 8 * 2 * 4)); LDCCHK(keep.alloc(&gb, (size_t)4 * C * 4));
+  LDCCHK(keep.alloc(&st, (size_t)B * 8 * kGnPad * 4)); LDCCHK(keep.alloc(&gb, (size_t)4 * C * 4));
   HIPCHK(hipMemset(x, 0x3c, n * es)); HIPCHK(hipMemset(r, 0x3c, n * es));
-  std::vector<float> hs((size_t)B * 16, 1.0f), hg((size_t)4 * C, 0.5f);
-  for (size_t i = 0; i < hs.size(); i += 2) { hs[i] = 10.f; hs[i + 1] = 1e4f; }
+  std::vector<float> hs((size_t)B * 8 * kGnPad, 1.0f), hg((size_t)4 * C, 0.5f);
+  for (size_t i = 0; i < hs.size(); i += kGnPad) { hs[i] = 10.f; hs[i + 1] = 1e4f; }
   HIPCHK(hipMemcpy(st, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(gb, hg.data(), hg.size() * 4, hipMemcpyHostToDevice));
   float* g = (float*)gb;

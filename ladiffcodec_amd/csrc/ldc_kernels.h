@@ -14,6 +14,10 @@ namespace ldc {
 enum { DT_F32 = 0, DT_BF16 = 1 };
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_ELU = 2, ACT_TANH = 3, ACT_GELU = 4, ACT_SIGMOID = 5, ACT_RELU = 6 };
 enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
+// GroupNorm statistics accumulators: every (item, group) pair owns a 64-byte line ([0] = sum, [1] = sum of squares).  Packed
+// ([B][groups][2] floats) the 4800 fp32 atomics of one conv launch landed on 8 cache lines and were serialised by the L2
+// (~10 ns each: +7.7 us per launch, measured on the same conv with and without fused statistics).
+static constexpr int kGnPad = 16;
 
 inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 

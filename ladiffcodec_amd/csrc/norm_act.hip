@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x, int L, int
   if (cur_g >= 0) { atomicAdd(&red[0][cur_g], s); atomicAdd(&red[1][cur_g], ss); }
   __syncthreads();
   if (tid < groups) {
-    atomicAdd(&stats[((size_t)b * groups + tid) * 2 + 0], red[0][tid]);
-    atomicAdd(&stats[((size_t)b * groups + tid) * 2 + 1], red[1][tid]);
+    atomicAdd(&stats[((size_t)b * groups + tid) * kGnPad + 0], red[0][tid]);
+    atomicAdd(&stats[((size_t)b * groups + tid) * kGnPad + 1], red[1][tid]);
   }
 }
 
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* x, void* y, c
     for (int i = 0; i < 8; ++i) {
       const int c = v * 8 + i;
       const int g = c / cpg;
-      const float sum = stats[((size_t)b * groups + g) * 2], sq = stats[((size_t)b * groups + g) * 2 + 1];
+      const float sum = stats[((size_t)b * groups + g) * kGnPad], sq = stats[((size_t)b * groups + g) * kGnPad + 1];
       const float mean = sum * inv_n;
       const float var = fmaxf(sq * inv_n - mean * mean, 0.0f);
       const float rstd = rsqrtf(var + 1e-5f);
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
   for (int c = threadIdx.x; c < C; c += 256) {
     if (dbg & 1) { s_a[c] = 1.0f; s_b[c] = 0.5f; continue; }
     const int g = c / cpg;
-    const float mean = stats[((size_t)b * groups + g) * 2] * inv_n;
-    const float var = fmaxf(stats[((size_t)b * groups + g) * 2 + 1] * inv_n - mean * mean, 0.0f);
+    const float mean = stats[((size_t)b * groups + g) * kGnPad] * inv_n;
+    const float var = fmaxf(stats[((size_t)b * groups + g) * kGnPad + 1] * inv_n - mean * mean, 0.0f);
     const float rstd = rsqrtf(var + 1e-5f);
     float a1 = rstd * gamma[c];
     float b1 = beta[c] - mean * a1;
