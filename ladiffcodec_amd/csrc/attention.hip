@@ -325,6 +325,257 @@ __global__ __launch_bounds__(256) void linattn_out_mfma_kernel(const unsigned sh
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// LinearAttention tail in one launch (bf16 engine): out = einsum(context, softmax_d(q) * scale), to_out 1x1 conv (128 -> C) +
+// bias, channel LayerNorm, + x  (unet.py:216-222 and the Residual around it).  It replaces three launches per attention
+// (linattn_out, the to_out conv, ln_rows): at these sizes every one of them is a single round of workgroups that lives on
+// its launch boundary and its load/store latencies.
+//   phase 1  wave h = head h: the 32 x 32 context (scaled by scale / ksum) is the stationary MFMA operand, the q rows are
+//            soft-maxed in registers; the [R][128] bf16 result goes to LDS, where it is the A operand of
+//   phase 2  the to_out GEMM: wave w owns C/4 output channels of all R positions, K = 128 in eight MFMA steps, weight
+//            fragments straight from the packed conv image ([chunk][n_pad][32 bf16]) in L2, one step ahead;
+//   phase 3  bias, LayerNorm over the C channels of a position (two passes as ln_rows: mean, then centred squares; a position's
+//            channels sit in 32 lanes x NT tiles x 4 waves -> a 16-value butterfly across lanes, then LDS across waves),
+//            gain in fp32 through LDS into position-major pieces, + residual (read coalesced, issued before the reductions),
+//            one rounding to bf16, 8-byte row stores.
+// The weight fragments of a wave's channels are all requested at kernel entry (they do not depend on phase 1).
+// ---------------------------------------------------------------------------------------------
+// sum of each of the 16 values over the 32 lanes that share lane>>5; on return every lane holds the total of value
+// index (lane & 31) >> 1 (a transposing butterfly: 16 shuffles instead of 80)
+__device__ __forceinline__ float reduce16_over32(const float (&v)[16], int lane) {
+  float a8[8], a4[4], a2[2];
+  const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a8[k] = (b4 ? v[8 + k] : v[k]) + __shfl_xor(b4 ? v[k] : v[8 + k], 16);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a4[k] = (b3 ? a8[4 + k] : a8[k]) + __shfl_xor(b3 ? a8[k] : a8[4 + k], 8);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) a2[k] = (b2 ? a4[2 + k] : a4[k]) + __shfl_xor(b2 ? a4[k] : a4[2 + k], 4);
+  float a1 = (b1 ? a2[1] : a2[0]) + __shfl_xor(b1 ? a2[0] : a2[1], 2);
+  a1 += __shfl_xor(a1, 1);
+  return a1;
+}
+
+template <int C>   // output channels; 32 positions per workgroup
+__global__ __launch_bounds__(256) void linattn_tail_mfma_kernel(const unsigned short* qkv, const float* ws, size_t ws_stride, float scale,
+                                                                const unsigned short* wo, int n_pad, const float* bias, const float* gain,
+                                                                const unsigned short* resid, unsigned short* out, int L) {
+  constexpr int D = 32, HD = 128, R = 32, CPW = C / 4, NT = CPW / 32;
+  constexpr int AP = HD + 8;                  // sA pitch (bf16 elements): 272 B rows
+  constexpr int TP = CPW * 4 + 16;            // transpose pitch (bytes, fp32 values)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* sA = reinterpret_cast<unsigned short*>(smem);                   // [R][AP]
+  float* sred = reinterpret_cast<float*>(smem + (size_t)R * AP * 2);              // [4][R] partial sums of a pass
+  float* srow = sred + 4 * R;                                                      // [R] mean, then rstd
+  char* strans = smem + (size_t)R * AP * 2 + (size_t)5 * R * 4;                   // [4 waves][R][TP]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, i32 = lane & 31, g = lane >> 5;
+  const int r0 = blockIdx.x * R;
+  const float* wsb = ws + (size_t)b * ws_stride;
+  const int colw = w * CPW + i32;
+  // every weight fragment of this wave's channels (independent of phase 1: they land while the softmax runs)
+  uint4 bfr[8][NT];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      bfr[ks][j] = *reinterpret_cast<const uint4*>(wo + ((size_t)(ks >> 1) * n_pad + colw + 32 * j) * 32 + (ks & 1) * 16 + 8 * g);
+  float bv[NT], gv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { bv[j] = bias[colw + 32 * j]; gv[j] = gain[colw + 32 * j]; }
+  // ---- phase 1: head w ----
+  {
+    const int h = w;
+    const int n = r0 + i32;
+    uint4 qq[2];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      if (n < L) qq[sx] = *reinterpret_cast<const uint4*>(qkv + ((size_t)b * L + n) * (3 * HD) + h * D + 16 * sx + 8 * g);
+      else qq[sx] = make_uint4(0, 0, 0, 0);
+    }
+    uint4 af[2];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      unsigned wv[4];
+#pragma unroll
+      for (int m = 0; m < 8; m += 2) {
+        const int d0 = 16 * sx + 8 * g + m;
+        const float c0 = wsb[2 * HD + (size_t)h * D * D + d0 * D + i32] * (scale / wsb[HD + h * D + d0]);
+        const float c1 = wsb[2 * HD + (size_t)h * D * D + (d0 + 1) * D + i32] * (scale / wsb[HD + h * D + d0 + 1]);
+        wv[m >> 1] = (unsigned)af2bf(c0) | ((unsigned)af2bf(c1) << 16);
+      }
+      af[sx] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+    float x[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const unsigned wv[4] = {qq[sx].x, qq[sx].y, qq[sx].z, qq[sx].w};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        x[8 * sx + 2 * m] = abf2f((unsigned short)(wv[m] & 0xffffu));
+        x[8 * sx + 2 * m + 1] = abf2f((unsigned short)(wv[m] >> 16));
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) mx = fmaxf(mx, x[m]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { x[m] = __expf(x[m] - mx); sum += x[m]; }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    uint4 bq[2];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      unsigned wv[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        wv[m] = (unsigned)af2bf(x[8 * sx + 2 * m] * inv) | ((unsigned)af2bf(x[8 * sx + 2 * m + 1] * inv) << 16);
+      bq[sx] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+    lf32x16 acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    acc1 = mfma_bf16(af[0], bq[0], acc1);
+    acc1 = mfma_bf16(af[1], bq[1], acc1);
+    unsigned short* arow = sA + (size_t)i32 * AP + h * D;   // position i32, channels of head h
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const unsigned lo = (unsigned)af2bf(acc1[4 * rr]) | ((unsigned)af2bf(acc1[4 * rr + 1]) << 16);
+      const unsigned hi = (unsigned)af2bf(acc1[4 * rr + 2]) | ((unsigned)af2bf(acc1[4 * rr + 3]) << 16);
+      *reinterpret_cast<uint2*>(arow + 8 * rr + 4 * g) = make_uint2(lo, hi);
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: to_out GEMM, wave w -> channels [w * CPW, (w + 1) * CPW) ----
+  lf32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const uint4 afr = *reinterpret_cast<const uint4*>(sA + (size_t)i32 * AP + 16 * ks + 8 * g);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = mfma_bf16(afr, bfr[ks][j], acc[j]);
+  }
+  // the residual rows in the layout of the final sweep (16-byte fp32 pieces of a position's channels -> 8 bytes of bf16):
+  // issued now, consumed after the LayerNorm reductions
+  constexpr int LPR = CPW / 4;        // lanes per position in the final sweep
+  constexpr int RPS = 64 / LPR;       // positions per sweep
+  constexpr int NSW = R / RPS;
+  const int rsub = lane / LPR, piece = lane % LPR;
+  uint2 rres[NSW];
+#pragma unroll
+  for (int sw = 0; sw < NSW; ++sw) {
+    const int n = r0 + sw * RPS + rsub;
+    rres[sw] = n < L ? *reinterpret_cast<const uint2*>(resid + ((size_t)b * L + n) * C + w * CPW + piece * 4) : make_uint2(0, 0);
+  }
+  // ---- phase 3: bias, LayerNorm over channels, gain, residual ----
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] += bv[j];
+  const int rr = i32 >> 1;
+  const int my_row = (rr & 3) + 8 * (rr >> 2) + 4 * g;   // the position whose total reduce16_over32 leaves in this lane
+  {   // pass 1: mean
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) sacc += acc[j][r];
+      v[r] = sacc;
+    }
+    const float tot = reduce16_over32(v, lane);
+    if ((lane & 1) == 0) sred[w * R + my_row] = tot;
+  }
+  __syncthreads();
+  if (tid < R) srow[tid] = (sred[tid] + sred[R + tid] + sred[2 * R + tid] + sred[3 * R + tid]) * (1.0f / (float)C);
+  __syncthreads();
+  float mean[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mean[r] = srow[(r & 3) + 8 * (r >> 2) + 4 * g];
+  {   // pass 2: centred squares
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { const float d = acc[j][r] - mean[r]; sacc = fmaf(d, d, sacc); }
+      v[r] = sacc;
+    }
+    const float tot = reduce16_over32(v, lane);
+    if ((lane & 1) == 0) sred[w * R + my_row] = tot;
+  }
+  __syncthreads();
+  if (tid < R) srow[tid] = rsqrtf((sred[tid] + sred[R + tid] + sred[2 * R + tid] + sred[3 * R + tid]) * (1.0f / (float)C) + 1e-5f);
+  __syncthreads();
+  char* tw = strans + (size_t)w * R * TP;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+    const float rstd = srow[row];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      reinterpret_cast<float*>(tw + (size_t)row * TP)[32 * j + i32] = (acc[j][r] - mean[r]) * rstd * gv[j];
+  }
+  // the same wave wrote and reads its transpose region: LDS executes a wave's operations in order
+#pragma unroll
+  for (int sw = 0; sw < NSW; ++sw) {
+    const int row = sw * RPS + rsub;
+    const int n = r0 + row;
+    const float4 y = *reinterpret_cast<const float4*>(tw + (size_t)row * TP + piece * 16);
+    const float o0 = y.x + abf2f((unsigned short)(rres[sw].x & 0xffffu)), o1 = y.y + abf2f((unsigned short)(rres[sw].x >> 16));
+    const float o2 = y.z + abf2f((unsigned short)(rres[sw].y & 0xffffu)), o3 = y.w + abf2f((unsigned short)(rres[sw].y >> 16));
+    const uint2 o = make_uint2((unsigned)af2bf(o0) | ((unsigned)af2bf(o1) << 16), (unsigned)af2bf(o2) | ((unsigned)af2bf(o3) << 16));
+    if (n < L) *reinterpret_cast<uint2*>(out + ((size_t)b * L + n) * C + w * CPW + piece * 4) = o;
+  }
+}
+
+template <int C>
+static hipError_t launch_tail_cfg(const void* qkv, const float* ws, size_t wss, float scale, const void* wo, int n_pad, const float* bias,
+                                  const float* gain, const void* resid, void* out, int B, int L, hipStream_t s) {
+  constexpr int R = 32, CPW = C / 4;
+  const size_t lds = (size_t)R * (128 + 8) * 2 + (size_t)5 * R * 4 + (size_t)4 * R * (CPW * 4 + 16);
+  auto kern = linattn_tail_mfma_kernel<C>;
+  static bool lds_opt_in = false;   // one-off, outside any stream capture (the first step of a plan runs eagerly)
+  if (!lds_opt_in) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    lds_opt_in = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((L + R - 1) / R, B), dim3(256), lds, s, reinterpret_cast<const unsigned short*>(qkv), ws, wss, scale,
+                     reinterpret_cast<const unsigned short*>(wo), n_pad, bias, gain, reinterpret_cast<const unsigned short*>(resid),
+                     reinterpret_cast<unsigned short*>(out), L);
+  return hipGetLastError();
+}
+
+bool linattn_tail_supported(int dt, int heads, int dim_head, int C) {
+  return dt == DT_BF16 && heads == 4 && dim_head == 32 && (C == 256 || C == 512 || C == 1024);
+}
+
+// context pass only (the k column maxima are already in `ws`: fused into the qkv conv's epilogue)
+hipError_t launch_linattn_ctx(int dt, const void* qkv, float* ws, int B, int L, int heads, int dim_head, hipStream_t s) {
+  if (dt != DT_BF16 || heads != 4 || dim_head != 32) return hipErrorInvalidValue;
+  const size_t wss = linattn_ws_per_item(heads, dim_head);
+  hipLaunchKernelGGL(linattn_ctx_mfma_kernel<64>, dim3((L + 63) / 64, B), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(qkv), ws, L, wss);
+  return hipGetLastError();
+}
+
+// out = LayerNorm_C(to_out(linear-attention output)) * gain + resid, from the qkv rows and the finished context in `ws`
+hipError_t launch_linattn_tail(int dt, const void* qkv, const float* ws, const void* wo_packed, int n_pad, const float* bias, const float* gain,
+                               const void* resid, void* out, int B, int L, int heads, int dim_head, int C, hipStream_t s) {
+  if (!linattn_tail_supported(dt, heads, dim_head, C) || !bias || !gain || !resid) return hipErrorInvalidValue;
+  const size_t wss = linattn_ws_per_item(heads, dim_head);
+  const float scale = 1.0f / sqrtf((float)dim_head);
+  if (C == 256) return launch_tail_cfg<256>(qkv, ws, wss, scale, wo_packed, n_pad, bias, gain, resid, out, B, L, s);
+  if (C == 512) return launch_tail_cfg<512>(qkv, ws, wss, scale, wo_packed, n_pad, bias, gain, resid, out, B, L, s);
+  return launch_tail_cfg<1024>(qkv, ws, wss, scale, wo_packed, n_pad, bias, gain, resid, out, B, L, s);
+}
+
 size_t linattn_ws_floats_per_item(int heads, int dim_head) { return linattn_ws_per_item(heads, dim_head); }
 
 // kmax_fused: the caller zeroed `ws` before the qkv conv and that conv's epilogue already produced the column

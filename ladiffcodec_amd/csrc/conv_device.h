@@ -11,6 +11,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 static constexpr int kRowBytes = 64;   // bytes of K (channels) per LDS row per chunk: 32 bf16 or 16 f32
 
+// Division by a launch-invariant divisor (Granlund-Montgomery, exact for every 32-bit n): gfx950 has no integer divide, so
+// every `/` by a run-time value is a ~30-instruction reciprocal sequence -- ten of them sat in the conv prologue in front of
+// the first copy.  The host prepares (m, sh1, sh2); the device spends a mul_hi, a sub, an add and two shifts.
+struct FastDivU { unsigned m, sh1, sh2; };
+inline FastDivU make_fastdiv(unsigned d) {
+  if (d < 1) d = 1;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  const unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+  FastDivU r;
+  r.m = (unsigned)m; r.sh1 = l < 1 ? l : 1u; r.sh2 = l > 0 ? l - 1 : 0u;
+  return r;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDivU& d) {
+  const unsigned t = __umulhi(d.m, n);
+  return (t + ((n - t) >> d.sh1)) >> d.sh2;
+}
+
 struct ConvKArgs {
   const char* x1;
   const char* x2;
@@ -21,6 +39,7 @@ struct ConvKArgs {
   int C1, C2;          // channels of the two inputs
   int n, n_pad;
   int B, L_in, L_rows, L_final, y_ld;
+  FastDivU lrows_div;  // division by L_rows
   int taps, stride, dil, pad_left, ups, pad_mode, pre_act, post_act;
   int tr_stride, tr_cout, tr_trim_left;
   int win_rows;        // generic kernel: LDS window capacity (rows); the zero row lives at index win_rows
@@ -111,11 +130,11 @@ __device__ __forceinline__ int gather_row(const ConvKArgs& a, int b, int l, int 
 __device__ __forceinline__ void tile_window(const ConvKArgs& a, int m0, int BM, int M, int& R_lo, int& R_hi) {
   const int leff = a.L_in << a.ups;
   const int m_last = min(m0 + BM, M) - 1;
-  int b = m0 / a.L_rows, l = m0 - b * a.L_rows;
+  int b = (int)fdiv((unsigned)m0, a.lrows_div), l = m0 - b * a.L_rows;
   int u = l * a.stride - a.pad_left;
   u = max(0, min(u, leff - 1));
   R_lo = b * a.L_in + (u >> a.ups) - a.reflect_back;
-  b = m_last / a.L_rows;
+  b = (int)fdiv((unsigned)m_last, a.lrows_div);
   l = m_last - b * a.L_rows;
   u = l * a.stride + (a.taps - 1) * a.dil - a.pad_left;
   u = max(0, min(u, leff - 1));
@@ -169,8 +188,8 @@ template <typename T, int TM, int TN>
 __device__ __forceinline__ void epilogue_colmax(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int m0, int BM,
                                                 int M) {
   const int lane = threadIdx.x & 63;
-  const int b_first = m0 / a.L_rows;
-  const int b_last = (min(m0 + BM, M) - 1) / a.L_rows;
+  const int b_first = (int)fdiv((unsigned)m0, a.lrows_div);
+  const int b_last = (int)fdiv((unsigned)(min(m0 + BM, M) - 1), a.lrows_div);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = col0 + j * 32;
@@ -206,8 +225,8 @@ template <int TM, int TN>
 __device__ __forceinline__ void epilogue_gn_stats(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int m0,
                                                   int BM, int M) {
   const int lane = threadIdx.x & 63;
-  const int b_first = m0 / a.L_rows;
-  const int b_last = (min(m0 + BM, M) - 1) / a.L_rows;
+  const int b_first = (int)fdiv((unsigned)m0, a.lrows_div);
+  const int b_last = (int)fdiv((unsigned)(min(m0 + BM, M) - 1), a.lrows_div);
   const int cpg = a.gn_cpg;
   const int seg = min(cpg, 32);
 #pragma unroll

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + (wm * TM + i) * 32 + (lane & 31);
     if (m < M) {
-      row_b[i] = m / a.L_rows;
+      row_b[i] = (int)fdiv((unsigned)m, a.lrows_div);
       row_l[i] = m - row_b[i] * a.L_rows;
     } else {
       row_b[i] = -1;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
       for (int r = 0; r < 16; ++r) {
         const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
         if (m >= M) continue;
-        const int b = m / a.L_rows, q = m - b * a.L_rows;
+        const int b = (int)fdiv((unsigned)m, a.lrows_div), q = m - b * a.L_rows;
         const int pos = q * a.tr_stride + tr_p - a.tr_trim_left;
         if (pos < 0 || pos >= a.L_final) continue;
         const float v = act_apply(acc[i][j][r] + bv, a.post_act);
@@ -368,6 +368,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   a.y = (char*)c.y; a.residual = (const char*)c.residual;
   a.C1 = ly.cin1; a.C2 = ly.cin2; a.n = ly.n; a.n_pad = ly.n_pad;
   a.B = c.B; a.L_in = c.L_in; a.L_rows = c.L_rows; a.L_final = c.L_final; a.y_ld = c.y_ld;
+  a.lrows_div = make_fastdiv((unsigned)std::max(1, c.L_rows));
   a.taps = ly.taps; a.stride = ly.stride; a.dil = ly.dil; a.pad_left = ly.pad_left; a.ups = ly.ups;
   a.pad_mode = ly.pad_mode; a.pre_act = ly.pre_act; a.post_act = ly.post_act;
   a.tr_stride = ly.tr_stride; a.tr_cout = ly.tr_cout; a.tr_trim_left = ly.tr_trim_left;

@@ -245,6 +245,7 @@ struct ldc_ctx {
   int side_streams = 0;
   int fuse_kmax = 1;
   int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
+  int fuse_attn_tail = 1;       // LinearAttention out + to_out conv + LayerNorm + residual in one launch (bf16 engine)
   int fuse_gn_stats = 1;
   int strip_mode = 0;           // LDC_STRIP: 0 never (default: measured 5 % slower end to end) | 1 when the grid fills the chip | 2 whenever eligible
   int strip_min_wgs = 96;       // LDC_STRIP_MIN: workgroups (items x strips) from which mode 1 picks the strip form
@@ -950,6 +951,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
   c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
+  c->fuse_attn_tail = getenv("LDC_NO_TAIL_FUSE") ? 0 : 1;
   c->tune.force_generic = getenv("LDC_CONV_V1") ? 1 : 0;
   c->tune.small_max = env_int("LDC_CONV_SMALL_TILES", c->tune.small_max);
   c->tune.medium_max = env_int("LDC_CONV_MEDIUM_TILES", c->tune.medium_max);
@@ -1610,6 +1612,17 @@ struct PlanBuilder {
           2.0 * rows * a.dim * es);
     if (linear) {
       const size_t wss = linattn_ws_floats_per_item(H, Dh);
+      if (c->fuse_kmax && c->fuse_attn_tail && !a.out.w8 && linattn_tail_supported(dt, H, Dh, a.dim)) {
+        // three launches: qkv conv (+ k column max) -> context -> tail (out, to_out conv, LayerNorm, + x)
+        conv(a.qkv, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
+        add([=](hipStream_t s) { return launch_linattn_ctx(dt, qkv, ws, Bn, L, H, Dh, s); }, false, 0, LDC_CLASS_LINATTN, 2.0 * rows * hid * es);
+        const int dim = a.dim;
+        info = "tail_c" + std::to_string(dim) + "_L" + std::to_string(L) + "_B" + std::to_string(B);
+        add([=](hipStream_t s) {
+          return launch_linattn_tail(dt, qkv, ws, ap->out.w, ap->out.n_pad, ap->out.bias, ap->out_g, x, out, Bn, L, H, Dh, dim, s);
+        }, false, 2.0 * rows * hid * dim, LDC_CLASS_LINATTN, (1.0 * hid + 2.0 * dim) * rows * es);
+        return out;
+      }
       if (c->fuse_kmax) {
         conv(a.qkv, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
         add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, true, s); }, false, 0, LDC_CLASS_LINATTN,

@@ -152,6 +152,11 @@ hipError_t launch_act(int dt, const void* x, void* y, int64_t n, int act, hipStr
 hipError_t launch_linattn(int dt, const void* qkv, void* out, float* ctx_ws, int B, int L, int heads, int dim_head,
                           bool kmax_fused, hipStream_t s);
 size_t linattn_ws_floats_per_item(int heads, int dim_head);
+// LinearAttention in three launches (bf16 engine): qkv conv (+ k column max) -> context -> tail (out + to_out conv + LayerNorm + residual)
+bool linattn_tail_supported(int dt, int heads, int dim_head, int C);
+hipError_t launch_linattn_ctx(int dt, const void* qkv, float* ctx_ws, int B, int L, int heads, int dim_head, hipStream_t s);
+hipError_t launch_linattn_tail(int dt, const void* qkv, const float* ctx_ws, const void* wo_packed, int n_pad, const float* bias, const float* gain,
+                               const void* resid, void* out, int B, int L, int heads, int dim_head, int C, hipStream_t s);
 hipError_t launch_attn_full(int dt, const void* qkv, void* out, int B, int L, int heads, int dim_head, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
