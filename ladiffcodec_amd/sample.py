@@ -68,9 +68,12 @@ _FLAGS: List[Tuple[str, dict]] = [
 # additions of this implementation
 _EXTRA: List[Tuple[str, dict]] = [
     ("--midway_t", dict(type=int, default=100, help="reverse-diffusion steps (literal 100 in the reference)")),
-    ("--dtype", dict(type=str, default="bf16", choices=["bf16", "f32"], help="UNet compute dtype on the GPU")),
+    ("--dtype", dict(type=str, default="bf16", choices=["bf16", "f32", "fp8"], help="UNet compute dtype on the GPU (fp8: e4m3 conv weights, bf16 math)")),
     ("--batch_size", dict(type=int, default=32, help="utterances decoded per engine call")),
     ("--seed", dict(type=int, default=0, help="seed of the device noise stream (rank r uses seed + r)")),
+    ("--chunk_sec", dict(type=float, default=0.0, help="long-form mode (BASELINE config 5): mono recordings longer than this are "
+                                                        "decoded as chunks of this length batched together, the chunks' raw decoder "
+                                                        "outputs are joined and normalised over the whole recording; 0 = whole files")),
 ]
 
 
@@ -177,12 +180,78 @@ def plan_batches(lengths: List[int], channels: List[int], rank: int, world: int,
     return work
 
 
+_CHUNK_QUANTUM = 1280     # samples: a chunk holds whole condition frames (320) and a latent length divisible by 8 (hop 32 x 8)
+
+
+def plan_chunks(n_samples: int, chunk: int) -> List[Tuple[int, int]]:
+    """[(start, length)] of a recording cut into `chunk`-sample pieces; the tail keeps whole quanta (a shorter last chunk),
+    what is left of it (< 1280 samples = 80 ms) is dropped as the reference drops the sub-frame tail (sample.py:87-88)."""
+    out, pos = [], 0
+    while n_samples - pos >= chunk:
+        out.append((pos, chunk)); pos += chunk
+    tail = (n_samples - pos) // _CHUNK_QUANTUM * _CHUNK_QUANTUM
+    if tail > 0:
+        out.append((pos, tail))
+    return out
+
+
+def decode_long_files(eng, files: List[str], wavs, inp_args, rank: int, world: int, local_rank: int) -> List[str]:
+    """Long-form mode: every chunk of every recording of this rank is one batch item (equal-length chunks share engine calls
+    across recordings); the chunks' latents go through the decoder, the raw waveforms are joined per recording and the
+    reference's output normalisation (sample.py:133-134) runs once over the whole recording."""
+    import torch
+    from scipy.io import wavfile
+    from . import lib as L, parallel
+    chunk = max(_CHUNK_QUANTUM, int(round(inp_args.chunk_sec * 16000)) // _CHUNK_QUANTUM * _CHUNK_QUANTUM)
+    mine = parallel.shard_utterances([w.shape[-1] for w in wavs], rank, world)
+    pieces: Dict[int, List[Tuple[int, int, int]]] = {}            # chunk length -> [(file, order, start)]
+    nchunks = {}
+    for i in mine:
+        plan = plan_chunks(wavs[i].shape[-1], chunk)
+        nchunks[i] = len(plan)
+        for k, (st, ln) in enumerate(plan):
+            pieces.setdefault(ln, []).append((i, k, st))
+    dev = torch.device("cuda", local_rank)
+    raw: Dict[int, List] = {i: [None] * nchunks[i] for i in mine}
+    for ln, items in sorted(pieces.items(), reverse=True):
+        for s in range(0, len(items), inp_args.batch_size):
+            part = items[s:s + inp_args.batch_size]
+            batch = torch.from_numpy(np.stack([wavs[i][0, st:st + ln] for i, _, st in part])[:, None, :])
+            stages = eng.decode(batch.to(dev), inp_args.midway_t, noise=None, per_item=True, want_stages=True)
+            wav_raw = eng.decode_latents(L.MODEL_MAIN, stages["latents"])          # un-normalised decoder output
+            for j, (i, k, _) in enumerate(part):
+                raw[i][k] = wav_raw[j:j + 1]
+    written = []
+    for i in mine:
+        if not raw[i]:
+            continue
+        whole = eng.output_normalise(torch.cat(raw[i], dim=-1), per_item=False)
+        if not bool(torch.isfinite(whole).all()):
+            raise RuntimeError(f"non-finite audio decoded for {files[i]}")
+        path = output_path(files[i], inp_args.input_dir, inp_args.output_dir)
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        wavfile.write(path, 16000, np.ascontiguousarray(whole.cpu().numpy()[0, 0]))
+        written.append(path)
+    return written
+
+
 def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_rank: int) -> List[str]:
     import torch
     from scipy.io import wavfile
     wavs = [read_wav_16k(f, eng if hasattr(eng, "resample") else None) for f in files]
     keep = [i for i, w in enumerate(wavs) if w.shape[-1] // 640 * 640 > 0]                   # sample.py:87-88
     files, wavs = [files[i] for i in keep], [wavs[i] for i in keep]
+    chunk_sec = float(getattr(inp_args, "chunk_sec", 0.0) or 0.0)
+    if chunk_sec > 0:
+        # recordings longer than a chunk (mono) take the long-form path, everything else the reference's whole-file path
+        is_long = [w.shape[0] == 1 and w.shape[-1] > int(round(chunk_sec * 16000)) for w in wavs]
+        long_f = [f for f, m in zip(files, is_long) if m]
+        long_w = [w for w, m in zip(wavs, is_long) if m]
+        files = [f for f, m in zip(files, is_long) if not m]
+        wavs = [w for w, m in zip(wavs, is_long) if not m]
+        written_long = decode_long_files(eng, long_f, long_w, inp_args, rank, world, local_rank) if long_f else []
+    else:
+        written_long = []
     lengths = [w.shape[-1] for w in wavs]
     channels = [w.shape[0] for w in wavs]
     written = []
@@ -203,7 +272,7 @@ def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_r
             data = out[:, 0, :].T if joint else out[k, 0]                                     # [T, channels] | [T]
             wavfile.write(path, 16000, np.ascontiguousarray(data))
             written.append(path)
-    return written
+    return written_long + written
 
 
 def main(argv=None):

@@ -31,7 +31,7 @@ def test_cli_flags_and_defaults_match_reference():
         assert k in ns, k
         assert ns[k] == v, (k, ns[k], v)
     assert ns["midway_t"] == 100                      # the reference's literal (sample.py:69)
-    assert set(ns) - set(REFERENCE_DEFAULTS) == {"midway_t", "dtype", "batch_size", "seed"}
+    assert set(ns) - set(REFERENCE_DEFAULTS) == {"midway_t", "dtype", "batch_size", "seed", "chunk_sec"}
 
 
 def test_cli_readme_invocation_parses():
@@ -155,3 +155,55 @@ def test_plan_batches_properties():
             assert joint == (channels[idxs[0]] > 1) and (not joint or len(idxs) == 1)
             seen += idxs
     assert sorted(seen) == list(range(len(lengths)))
+
+
+def test_long_form_chunk_plan_and_reassembly(tmp_path, monkeypatch):
+    """--chunk_sec (BASELINE config 5): a 30 s recording becomes 12 chunks of 2.4 s + a shorter tail, chunks of equal length
+    batch together across recordings, the raw decoder outputs are joined in order and normalised ONCE per recording; short
+    and multi-channel files keep the whole-file path."""
+    import torch
+    from scipy.io import wavfile
+    from ladiffcodec_amd import sample
+    assert sample.plan_chunks(480000, 38400) == [(k * 38400, 38400) for k in range(12)] + [(460800, 19200)]
+    assert sample.plan_chunks(38400 + 1279, 38400) == [(0, 38400)]                       # < 80 ms of tail: dropped
+    assert sample.plan_chunks(2560 + 1280, 2560) == [(0, 2560), (2560, 1280)]
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir(); outd.mkdir()
+    rng = np.random.default_rng(1)
+    spec_files = {"long1.wav": (1, 2560 * 3 + 1280 + 7), "long2.wav": (1, 2560 * 2), "short.wav": (1, 1920), "st.wav": (2, 2560 * 4)}
+    for name, (ch, n) in spec_files.items():
+        x = (rng.standard_normal((n, ch)) * 0.1).astype(np.float32)
+        wavfile.write(str(ind / name), 16000, x[:, 0] if ch == 1 else x)
+
+    class Stub:
+        def __init__(self):
+            self.calls, self.norm_calls = [], []
+        def decode(self, batch, n_steps, noise=None, per_item=False, want_stages=False):
+            self.calls.append((tuple(batch.shape), bool(per_item), bool(want_stages)))
+            return {"latents": batch * 2.0} if want_stages else batch * 0.5
+        def decode_latents(self, which, z):
+            return z + 1.0                                                                  # "raw decoder output"
+        def output_normalise(self, wav, per_item=False):
+            self.norm_calls.append((tuple(wav.shape), bool(per_item)))
+            return wav * 0.25
+
+    class A:
+        pass
+    a = A(); a.batch_size = 4; a.midway_t = 3; a.input_dir = str(ind) + "/"; a.output_dir = str(outd) + "/"; a.chunk_sec = 2560 / 16000.0
+    monkeypatch.setattr(torch.Tensor, "to", lambda self, *x, **k: self)                     # no GPU here
+    eng = Stub()
+    files = sorted(str(ind / n) for n in spec_files)
+    written = sample.decode_files(eng, files, a, 0, 1, 0)
+    assert sorted(written) == sorted(str(outd / n) for n in spec_files)
+    # long1: 3 chunks of 2560 + tail 1280; long2: exactly 2 chunks is NOT longer than... (5120 > 2560 -> long): 2 chunks
+    long_calls = [c for c in eng.calls if c[2]]
+    assert sorted(c[0] for c in long_calls) == [(1, 1, 1280), (4, 1, 2560), (1, 1, 2560)] or \
+        sorted(c[0] for c in long_calls) == sorted([(4, 1, 2560), (1, 1, 2560), (1, 1, 1280)])
+    assert all(c[1] for c in long_calls)
+    assert sorted(eng.norm_calls) == [((1, 1, 2560 * 2), False), ((1, 1, 2560 * 3 + 1280), False)]   # once per recording
+    sr, y = wavfile.read(str(outd / "long1.wav"))
+    src = wavfile.read(str(ind / "long1.wav"))[1]
+    assert y.shape == (2560 * 3 + 1280,)
+    np.testing.assert_allclose(y, (src[:y.shape[0]] * 2.0 + 1.0) * 0.25, rtol=1e-6, atol=1e-7)   # chunks joined in order
+    whole = [c for c in eng.calls if not c[2]]
+    assert ((2, 1, 2560 * 4), False, False) in whole and ((1, 1, 1920), True, False) in whole       # stereo / short: whole-file path

@@ -47,3 +47,36 @@ def test_cli_resamples_non_16k_input(tmp_path):
     ref = O.decode_utterances(synth.to_torch(cond_sd_np()), COND_CFG, synth.to_torch(main_sd_np("r84")), mc, u,
                               T(x16[:m]).reshape(1, 1, m), 1, None)
     assert rel(y, ref["wav"].numpy().reshape(-1)) < 5e-3
+
+
+def test_cli_long_form_chunks_against_oracle(tmp_path):
+    """--chunk_sec (BASELINE config 5): a recording of 2 chunks + a shorter tail through the CLI; every chunk's raw decoder
+    output must equal the oracle's for that chunk decoded alone, and the normalisation must run over the joined recording."""
+    from scipy.io import wavfile
+    from ladiffcodec_amd import sample as cli
+    mc, u, _ = CASES["r84"]
+    synth.save_amlt(main_sd_np("r84"), str(tmp_path / "ladiff.amlt"))
+    synth.save_amlt(cond_sd_np(), str(tmp_path / "codec.amlt"))
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    chunk, tail = 5120, 2560
+    n = 2 * chunk + tail + 300
+    t = np.arange(n) / 16000.0
+    x = (0.3 * np.sin(2 * np.pi * 180.0 * t) + 0.1 * np.sin(2 * np.pi * 1230.0 * t)).astype(np.float32)
+    wavfile.write(str(ind / "long.wav"), 16000, x)
+    args = cli.build_parser().parse_args([
+        "--model_for_cond", str(tmp_path / "codec.amlt"), "--model_path", str(tmp_path / "ladiff.amlt"), "--run_diff", "--scaling_global",
+        "--cond_bandwidth", "3", "--unet_scale_cond", "--enc_ratios", "8", "4", "--upsampling_ratios", "5", "2", "--diff_dims", "32",
+        "--input_dir", str(ind) + "/", "--output_dir", str(outd) + "/", "--midway_t", "1", "--dtype", "f32",
+        "--chunk_sec", str(chunk / 16000.0)])
+    written = cli.synthesis(args)
+    assert len(written) == 1
+    sr_out, y = wavfile.read(str(outd / "long.wav"))
+    assert sr_out == 16000 and y.shape == (2 * chunk + tail,)
+    sdc, sdm = synth.to_torch(cond_sd_np()), synth.to_torch(main_sd_np("r84"))
+    raws = []
+    for st, ln in ((0, chunk), (chunk, chunk), (2 * chunk, tail)):
+        ref = O.decode_utterances(sdc, COND_CFG, sdm, mc, u, T(x[st:st + ln]).reshape(1, 1, ln), 1, None, per_item=True)
+        raws.append(ref["wav_raw"])                                    # un-normalised decoder output of the chunk
+    whole = O.output_normalise(torch.cat(raws, dim=-1))
+    assert rel(y, whole.numpy().reshape(-1)) < 5e-3

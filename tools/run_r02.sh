@@ -24,6 +24,7 @@ if [[ $STAGE == all || $STAGE == pmc ]]; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc2_FETCH -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $O/pmc2_FETCH.log 2>&1)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc2_WRITE -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $O/pmc2_WRITE.log 2>&1)
   python tools/pmc_traffic.py $O/pmc2_FETCH $O/pmc2_WRITE $O/conv_traffic_r02.json
+  python tools/pmc_classes.py $O/pmc2_FETCH $O/pmc2_WRITE $O/conv_pmc_classes_r02.md > /dev/null
   find $O/pmc2_FETCH $O/pmc2_WRITE -name "*.csv" -size +20M -delete
   cat $O/conv_traffic_r02.json
 fi
