@@ -103,6 +103,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the CPU-oracle sample (SURVEY 8d: B = 4)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the supplementary two-batches-in-flight measurement")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="batches decoded concurrently (default 1 = the metric's reading: one batch of the config's size at a time). "
+                         "n > 1: n engines on n streams, every batch as ONE chain; steps are dealt round-robin and all K finish inside "
+                         "the timed region (supplementary number, see DESIGN.md section 7)")
     args = ap.parse_args()
     args.batch = args.batch or (13 if args.config == "c5" else 32)
     args.dtype = args.dtype or ("fp8" if args.config == "c5" else "bf16")
@@ -146,24 +151,42 @@ def main():
 
     log(f"rank {rank}/{world}: checkpoints ready ({len(sd_main)} + {len(sd_cond)} tensors)")
     from ladiffcodec_amd.model import Engine
-    eng = Engine(mc, u, cc, dtype=args.dtype, device=local_rank, noise_seed=4321 + rank)
-    eng.load_state_dict(L.MODEL_MAIN, sd_main)
-    eng.load_state_dict(L.MODEL_COND, sd_cond)
-    eng.finalize(strict=True)
+    n_fl = max(1, args.in_flight)
+    if n_fl > 1:
+        os.environ["LDC_NO_SPLIT"] = "1"      # read at ldc_create: with several batches in flight each batch is one chain
+    engines, slot_streams = [], []
+    for k in range(n_fl):
+        e_k = Engine(mc, u, cc, dtype=args.dtype, device=local_rank, noise_seed=4321 + rank + 1000 * k)
+        e_k.load_state_dict(L.MODEL_MAIN, sd_main)
+        e_k.load_state_dict(L.MODEL_COND, sd_cond)
+        e_k.finalize(strict=True)
+        engines.append(e_k)
+        slot_streams.append(torch.cuda.Stream(device=dev) if n_fl > 1 else None)
+    eng = engines[0]
     log("weights folded/packed/uploaded")
 
     B = args.batch
     wav = torch.from_numpy(synth.synthetic_wav(B, T, seed=1234 + rank)).to(dev)   # resident in HBM before timing
 
+    step_no = [0]
+
     def step():
-        out = eng.decode(wav, N, noise=None, per_item=True)
-        parallel.gather_results(out, world)      # RCCL all_gather of the decoded waveforms (no-op without a process group)
+        k = step_no[0] % n_fl
+        step_no[0] += 1
+        if n_fl == 1:
+            out = eng.decode(wav, N, noise=None, per_item=True)
+            parallel.gather_results(out, world)      # RCCL all_gather of the decoded waveforms (no-op without a process group)
+            return out
+        with torch.cuda.stream(slot_streams[k]):
+            out = engines[k].decode(wav, N, noise=None, per_item=True)
+            parallel.gather_results(out, world)
         return out
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, n_fl if args.warmup else 0)):     # every engine captures its graphs before the timed region
         step()
         torch.cuda.synchronize(dev)
         log(f"warmup {i} done")
+    step_no[0] = 0
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
@@ -187,6 +210,7 @@ def main():
                                f"{N}-step DDPM, batch={B}x{T / 16000.0:.1f} s utterances per GPU", "name": args.config,
                    "global_batch": world * B, "latent_len": T // mc.hop_length, "denoise_steps": N,
                    "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                   "batches_in_flight": n_fl,
                    "parallelism": f"dp{world} (utterance-sharded, no data-path collective)"},
     }
 
@@ -199,8 +223,11 @@ def main():
         ms, launches, flops = eng.profile_read()
         eng.profile(False)
         log(f"profile pass: {launches} conv launches, {ms:.1f} ms")
-        # the engine decodes the batch as two halves (two streams): account the launches as they are issued
-        parts = [B // 2, B - B // 2] if B >= 2 else [B]
+        # the engine decodes the batch as independent chains on their own streams (ldc_api.cpp get_halves: two by default;
+        # LDC_SPLIT / LDC_NO_SPLIT override): account the launches as they are issued
+        nparts = 1 if os.environ.get("LDC_NO_SPLIT") else (int(os.environ["LDC_SPLIT"]) if os.environ.get("LDC_SPLIT") else min(2, B))
+        nparts = max(1, min(nparts, B))
+        parts = [B * (k + 1) // nparts - B * k // nparts for k in range(nparts)]
         step_flops = step_bytes = 0.0
         for pb in parts:
             f_, b_ = eng.unet_step_cost(pb, T // mc.hop_length)
@@ -245,25 +272,24 @@ def main():
         eng.decode(wav, N, noise=None, per_item=True)
         torch.cuda.synchronize(dev)
         wall_ms = 1000.0 * (time.perf_counter() - t1)
-        nparts = 2 if B >= 2 else 1
         tl = eng.timeline(N, nparts)
         eng.timeline_enable(False)
         span = max(float(a[:, 1].max()) for a in tl) - min(float(a[:, 0].min()) for a in tl)
         busy = [float((a[:, 1] - a[:, 0]).sum()) for a in tl]
         both = 0.0
-        if nparts == 2:
+        if nparts >= 2:
             ev = sorted([(float(b), 1) for a in tl for b in a[:, 0]] + [(float(e), -1) for a in tl for e in a[:, 1]])
             live, last = 0, ev[0][0]
             for tm, d in ev:
-                if live == 2:
+                if live == nparts:
                     both += tm - last
                 live += d
                 last = tm
         result["roofline"]["timeline"] = {
             "source": "device stamps (100 MHz clock) at the first and last kernel of every denoise step of every batch part, "
-                      "graph-replayed two-stream decode",
+                      "graph-replayed multi-stream decode", "parts": nparts,
             "decode_wall_ms": wall_ms, "denoise_span_ms": span / 1e3, "part_busy_ms": [b / 1e3 for b in busy],
-            "both_parts_in_a_step_ms": both / 1e3, "overlap_factor": sum(busy) / max(span, 1e-9),
+            "all_parts_in_a_step_ms": both / 1e3, "overlap_factor": sum(busy) / max(span, 1e-9),
             "mean_step_ms_per_part": [float((a[:, 1] - a[:, 0]).mean()) / 1e3 for a in tl]}
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "timeline_steps.csv"), "w") as f:
@@ -271,13 +297,56 @@ def main():
             for k, a in enumerate(tl):
                 for j in range(a.shape[0]):
                     f.write(f"{k},{j},{a[j, 0]:.2f},{a[j, 1]:.2f}\n")
+    if rank == 0 and world == 1 and n_fl == 1 and not args.no_pipelined and not os.environ.get("LDC_NO_SPLIT") and not os.environ.get("LDC_SPLIT"):
+        # Supplementary (NOT `value`): the same K steps with TWO batches of the config's size in flight -- two more engines on
+        # two streams, every batch decoded as ONE chain (kernels of 32 items instead of 16), steps dealt round-robin, all K
+        # finished inside the timed region.  Per-batch latency doubles; throughput and per-launch efficiency rise.
+        os.environ["LDC_NO_SPLIT"] = "1"      # read at ldc_create
+        try:
+            eng2, st2 = [], []
+            for k in range(2):
+                e_k = Engine(mc, u, cc, dtype=args.dtype, device=local_rank, noise_seed=8765 + k)
+                e_k.load_state_dict(L.MODEL_MAIN, sd_main)
+                e_k.load_state_dict(L.MODEL_COND, sd_cond)
+                e_k.finalize(strict=True)
+                eng2.append(e_k)
+                st2.append(torch.cuda.Stream(device=dev))
+                engines.append(e_k)
+            for k in range(2):
+                with torch.cuda.stream(st2[k]):
+                    eng2[k].decode(wav, N, noise=None, per_item=True)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for j in range(args.steps):
+                with torch.cuda.stream(st2[j % 2]):
+                    out2 = eng2[j % 2].decode(wav, N, noise=None, per_item=True)
+            torch.cuda.synchronize(dev)
+            el2 = time.perf_counter() - t1
+            assert bool(torch.isfinite(out2).all()), "non-finite output"
+            pip = {"batches_in_flight": 2, "chains_per_batch": 1, "value": B * (T / 16000.0) * args.steps / el2, "unit": "audio-s/wall-s",
+                   "ms_per_step": 1000.0 * el2 / args.steps, "steps": args.steps,
+                   "note": "same workload and K; two engines on two streams, each batch of the config's size decoded as one chain"}
+            if not args.no_roofline:
+                eng2[0].profile(True)
+                eng2[0].decode(wav, N, noise=None, per_item=True)
+                ms2, launches2, flops2 = eng2[0].profile_read()
+                eng2[0].profile(False)
+                ach2 = flops2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0
+                pip["roofline"] = {"bound": "mfma", "kernel": "conv_fast_kernel / conv_gemm_kernel", "achieved": ach2, "peak": MFMA_PEAK_TFLOPS[args.dtype],
+                                   "unit": "TFLOP/s", "frac": ach2 / MFMA_PEAK_TFLOPS[args.dtype], "launches": launches2,
+                                   "avg_launch_us": 1000.0 * ms2 / max(1, launches2), "traffic": None}
+            result["pipelined"] = pip
+            log(f"pipelined (2 batches in flight): {pip['value']:.1f} audio-s/s, {pip['ms_per_step']:.1f} ms per batch")
+        finally:
+            os.environ.pop("LDC_NO_SPLIT", None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cc, mc, u, sd_cond, sd_main, N, args.seconds, args.cpu_batch)
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(result) + "\n").encode())
     os.close(result_fd)
-    eng.close()
+    for e_k in engines:
+        e_k.close()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -246,6 +246,13 @@ struct ldc_ctx {
   int fuse_kmax = 1;
   int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
   int fuse_attn_tail = 1;       // LinearAttention out + to_out conv + LayerNorm + residual in one launch (bf16 engine)
+  // Flow control of the step-graph replays: with more than ~10-20 multi-thousand-node graph launches outstanding the ROCm 7.2
+  // runtime's enqueue path degrades (a decode queued behind a running one took 247 instead of 157 ms), so a replay waits on
+  // the host until the replay `flow_depth` launches before it has finished (an event of this context, never a device sync)
+  static constexpr int kFlowRing = 32;
+  hipEvent_t flow_ev[kFlowRing] = {};
+  unsigned long long flow_n = 0;
+  int flow_depth = 8;           // LDC_FLOW_DEPTH (0 = unbounded look-ahead)
   int fuse_gn_stats = 1;
   int strip_mode = 0;           // LDC_STRIP: 0 never (default: measured 5 % slower end to end) | 1 when the grid fills the chip | 2 whenever eligible
   int strip_min_wgs = 96;       // LDC_STRIP_MIN: workgroups (items x strips) from which mode 1 picks the strip form
@@ -933,6 +940,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->w8 = cfg->compute_dtype == LDC_BF16_W8;
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  for (auto& e : c->flow_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (int k = 1; k < kMaxParts; ++k) {
     HIPCHK(hipStreamCreateWithFlags(&c->aux_stream[k], hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
@@ -952,6 +960,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
   c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
   c->fuse_attn_tail = getenv("LDC_NO_TAIL_FUSE") ? 0 : 1;
+  c->flow_depth = std::max(0, std::min((int)ldc_ctx::kFlowRing - 1, env_int("LDC_FLOW_DEPTH", c->flow_depth)));
   c->tune.force_generic = getenv("LDC_CONV_V1") ? 1 : 0;
   c->tune.small_max = env_int("LDC_CONV_SMALL_TILES", c->tune.small_max);
   c->tune.medium_max = env_int("LDC_CONV_MEDIUM_TILES", c->tune.medium_max);
@@ -1022,6 +1031,7 @@ extern "C" int ldc_destroy(ldc_ctx* c) {
   if (c->tl_buf) (void)hipFree(c->tl_buf);
   for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (auto& e : c->flow_ev) if (e) (void)hipEventDestroy(e);
   for (int k = 1; k < kMaxParts; ++k) {
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
     if (c->aux_stream[k]) (void)hipStreamDestroy(c->aux_stream[k]);
@@ -1850,6 +1860,10 @@ static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Pl
 static int get_halves(ldc_ctx* c, int B, int L, int F, hipStream_t s, Halves* h) {
   *h = Halves();
   c->call_tick = c->use_tick;   // plans touched from here on belong to the call being served (not evictable)
+  // Independent chains the batch is decoded as (utterances never interact inside the UNet).  A chain is a
+  // dependent sequence of ~155 launches per step whose cost is mostly per-launch floor, so chains side by side hide each
+  // other's floors.  Measured on one box (32 x 2.4 s): 2 x 16 items 503 audio-s/s, 3 chains 505, 4 x 8 items 510 -- but
+  // the convs of a 4 x 8 decode run at 209 instead of 344 TFLOP/s per launch, so two chains stay the default (LDC_SPLIT).
   h->n = std::max(1, std::min(c->split_batch, B));
   for (int k = 0; k < h->n; ++k) {
     const int lo = (int)((long long)B * k / h->n), hi = (int)((long long)B * (k + 1) / h->n);
@@ -2111,9 +2125,20 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
     }
     sg->noise = noise; sg->x = x; sg->stream = s; sg->n = h.n * 100 + K;
   }
+  auto replay = [&](hipGraphExec_t ge) -> int {
+    if (c->flow_depth > 0) {
+      if (c->flow_n >= (unsigned long long)c->flow_depth) HIPCHK(hipEventSynchronize(c->flow_ev[(c->flow_n - c->flow_depth) % ldc_ctx::kFlowRing]));
+      HIPCHK(hipGraphLaunch(ge, s));
+      HIPCHK(hipEventRecord(c->flow_ev[c->flow_n % ldc_ctx::kFlowRing], s));
+      ++c->flow_n;
+    } else {
+      HIPCHK(hipGraphLaunch(ge, s));
+    }
+    return LDC_OK;
+  };
   int i = done;
-  for (; i + K <= n_steps; i += K) HIPCHK(hipGraphLaunch(sg->exec[0], s));
-  for (; i < n_steps; ++i) HIPCHK(hipGraphLaunch(sg->exec[K == 1 ? 0 : 1], s));
+  for (; i + K <= n_steps; i += K) LDCCHK(replay(sg->exec[0]));
+  for (; i < n_steps; ++i) LDCCHK(replay(sg->exec[K == 1 ? 0 : 1]));
   return LDC_OK;
 }
 

@@ -362,12 +362,32 @@ static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out
     const char* p = reinterpret_cast<const char*>(pre) + (size_t)b0 * T_len * 4 * H * esz;
     char* o = reinterpret_cast<char*>(out) + (size_t)b0 * T_len * H * esz;
     const char* k = skip ? reinterpret_cast<const char*>(skip) + (size_t)b0 * T_len * H * esz : nullptr;
-    // cooperative launch: the runtime checks that all H/4 workgroups can be resident together (the kernel's
-    // hand-rolled h exchange needs that); a grid it cannot place is refused here instead of spinning to the timeout
+    // All H/4 workgroups must be resident together (the kernel's hand-rolled h exchange spins on them).  That is checked
+    // ONCE per kernel against the occupancy query (below); the launch itself is a plain one.  hipLaunchCooperativeKernel
+    // makes the same check per launch, but on ROCm 7.2 it goes through a device-wide cooperative queue: enqueued while an
+    // earlier decode is still running it cost ~90 ms per decode (247 vs 157 ms with two decodes queued on a caller's
+    // stream).  LDC_COOP_LAUNCH=1 restores it.  A grid that does not become resident at run time (another process holding
+    // the CUs) still ends in the bounded spin's timeout: NaN output + the host-mapped failure flag.
     const void* pp = p; void* oo = o; const void* kk = k; int nbv = nb, tl = T_len;
     void* args[] = {&pp, &w_rm, &oo, &kk, &nbv, &tl, &hbuf, &sync, &host_flag};
     const void* fn = H == 512 ? reinterpret_cast<const void*>(lstm_coop_kernel<T, 512>) : reinterpret_cast<const void*>(lstm_coop_kernel<T, 256>);
-    e = hipLaunchCooperativeKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
+    static const bool coop_launch = getenv("LDC_COOP_LAUNCH") != nullptr;
+    if (coop_launch) {
+      e = hipLaunchCooperativeKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
+    } else {
+      static int fits[2] = {-1, -1};   // [H == 512]: -1 unknown, 0 no, 1 yes
+      int& f = fits[H == 512 ? 1 : 0];
+      if (f < 0) {
+        int dev = 0, per_cu = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess)
+          return hipErrorUnknown;
+        // the occupancy API can over-report by one block per CU for SGPR-heavy kernels (MI355X_MICROARCH.md): demand a margin
+        f = (long long)std::max(0, per_cu - 1) * cus >= H / 4 || ((long long)per_cu * cus >= 2 * (H / 4)) ? 1 : 0;
+      }
+      if (!f) return hipErrorCooperativeLaunchTooLarge;
+      e = hipLaunchKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
+    }
     if (e != hipSuccess) return e;
   }
   return hipSuccess;

@@ -19,7 +19,7 @@ engs, streams = [], []
 for i in range(slots):
     e = Engine(mc, u, cc, dtype="bf16", device=0, noise_seed=100 + i)
     e.load_state_dict(L.MODEL_MAIN, main); e.load_state_dict(L.MODEL_COND, cond); e.finalize(strict=True)
-    engs.append(e); streams.append(torch.cuda.Stream())
+    engs.append(e); streams.append(torch.cuda.current_stream() if os.environ.get("PROBE_DEFAULT_STREAM") else torch.cuda.Stream())
 B, T, N = 32, 38400, 50
 wav = torch.from_numpy(synth.synthetic_wav(B, T, seed=1234)).cuda()
 torch.cuda.synchronize()
@@ -29,10 +29,15 @@ for i in range(slots):
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 outs = []
+depth = int(os.environ.get("PROBE_DEPTH", "0"))      # > 0: at most this many decodes of a slot may be outstanding when the next is submitted
+evs = [[] for _ in range(slots)]
 for k in range(nb):
     i = k % slots
+    if depth and len(evs[i]) >= depth:
+        evs[i][-depth].synchronize()
     with torch.cuda.stream(streams[i]):
         outs.append(engs[i].decode(wav, N, per_item=True))
+        ev = torch.cuda.Event(); ev.record(); evs[i].append(ev)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 assert all(bool(torch.isfinite(o).all()) for o in outs)
