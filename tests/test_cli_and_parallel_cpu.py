@@ -31,7 +31,7 @@ def test_cli_flags_and_defaults_match_reference():
         assert k in ns, k
         assert ns[k] == v, (k, ns[k], v)
     assert ns["midway_t"] == 100                      # the reference's literal (sample.py:69)
-    assert set(ns) - set(REFERENCE_DEFAULTS) == {"midway_t", "dtype", "batch_size", "seed", "chunk_sec"}
+    assert set(ns) - set(REFERENCE_DEFAULTS) == {"midway_t", "dtype", "batch_size", "seed", "chunk_sec", "in_flight"}
 
 
 def test_cli_readme_invocation_parses():
@@ -207,3 +207,42 @@ def test_long_form_chunk_plan_and_reassembly(tmp_path, monkeypatch):
     np.testing.assert_allclose(y, (src[:y.shape[0]] * 2.0 + 1.0) * 0.25, rtol=1e-6, atol=1e-7)   # chunks joined in order
     whole = [c for c in eng.calls if not c[2]]
     assert ((2, 1, 2560 * 4), False, False) in whole and ((1, 1, 1920), True, False) in whole       # stereo / short: whole-file path
+
+
+def test_cli_batches_in_flight_round_robin(tmp_path, monkeypatch):
+    """--in_flight: several engines, batches dealt round-robin, an engine's previous output is read before its slot is reused,
+    every file written once."""
+    import contextlib
+    import torch
+    from scipy.io import wavfile
+    from ladiffcodec_amd import sample
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir(); outd.mkdir()
+    rng = np.random.default_rng(2)
+    names = [f"f{k}.wav" for k in range(7)]
+    for k, name in enumerate(names):
+        wavfile.write(str(ind / name), 16000, (rng.standard_normal(1280) * 0.1).astype(np.float32))
+    log = []
+
+    class Stub:
+        def __init__(self, tag):
+            self.tag = tag
+        def decode(self, batch, n_steps, noise=None, per_item=False):
+            log.append(("decode", self.tag, batch.shape[0]))
+            return batch * (1.0 + self.tag)
+
+    class A:
+        pass
+    a = A(); a.batch_size = 2; a.midway_t = 3; a.input_dir = str(ind) + "/"; a.output_dir = str(outd) + "/"; a.chunk_sec = 0.0
+    monkeypatch.setattr(torch.Tensor, "to", lambda self, *x, **k: self)
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: object())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    files = sorted(str(ind / n) for n in names)
+    written = sample.decode_files([Stub(0), Stub(1)], files, a, 0, 1, 0)
+    assert sorted(written) == sorted(str(outd / n) for n in names) and len(set(written)) == 7
+    assert [e[1] for e in log] == [0, 1, 0, 1]                      # 7 files / batch 2 = 4 batches, alternating engines
+    assert sum(e[2] for e in log) == 7
+    for n in names:                                                  # each output carries its engine's factor
+        y = wavfile.read(str(outd / n))[1]; x = wavfile.read(str(ind / n))[1]
+        r = float(np.abs(y).max() / np.abs(x).max())
+        assert abs(r - 1.0) < 1e-5 or abs(r - 2.0) < 1e-5
