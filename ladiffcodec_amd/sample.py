@@ -275,11 +275,13 @@ def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_r
     written = []
     dev = torch.device("cuda", local_rank)
     streams = [torch.cuda.Stream(device=dev) for _ in engines] if len(engines) > 1 else [None]
-    pending: List[tuple] = []                 # (output tensor on the device, file indices, joint), oldest first
+    pending: List[tuple] = []                 # (output tensor on the device, file indices, joint, stream), oldest first
 
     def retire(item):
-        out, idxs, joint = item
-        out = out.cpu()                        # waits for that engine's stream only
+        out, idxs, joint, stream = item
+        if stream is not None:
+            stream.synchronize()               # the producer stream, not the current one: waits for that engine's batch only
+        out = out.cpu()
         if not bool(torch.isfinite(out).all()):
             raise RuntimeError(f"non-finite audio decoded for {[files[i] for i in idxs]}")
         out = out.numpy()
@@ -304,7 +306,7 @@ def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_r
                 out = engines[slot].decode(batch.to(dev, non_blocking=True), inp_args.midway_t, noise=None, per_item=not joint)
         else:
             out = engines[slot].decode(batch.to(dev), inp_args.midway_t, noise=None, per_item=not joint)
-        pending.append((out, idxs, joint))
+        pending.append((out, idxs, joint, streams[slot]))
     while pending:
         retire(pending.pop(0))
     return written_long + written

@@ -235,13 +235,19 @@ def test_cli_batches_in_flight_round_robin(tmp_path, monkeypatch):
         pass
     a = A(); a.batch_size = 2; a.midway_t = 3; a.input_dir = str(ind) + "/"; a.output_dir = str(outd) + "/"; a.chunk_sec = 0.0
     monkeypatch.setattr(torch.Tensor, "to", lambda self, *x, **k: self)
-    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: object())
+    class FakeStream:
+        def synchronize(self):
+            log.append(("sync",))
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: FakeStream())
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
     files = sorted(str(ind / n) for n in names)
     written = sample.decode_files([Stub(0), Stub(1)], files, a, 0, 1, 0)
     assert sorted(written) == sorted(str(outd / n) for n in names) and len(set(written)) == 7
-    assert [e[1] for e in log] == [0, 1, 0, 1]                      # 7 files / batch 2 = 4 batches, alternating engines
-    assert sum(e[2] for e in log) == 7
+    dec = [e for e in log if e[0] == "decode"]
+    assert [e[1] for e in dec] == [0, 1, 0, 1]                      # 7 files / batch 2 = 4 batches, alternating engines
+    assert sum(e[2] for e in dec) == 7
+    assert sum(1 for e in log if e[0] == "sync") == 4               # every batch's producer stream is waited for before its read
+    assert [e[0] for e in log[:3]] == ["decode", "decode", "sync"]  # two batches in flight before the first output is read
     for n in names:                                                  # each output carries its engine's factor
         y = wavfile.read(str(outd / n))[1]; x = wavfile.read(str(ind / n))[1]
         r = float(np.abs(y).max() / np.abs(x).max())

@@ -80,3 +80,33 @@ def test_cli_long_form_chunks_against_oracle(tmp_path):
         raws.append(ref["wav_raw"])                                    # un-normalised decoder output of the chunk
     whole = O.output_normalise(torch.cat(raws, dim=-1))
     assert rel(y, whole.numpy().reshape(-1)) < 5e-3
+
+
+def test_cli_two_batches_in_flight_against_oracle(tmp_path):
+    """--in_flight 2 (the CLI's default when a run has several batches): three files at batch_size 1 go through two engines on
+    two streams; every output must equal the oracle's for that file decoded alone."""
+    from scipy.io import wavfile
+    from ladiffcodec_amd import sample as cli
+    mc, u, _ = CASES["r84"]
+    synth.save_amlt(main_sd_np("r84"), str(tmp_path / "ladiff.amlt"))
+    synth.save_amlt(cond_sd_np(), str(tmp_path / "codec.amlt"))
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    n = 5120
+    xs = {}
+    for k, f0 in enumerate((150.0, 310.0, 95.0)):
+        t = np.arange(n) / 16000.0
+        xs[f"u{k}.wav"] = (0.25 * np.sin(2 * np.pi * f0 * t) + 0.05 * np.sin(2 * np.pi * 7.3 * f0 * t)).astype(np.float32)
+        wavfile.write(str(ind / f"u{k}.wav"), 16000, xs[f"u{k}.wav"])
+    args = cli.build_parser().parse_args([
+        "--model_for_cond", str(tmp_path / "codec.amlt"), "--model_path", str(tmp_path / "ladiff.amlt"), "--run_diff", "--scaling_global",
+        "--cond_bandwidth", "3", "--unet_scale_cond", "--enc_ratios", "8", "4", "--upsampling_ratios", "5", "2", "--diff_dims", "32",
+        "--input_dir", str(ind) + "/", "--output_dir", str(outd) + "/", "--midway_t", "1", "--dtype", "f32", "--batch_size", "1",
+        "--in_flight", "2"])
+    written = cli.synthesis(args)
+    assert len(written) == 3
+    sdc, sdm = synth.to_torch(cond_sd_np()), synth.to_torch(main_sd_np("r84"))
+    for name, x in xs.items():
+        y = wavfile.read(str(outd / name))[1]
+        ref = O.decode_utterances(sdc, COND_CFG, sdm, mc, u, T(x).reshape(1, 1, n), 1, None)
+        assert rel(y, ref["wav"].numpy().reshape(-1)) < 5e-3, name
