@@ -14,21 +14,21 @@ if [[ $STAGE == all || $STAGE == bench ]]; then
 fi
 if [[ $STAGE == all || $STAGE == prof ]]; then
   rm -rf $O/prof_r02
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_r02 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_r02.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_r02 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-pipelined > $O/prof_r02.log 2>&1)
   python tools/prof_summary.py $(find $O/prof_r02 -name "*.db" | head -1) > $O/prof_r02_summary.md
   find $O/prof_r02 -name "*.db" -size +30M -delete
   head -40 $O/prof_r02_summary.md
 fi
 if [[ $STAGE == all || $STAGE == pmc ]]; then
   rm -rf $O/pmc2_FETCH $O/pmc2_WRITE
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc2_FETCH -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $O/pmc2_FETCH.log 2>&1)
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc2_WRITE -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $O/pmc2_WRITE.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc2_FETCH -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipelined > $O/pmc2_FETCH.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc2_WRITE -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipelined > $O/pmc2_WRITE.log 2>&1)
   python tools/pmc_traffic.py $O/pmc2_FETCH $O/pmc2_WRITE $O/conv_traffic_r02.json
   python tools/pmc_classes.py $O/pmc2_FETCH $O/pmc2_WRITE $O/conv_pmc_classes_r02.md > /dev/null
   find $O/pmc2_FETCH $O/pmc2_WRITE -name "*.csv" -size +20M -delete
   cat $O/conv_traffic_r02.json
 fi
 if [[ $STAGE == all || $STAGE == shapes ]]; then
-  LDC_PROFILE_DUMP=/tmp/d.txt timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_shapes.json 2> $O/bench_shapes.err
+  LDC_PROFILE_DUMP=/tmp/d.txt timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined > $O/bench_shapes.json 2> $O/bench_shapes.err
   python tools/prof_shapes.py /tmp/d.txt > $O/shapes_r02.txt 2>&1; head -60 $O/shapes_r02.txt
 fi
