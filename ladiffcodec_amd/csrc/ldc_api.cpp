@@ -974,7 +974,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->strip_min_wgs = env_int("LDC_STRIP_MIN", 96);
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
   c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
-  c->graph_steps = std::max(1, env_int("LDC_GRAPH_STEPS", 5));
+  c->graph_steps = std::max(0, env_int("LDC_GRAPH_STEPS", 0));   // 0 = by chain count (denoise_loop)
   c->plan_bytes_cap = (size_t)std::max(1, env_int("LDC_PLAN_CACHE_GB", 48)) << 30;
   c->plan_count_cap = std::max(2 * kMaxParts, env_int("LDC_PLAN_CACHE_N", 24));
   switch (cfg->final_activation) {
@@ -2092,7 +2092,11 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   // steps per replayed graph: the parts fork at the head of the graph and join at its tail, so K > 1 lets them
   // drift apart for K steps (concurrent replays of SEPARATE graphs on different streams were measured: the ROCm
   // 7.2 runtime serialises them, 198 vs 188 ms)
-  const int K = std::min(c->graph_steps, std::max(1, n_steps - 1));
+  // ~1 500 kernel nodes per graph measured best in both arrangements: 5 steps of two chains (3 / 4 / 5 / 7 steps within 0.2 %,
+  // 10 / 25 steps 2 % / 16 % slower), 10 steps of a single chain (5 steps 2.8 % slower; 8 / 10 / 25 equal).  A remainder of
+  // single-step replays is slow (13 or 17 steps per graph: 154 instead of 124 ms), so the defaults divide the usual 50.
+  const int k_want = c->graph_steps > 0 ? c->graph_steps : (h.n == 1 ? 10 : 5);
+  const int K = std::min(k_want, std::max(1, n_steps - 1));
   int done = 0;
   if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K) {
     if (sg->any()) {
