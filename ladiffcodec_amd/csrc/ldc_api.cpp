@@ -2095,7 +2095,14 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   // ~1 500 kernel nodes per graph measured best in both arrangements: 5 steps of two chains (3 / 4 / 5 / 7 steps within 0.2 %,
   // 10 / 25 steps 2 % / 16 % slower), 10 steps of a single chain (5 steps 2.8 % slower; 8 / 10 / 25 equal).  A remainder of
   // single-step replays is slow (13 or 17 steps per graph: 154 instead of 124 ms), so the defaults divide the usual 50.
-  const int k_want = c->graph_steps > 0 ? c->graph_steps : (h.n == 1 ? 10 : 5);
+  int k_want = c->graph_steps > 0 ? c->graph_steps : (h.n == 1 ? 10 : 5);
+  if (c->graph_steps == 0) {   // prefer a graph length that divides the step count (within the flat part of the measured range)
+    const int lo = h.n == 1 ? 8 : 3, hi = h.n == 1 ? 25 : 7;
+    int best = 0;
+    for (int k = lo; k <= hi; ++k)
+      if (n_steps % k == 0 && (best == 0 || std::abs(k - k_want) < std::abs(best - k_want))) best = k;
+    if (best) k_want = best;
+  }
   const int K = std::min(k_want, std::max(1, n_steps - 1));
   int done = 0;
   if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K) {
