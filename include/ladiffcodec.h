@@ -19,6 +19,11 @@
  *     state: (1) when a context-owned workspace has to grow (first call at a larger shape),
  *     (2) when a captured step graph is replaced or evicted (a new (B, L, F), a new noise pointer,
  *     the LRU plan cache bound, see LDC_PLAN_CACHE_GB / LDC_PLAN_CACHE_N), (3) in ldc_destroy.
+ *     Besides those, a sampler call may wait ON THE HOST for an earlier step-graph replay of the same
+ *     context (bounded look-ahead, LDC_FLOW_DEPTH = 8 replays; an event wait, not a device sync).
+ *   - Several contexts may be used side by side on one device (one per stream of work): two batches
+ *     in flight, each decoded by its own context on its own stream, is how `python -m srcs.sample`
+ *     and `bench.py --in-flight 2` raise throughput.
  *   - Reproducibility: GroupNorm statistics and the fused column maxima are accumulated with fp32
  *     atomics, so two identical UNet calls agree to rounding (~1e-6 relative), not bit for bit; the
  *     split-K reduction order is fixed.  The codec stages (SEANet, LSTM, RVQ) use no atomics: RVQ code
