@@ -227,6 +227,18 @@ int ldc_train_block_backward(ldc_ctx* ctx, const float* dy, const float* x, cons
                              const float* scale_shift, int B, int Cin, int Cout, int L, int groups, float* ws, float* dx, float* dw,
                              float* db, float* dgamma, float* dbeta, float* dscale_shift, void* stream);
 
+/* Channel LayerNorm of the UNet's attention blocks (srcs/modules/unet.py:82-101), forward and backward, [B, C, L] float32:
+ * y = (x - mean_c) * rsqrt(var_c + 1e-5) * g.  `stats`: [B, L, 2] floats written by the forward pass (mean, 1/std), read by the
+ * backward pass, which returns dx and dg [C]. */
+int ldc_train_layernorm_forward(ldc_ctx* ctx, const float* x, const float* g, int B, int C, int L, float* y, float* stats, void* stream);
+int ldc_train_layernorm_backward(ldc_ctx* ctx, const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L,
+                                 float* dx, float* dg, void* stream);
+
+/* One Adam step over flat device buffers, in place (srcs/train.py:365-371: optim.Adam(params, lr); torch's defaults are
+ * beta1 0.9, beta2 0.999, eps 1e-8, no weight decay, no amsgrad).  `step` counts from 1 (bias correction). */
+int ldc_train_adam_step(ldc_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
+                        float beta1, float beta2, float eps, void* stream);
+
 /* L1 primitives (reference srcs/modules/conv.py, lstm.py), exposed for the parity tests ---------- */
 /* SConv1d.forward (conv.py:217-232), reflect padding.  w [Cout,Cin,k] (already weight-norm folded),
  * all HOST float32; x/y DEVICE [B,Cin,L] / [B,Cout,Lout].  pre_elu applies ELU to the input. */

@@ -2489,6 +2489,33 @@ extern "C" int ldc_train_block_backward(ldc_ctx* c, const float* dy, const float
   return finish_stream(c, stream);
 }
 
+extern "C" int ldc_train_adam_step(ldc_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                                   float lr, float beta1, float beta2, float eps, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
+    return fail(LDC_E_INVALID, "bad arguments (step counts from 1)");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_adam(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_layernorm_forward(ldc_ctx* c, const float* x, const float* g, int B, int C, int L, float* y, float* stats, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!x || !g || !y || !stats || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_ln_forward(x, g, B, C, L, y, stats, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_layernorm_backward(ldc_ctx* c, const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L,
+                                            float* dx, float* dg, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!dy || !x || !g || !stats || !dx || !dg || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_ln_backward(dy, x, g, stats, B, C, L, dx, dg, s));
+  return finish_stream(c, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // L1 primitives for the parity tests
 // ------------------------------------------------------------------------------------------------

@@ -5,6 +5,8 @@
 //   Block forward / backward      srcs/modules/unet.py:137-154 with WeightStandardizedConv2d (:67-80), GroupNorm(8), SiLU:
 //                                 y = SiLU( GN(conv_k3(x; WS(W), b)) * (scale + 1) + shift )
 //                                 backward: dx, dW (THROUGH the weight standardisation), db, dgamma, dbeta, dscale, dshift
+//   channel LayerNorm fwd / bwd   unet.py:82-101 (PreNorm and to_out of the attention blocks)
+//   Adam step                     srcs/train.py:365-371 (optim.Adam(params, lr)), flat parameter / gradient / moment buffers
 //
 // fp32 throughout, reference layouts [B, C, L].  This slice is the correctness baseline of the training path (gradients
 // pinned to the reference's autograd, tests/golden/train_block.npz); the three GEMM-shaped pieces (conv forward, dX, dW)
@@ -305,6 +307,98 @@ hipError_t launch_train_block_backward(const float* dy, const float* x, const fl
   hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, k.tmp, x, B, Cin, Cout, L, k.dwn);
   hipLaunchKernelGGL(ws_backward_kernel, dim3(Cout), dim3(256), 0, s, k.dwn, k.wn, k.rstd_w, Cin * 3, dw);
   if (dx) hipLaunchKernelGGL(conv3_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, k.tmp, k.wn, Cin, Cout, L, dx);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam step (srcs/train.py:365-371: optim.Adam(params, lr), default betas (0.9, 0.999), eps 1e-8, no weight decay), flat buffers.
+// torch.optim.Adam's arithmetic: m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                                                   float eps, float step_size, float inv_sqrt_bc2) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;          // (torch: m.lerp_(g, 1 - b1) == m + (g - m)(1 - b1); same to rounding)
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel LayerNorm of the UNet (srcs/modules/unet.py:82-101): per position, over C: y = (x - mean) * rsqrt(var + 1e-5) * g
+// ([B, C, L] fp32; var biased).  backward: dx = rstd * (dxhat - mean_c(dxhat) - xhat * mean_c(dxhat * xhat)), dxhat = dy * g;
+// dg[c] = sum_{b,l} dy * xhat (two-stage, fixed order).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_forward_kernel(const float* x, const float* g, int C, int L, float* y, float* stats) {
+  const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  const float* xb = x + (size_t)b * C * L + l;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += xb[(size_t)c * L];
+  const float mean = s / (float)C;
+  float ss = 0.f;
+  for (int c = 0; c < C; ++c) { const float d = xb[(size_t)c * L] - mean; ss += d * d; }
+  const float rstd = rsqrtf(ss / (float)C + 1e-5f);
+  float* yb = y + (size_t)b * C * L + l;
+  for (int c = 0; c < C; ++c) yb[(size_t)c * L] = (xb[(size_t)c * L] - mean) * rstd * g[c];
+  stats[((size_t)b * L + l) * 2] = mean;
+  stats[((size_t)b * L + l) * 2 + 1] = rstd;
+}
+__global__ __launch_bounds__(256) void ln_backward_dx_kernel(const float* dy, const float* x, const float* g, const float* stats, int C, int L,
+                                                             float* dx) {
+  const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  const size_t base = (size_t)b * C * L + l;
+  const float mean = stats[((size_t)b * L + l) * 2], rstd = stats[((size_t)b * L + l) * 2 + 1];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float xh = (x[base + (size_t)c * L] - mean) * rstd, dxh = dy[base + (size_t)c * L] * g[c];
+    s1 += dxh;
+    s2 += dxh * xh;
+  }
+  s1 /= (float)C; s2 /= (float)C;
+  for (int c = 0; c < C; ++c) {
+    const float xh = (x[base + (size_t)c * L] - mean) * rstd, dxh = dy[base + (size_t)c * L] * g[c];
+    dx[base + (size_t)c * L] = rstd * (dxh - s1 - xh * s2);
+  }
+}
+// one block per channel: dg[c] = sum_{b,l} dy * xhat in a fixed order
+__global__ __launch_bounds__(256) void ln_backward_dg_kernel(const float* dy, const float* x, const float* stats, int B, int C, int L, float* dg) {
+  const int c = blockIdx.x;
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int idx = threadIdx.x; idx < B * L; idx += 256) {
+    const int b = idx / L, l = idx - b * L;
+    const float mean = stats[((size_t)b * L + l) * 2], rstd = stats[((size_t)b * L + l) * 2 + 1];
+    const size_t off = ((size_t)b * C + c) * L + l;
+    acc += dy[off] * (x[off] - mean) * rstd;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dg[c] = red[0];
+}
+hipError_t launch_train_ln_forward(const float* x, const float* g, int B, int C, int L, float* y, float* stats, hipStream_t s) {
+  hipLaunchKernelGGL(ln_forward_kernel, dim3((L + 255) / 256, B), dim3(256), 0, s, x, g, C, L, y, stats);
+  return hipGetLastError();
+}
+hipError_t launch_train_ln_backward(const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L, float* dx,
+                                    float* dg, hipStream_t s) {
+  hipLaunchKernelGGL(ln_backward_dx_kernel, dim3((L + 255) / 256, B), dim3(256), 0, s, dy, x, g, stats, C, L, dx);
+  hipLaunchKernelGGL(ln_backward_dg_kernel, dim3(C), dim3(256), 0, s, dy, x, stats, B, C, L, dg);
   return hipGetLastError();
 }
 

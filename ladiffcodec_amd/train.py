@@ -87,3 +87,60 @@ def p_losses_objective(eng, model_out, target, t, want_grad: bool = True):
                                       grad.data_ptr() if grad is not None else None, s))
     eng._exit()
     return (loss, grad) if want_grad else loss
+
+
+class LayerNorm:
+    """Channel LayerNorm of the attention blocks (srcs/modules/unet.py:82-101) with its backward pass."""
+
+    def __init__(self, eng, g):
+        self.eng, self.lib, self.torch = eng, eng.lib, eng.torch
+        self.g = g.to(eng.device, eng.torch.float32).reshape(-1).contiguous()
+
+    def forward(self, x):
+        t = self.torch
+        x = x.to(self.eng.device, t.float32).contiguous()
+        B, Cc, Lx = x.shape
+        y = t.empty_like(x)
+        stats = t.empty(B, Lx, 2, dtype=t.float32, device=self.eng.device)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_layernorm_forward(self.eng._ctx, x.data_ptr(), self.g.data_ptr(), B, Cc, Lx, y.data_ptr(), stats.data_ptr(), s))
+        self.eng._exit()
+        self._saved = (x, stats)
+        return y
+
+    def backward(self, dy):
+        """-> (dx, dg)"""
+        t = self.torch
+        x, stats = self._saved
+        B, Cc, Lx = x.shape
+        dy = dy.to(self.eng.device, t.float32).contiguous()
+        dx, dg = t.empty_like(x), t.empty(Cc, dtype=t.float32, device=self.eng.device)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_layernorm_backward(self.eng._ctx, dy.data_ptr(), x.data_ptr(), self.g.data_ptr(), stats.data_ptr(), B, Cc, Lx,
+                                                      dx.data_ptr(), dg.data_ptr(), s))
+        self.eng._exit()
+        return dx, dg
+
+
+class Adam:
+    """optim.Adam(params, lr) of srcs/train.py:365-371 over ONE flat fp32 parameter buffer (the layout parallel.allreduce_gradients
+    reduces): state and update live on the device, `step(grad)` updates `param` in place."""
+
+    def __init__(self, eng, param, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
+        t = eng.torch
+        assert param.dtype == t.float32 and param.is_contiguous() and param.device.type == "cuda"
+        self.eng, self.param, self.lr, self.betas, self.eps = eng, param, float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.exp_avg, self.exp_avg_sq = t.zeros_like(param), t.zeros_like(param)
+        self.steps = 0
+
+    def step(self, grad):
+        t = self.eng.torch
+        grad = grad.to(self.param.device, t.float32).contiguous()
+        assert grad.numel() == self.param.numel()
+        self.steps += 1
+        s = self.eng._enter()
+        L.check(self.eng.lib.ldc_train_adam_step(self.eng._ctx, self.param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                 self.exp_avg_sq.data_ptr(), self.param.numel(), self.steps, self.lr, self.betas[0],
+                                                 self.betas[1], self.eps, s))
+        self.eng._exit()
+        return self.param

@@ -29,3 +29,18 @@ def q_sample(sd, x_start, t, noise):
 def p_losses_objective(sd, model_out, target, t):
     loss = F.l1_loss(model_out, target, reduction="none").flatten(1).mean(dim=1)
     return (loss * sd["diffusion.p2_loss_weight"][t]).mean()
+
+
+def layer_norm(x, g):
+    """channel LayerNorm, unet.py:82-101 (float32 branch: eps 1e-5, biased variance)."""
+    var = torch.var(x, dim=1, unbiased=False, keepdim=True)
+    mean = torch.mean(x, dim=1, keepdim=True)
+    return (x - mean) * (var + 1e-5).rsqrt() * g.view(1, -1, 1)
+
+
+def adam_step(p, g, m, v, step: int, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
+    """torch.optim.Adam's update (the reference's optimiser, train.py:365-371): returns (p, m, v) after one step."""
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    denom = v.sqrt() / (1 - b2 ** step) ** 0.5 + eps
+    return p - (lr / (1 - b1 ** step)) * (m / denom), m, v

@@ -58,3 +58,36 @@ def test_q_sample_and_objective_reference_vectors():
     loss, grad = TR.p_losses_objective(e, T(g["q.model_out"]), T(g["q.noise"]), t)
     assert abs(float(loss.cpu()[0]) - float(g["q.loss"][0])) < 1e-5
     assert rel(grad.cpu().numpy(), g["q.grad"]) < 1e-6
+
+
+def test_layernorm_forward_backward_reference_vectors_and_wide():
+    g = load_golden("train_block")
+    e = engine("r84", "f32")
+    ln = TR.LayerNorm(e, T(g["ln.g"]))
+    y = ln.forward(T(g["ln.x"]))
+    assert rel(y.cpu().numpy(), g["ln.y"]) < 1e-5
+    dx, dg = ln.backward(T(g["ln.dy"]))
+    assert rel(dx.cpu().numpy(), g["ln.dx"]) < TOL and rel(dg.cpu().numpy(), g["ln.dg"].reshape(-1)) < TOL
+    # the widths of the deepest attention block: C = 1024, L = 75, against autograd of the oracle
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(3, 1024, 75, generator=gen) * 2.0 - 0.3).requires_grad_()
+    gg = (torch.rand(1024, generator=gen) + 0.5).requires_grad_()
+    yo = TO.layer_norm(x, gg)
+    dy = torch.randn(yo.shape, generator=gen)
+    yo.backward(dy)
+    ln = TR.LayerNorm(e, gg.detach())
+    assert rel(ln.forward(x.detach()).cpu().numpy(), yo.detach().numpy()) < 1e-5
+    dx, dg = ln.backward(dy)
+    assert rel(dx.cpu().numpy(), x.grad.numpy()) < TOL and rel(dg.cpu().numpy(), gg.grad.numpy()) < TOL
+
+
+def test_adam_steps_match_torch_optim_adam():
+    """Three steps against the reference's optimiser (optim.Adam(params, lr), train.py:365-371): golden from torch.optim.Adam."""
+    g = load_golden("train_block")
+    e = engine("r84", "f32")
+    p = T(g["adam.p0"]).cuda().contiguous()
+    opt = TR.Adam(e, p, lr=3e-4)
+    for k in range(3):
+        opt.step(T(g[f"adam.g{k}"]))
+        assert float((p.cpu() - T(g[f"adam.p{k + 1}"])).abs().max()) < 3e-7, k      # |p| ~ 0.2, steps of 3e-4: a few ulp
+    assert not bool(torch.isnan(p).any())

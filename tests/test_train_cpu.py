@@ -31,3 +31,17 @@ def test_q_sample_and_objective_match_reference():
     assert abs(float(loss) - float(g["q.loss"][0])) < 1e-6
     loss.backward()
     assert rel_err(out.grad.numpy(), g["q.grad"]) < 1e-6
+
+
+def test_oracle_layernorm_and_adam_match_reference():
+    g = load_golden("train_block")
+    x = T(g["ln.x"]).requires_grad_()
+    gn = T(g["ln.g"]).requires_grad_()
+    y = TO.layer_norm(x, gn)
+    assert rel_err(y.detach().numpy(), g["ln.y"]) < 1e-6
+    y.backward(T(g["ln.dy"]))
+    assert rel_err(x.grad.numpy(), g["ln.dx"]) < 1e-5 and rel_err(gn.grad.numpy().reshape(-1), g["ln.dg"].reshape(-1)) < 1e-5
+    p = T(g["adam.p0"]); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for k in range(3):
+        p, m, v = TO.adam_step(p, T(g[f"adam.g{k}"]), m, v, k + 1, 3e-4)
+        assert float((p - T(g[f"adam.p{k + 1}"])).abs().max()) < 2e-7, k

@@ -323,8 +323,28 @@ def main():
         loss.backward()
         out.update({"q.x0": np32(x0), "q.noise": np32(noise), "q.t": t.numpy().astype(np.int64), "q.x_t": np32(x_t),
                     "q.model_out": np32(model_out), "q.loss": np32(loss.reshape(1)), "q.grad": np32(model_out.grad)})
+        # channel LayerNorm (unet.py:82-101) under autograd
+        from srcs.modules.unet import LayerNorm
+        ln = LayerNorm(64)
+        with torch.no_grad():
+            ln.g.copy_(torch.rand(1, 64, 1, generator=gg) + 0.5)
+        xl = (torch.randn(2, 64, 90, generator=gg) * 1.3 + 0.2).requires_grad_()
+        yl = ln(xl)
+        dyl = torch.randn(yl.shape, generator=gg)
+        yl.backward(dyl)
+        out.update({"ln.x": np32(xl), "ln.g": np32(ln.g), "ln.y": np32(yl), "ln.dy": np32(dyl), "ln.dx": np32(xl.grad), "ln.dg": np32(ln.g.grad)})
+        # three steps of the reference's optimiser (train.py:365-371: optim.Adam(params, lr)) on a flat parameter
+        pa = torch.nn.Parameter(torch.randn(5000, generator=gg) * 0.2)
+        opt = torch.optim.Adam([pa], lr=3e-4)
+        out["adam.p0"] = np32(pa)
+        for k in range(3):
+            gk = torch.randn(5000, generator=gg) * (0.5 if k != 1 else 1e-4)
+            pa.grad = gk.clone()
+            opt.step()
+            out[f"adam.g{k}"] = np32(gk)
+            out[f"adam.p{k + 1}"] = np32(pa)
         np.savez_compressed(os.path.join(OUT, "train_block.npz"), **out)
-        print("train_block: loss", float(loss), "dw absmax", float(np.abs(out["a.dw"]).max()))
+        print("train_block: loss", float(loss), "dw absmax", float(np.abs(out["a.dw"]).max()), "ln dg absmax", float(np.abs(out["ln.dg"]).max()))
 
     train_case()
     if os.environ.get("GOLDEN_ONLY") == "train":
