@@ -234,6 +234,14 @@ int ldc_train_layernorm_forward(ldc_ctx* ctx, const float* x, const float* g, in
 int ldc_train_layernorm_backward(ldc_ctx* ctx, const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L,
                                  float* dx, float* dg, void* stream);
 
+/* y[b, o, l] = bias[o] + sum_i w[o, i] * a(x[b, i, l]) on [B, C, L] float32, a = identity or SiLU (`pre_silu`): the 1x1 res_conv of a
+ * ResnetBlock (srcs/modules/unet.py:171,192) and, with L = 1, its time-embedding MLP SiLU -> Linear (unet.py:163-166); backward
+ * returns dx (may be NULL), dw [Cout, Cin] and db (may be NULL).  With ldc_train_block_* this is a whole ResnetBlock. */
+int ldc_train_pointwise_forward(ldc_ctx* ctx, const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int pre_silu,
+                                float* y, void* stream);
+int ldc_train_pointwise_backward(ldc_ctx* ctx, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int pre_silu,
+                                 float* dx, float* dw, float* db, void* stream);
+
 /* One Adam step over flat device buffers, in place (srcs/train.py:365-371: optim.Adam(params, lr); torch's defaults are
  * beta1 0.9, beta2 0.999, eps 1e-8, no weight decay, no amsgrad).  `step` counts from 1 (bias correction). */
 int ldc_train_adam_step(ldc_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,

@@ -2489,6 +2489,24 @@ extern "C" int ldc_train_block_backward(ldc_ctx* c, const float* dy, const float
   return finish_stream(c, stream);
 }
 
+extern "C" int ldc_train_pointwise_forward(ldc_ctx* c, const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L,
+                                           int pre_silu, float* y, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!x || !w || !y || B < 1 || Cin < 1 || Cout < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_pw_forward(x, w, bias, B, Cin, Cout, L, pre_silu ? 1 : 0, y, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_pointwise_backward(ldc_ctx* c, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L,
+                                            int pre_silu, float* dx, float* dw, float* db, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!dy || !x || !w || !dw || B < 1 || Cin < 1 || Cout < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_pw_backward(dy, x, w, B, Cin, Cout, L, pre_silu ? 1 : 0, dx, dw, db, s));
+  return finish_stream(c, stream);
+}
+
 extern "C" int ldc_train_adam_step(ldc_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                                    float lr, float beta1, float beta2, float eps, void* stream) {
   LDCCHK(check_dev(c));

@@ -6,6 +6,8 @@
 //                                 y = SiLU( GN(conv_k3(x; WS(W), b)) * (scale + 1) + shift )
 //                                 backward: dx, dW (THROUGH the weight standardisation), db, dgamma, dbeta, dscale, dshift
 //   channel LayerNorm fwd / bwd   unet.py:82-101 (PreNorm and to_out of the attention blocks)
+//   pointwise linear fwd / bwd    unet.py:163-166,171 (time-embedding MLP SiLU -> Linear, 1x1 res_conv): with the two Blocks the
+//                                 whole ResnetBlock (unet.py:157-192) runs forward and backward (ladiffcodec_amd/train.py)
 //   Adam step                     srcs/train.py:365-371 (optim.Adam(params, lr)), flat parameter / gradient / moment buffers
 //
 // fp32 throughout, reference layouts [B, C, L].  This slice is the correctness baseline of the training path (gradients
@@ -399,6 +401,63 @@ hipError_t launch_train_ln_backward(const float* dy, const float* x, const float
                                     float* dg, hipStream_t s) {
   hipLaunchKernelGGL(ln_backward_dx_kernel, dim3((L + 255) / 256, B), dim3(256), 0, s, dy, x, g, stats, C, L, dx);
   hipLaunchKernelGGL(ln_backward_dg_kernel, dim3(C), dim3(256), 0, s, dy, x, stats, B, C, L, dg);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise linear maps on [B, C, L] (L = 1: nn.Linear on [B, K]): the 1x1 res_conv of a ResnetBlock (unet.py:171,192) and its
+// time-embedding MLP SiLU -> Linear (unet.py:163-166: `pre_silu`), forward and backward
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_grad_f(float v) { const float sg = 1.0f / (1.0f + expf(-v)); return sg * (1.0f + v * (1.0f - sg)); }
+
+__global__ __launch_bounds__(256) void pw_forward_kernel(const float* x, const float* w, const float* bias, int Cin, int Cout, int L, int pre_silu,
+                                                         float* y) {
+  const int b = blockIdx.z, o = blockIdx.y;
+  const float* wr = w + (size_t)o * Cin;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < L; l += gridDim.x * 256) {
+    float acc = bias ? bias[o] : 0.f;
+    for (int i = 0; i < Cin; ++i) {
+      float v = x[((size_t)b * Cin + i) * L + l];
+      if (pre_silu) v = silu_f(v);
+      acc = fmaf(wr[i], v, acc);
+    }
+    y[((size_t)b * Cout + o) * L + l] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void pw_dx_kernel(const float* dy, const float* x, const float* w, int Cin, int Cout, int L, int pre_silu, float* dx) {
+  const int b = blockIdx.z, i = blockIdx.y;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < L; l += gridDim.x * 256) {
+    float acc = 0.f;
+    for (int o = 0; o < Cout; ++o) acc = fmaf(w[(size_t)o * Cin + i], dy[((size_t)b * Cout + o) * L + l], acc);
+    if (pre_silu) acc *= silu_grad_f(x[((size_t)b * Cin + i) * L + l]);
+    dx[((size_t)b * Cin + i) * L + l] = acc;
+  }
+}
+// dw[o,i] = sum_{b,l} dy[b,o,l] * a[b,i,l], a = x or SiLU(x); one block per (o, i), fixed-order reduction
+__global__ __launch_bounds__(256) void pw_dw_kernel(const float* dy, const float* x, int B, int Cin, int Cout, int L, int pre_silu, float* dw) {
+  __shared__ float red[4];
+  const int o = blockIdx.y, i = blockIdx.x;
+  float a = 0.f;
+  for (int idx = threadIdx.x; idx < B * L; idx += 256) {
+    const int b = idx / L, l = idx - b * L;
+    float v = x[((size_t)b * Cin + i) * L + l];
+    if (pre_silu) v = silu_f(v);
+    a = fmaf(dy[((size_t)b * Cout + o) * L + l], v, a);
+  }
+  const float t = block_sum(a, red);
+  if (threadIdx.x == 0) dw[(size_t)o * Cin + i] = t;
+}
+hipError_t launch_train_pw_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int pre_silu, float* y,
+                                   hipStream_t s) {
+  hipLaunchKernelGGL(pw_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, L, pre_silu, y);
+  return hipGetLastError();
+}
+hipError_t launch_train_pw_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int pre_silu, float* dx,
+                                    float* dw, float* db, hipStream_t s) {
+  if (dx) hipLaunchKernelGGL(pw_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, dy, x, w, Cin, Cout, L, pre_silu, dx);
+  hipLaunchKernelGGL(pw_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, dy, x, B, Cin, Cout, L, pre_silu, dw);
+  if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L, db);
   return hipGetLastError();
 }
 

@@ -144,3 +144,96 @@ class Adam:
                                                  self.betas[1], self.eps, s))
         self.eng._exit()
         return self.param
+
+
+class Pointwise:
+    """y = W a(x) + b on [B, C, L] (a = identity | SiLU): the 1x1 res_conv and the time-embedding MLP of a ResnetBlock."""
+
+    def __init__(self, eng, weight, bias, pre_silu: bool = False):
+        t = eng.torch
+        self.eng, self.lib, self.torch = eng, eng.lib, t
+        self.weight = weight.to(eng.device, t.float32).reshape(weight.shape[0], -1).contiguous()      # [Cout, Cin]
+        self.bias = bias.to(eng.device, t.float32).contiguous() if bias is not None else None
+        self.pre_silu = bool(pre_silu)
+
+    def forward(self, x):
+        t = self.torch
+        x = x.to(self.eng.device, t.float32).contiguous()
+        x3 = x if x.dim() == 3 else x.reshape(x.shape[0], x.shape[1], 1)
+        B, Cin, Lx = x3.shape
+        Cout = self.weight.shape[0]
+        y = t.empty(B, Cout, Lx, dtype=t.float32, device=self.eng.device)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_pointwise_forward(self.eng._ctx, x3.data_ptr(), self.weight.data_ptr(),
+                                                     self.bias.data_ptr() if self.bias is not None else None, B, Cin, Cout, Lx,
+                                                     int(self.pre_silu), y.data_ptr(), s))
+        self.eng._exit()
+        self._saved = (x3, x.dim())
+        return y if x.dim() == 3 else y.reshape(B, Cout)
+
+    def backward(self, dy, want_dx: bool = True):
+        """-> dict(dx, dw, db)"""
+        t = self.torch
+        x3, nd = self._saved
+        B, Cin, Lx = x3.shape
+        Cout = self.weight.shape[0]
+        dy = dy.to(self.eng.device, t.float32).contiguous().reshape(B, Cout, Lx)
+        dx = t.empty_like(x3) if want_dx else None
+        dw = t.empty(Cout, Cin, dtype=t.float32, device=self.eng.device)
+        db = t.empty(Cout, dtype=t.float32, device=self.eng.device) if self.bias is not None else None
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_pointwise_backward(self.eng._ctx, dy.data_ptr(), x3.data_ptr(), self.weight.data_ptr(), B, Cin, Cout, Lx,
+                                                      int(self.pre_silu), dx.data_ptr() if dx is not None else None, dw.data_ptr(),
+                                                      db.data_ptr() if db is not None else None, s))
+        self.eng._exit()
+        out = {"dw": dw}
+        if db is not None:
+            out["db"] = db
+        if dx is not None:
+            out["dx"] = dx if nd == 3 else dx.reshape(B, Cin)
+        return out
+
+
+class ResnetBlock:
+    """ResnetBlock.forward (srcs/modules/unet.py:157-192) and its backward pass, composed of the slice's pieces:
+    time_emb -> SiLU -> Linear -> (scale, shift); Block1(x; scale, shift) -> Block2 -> + res_conv(x)."""
+
+    def __init__(self, eng, p: dict, groups: int = 8):
+        """p: the block's state-dict entries: mlp.1.weight/bias, block1|block2.proj.weight/bias, block1|block2.norm.weight/bias,
+        optionally res_conv.weight/bias."""
+        self.eng, self.torch = eng, eng.torch
+        self.mlp = Pointwise(eng, p["mlp.1.weight"], p["mlp.1.bias"], pre_silu=True)
+        self.block1 = Block(eng, p["block1.proj.weight"], p["block1.proj.bias"], p["block1.norm.weight"], p["block1.norm.bias"], groups)
+        self.block2 = Block(eng, p["block2.proj.weight"], p["block2.proj.bias"], p["block2.norm.weight"], p["block2.norm.bias"], groups)
+        self.res = Pointwise(eng, p["res_conv.weight"], p["res_conv.bias"]) if "res_conv.weight" in p else None
+
+    def forward(self, x, time_emb):
+        t = self.torch
+        x = x.to(self.eng.device, t.float32).contiguous()
+        ss = self.mlp.forward(time_emb)                                     # [B, 2 * Cout]
+        cout = ss.shape[1] // 2
+        scale, shift = ss[:, :cout].reshape(-1, cout, 1), ss[:, cout:].reshape(-1, cout, 1)
+        h = self.block1.forward(x, (scale, shift))
+        h = self.block2.forward(h)
+        return h + (self.res.forward(x) if self.res is not None else x)
+
+    def backward(self, dy):
+        """-> dict of gradients keyed like the parameters, plus dx and dtime_emb"""
+        t = self.torch
+        dy = dy.to(self.eng.device, t.float32).contiguous()
+        g2 = self.block2.backward(dy)
+        g1 = self.block1.backward(g2["dx"])
+        dss = t.cat([g1["dscale"].reshape(dy.shape[0], -1), g1["dshift"].reshape(dy.shape[0], -1)], dim=1)
+        gm = self.mlp.backward(dss)
+        out = {"mlp.1.weight": gm["dw"], "mlp.1.bias": gm["db"], "dtime_emb": gm["dx"],
+               "block1.proj.weight": g1["dw"], "block1.proj.bias": g1["db"], "block1.norm.weight": g1["dgamma"], "block1.norm.bias": g1["dbeta"],
+               "block2.proj.weight": g2["dw"], "block2.proj.bias": g2["db"], "block2.norm.weight": g2["dgamma"], "block2.norm.bias": g2["dbeta"]}
+        dx = g1["dx"]
+        if self.res is not None:
+            gr = self.res.backward(dy)
+            out["res_conv.weight"], out["res_conv.bias"] = gr["dw"].reshape(gr["dw"].shape[0], -1, 1), gr["db"]
+            dx = dx + gr["dx"]
+        else:
+            dx = dx + dy
+        out["dx"] = dx
+        return out

@@ -44,3 +44,13 @@ def adam_step(p, g, m, v, step: int, lr: float, b1: float = 0.9, b2: float = 0.9
     v = b2 * v + (1 - b2) * g * g
     denom = v.sqrt() / (1 - b2 ** step) ** 0.5 + eps
     return p - (lr / (1 - b1 ** step)) * (m / denom), m, v
+
+
+def resnet_block_forward(p, x, time_emb, groups: int = 8):
+    """ResnetBlock.forward, unet.py:157-192 (use_film False): p holds the block's parameters keyed as in its state dict."""
+    ss = F.linear(F.silu(time_emb), p["mlp.1.weight"], p["mlp.1.bias"]).unsqueeze(-1)
+    scale, shift = ss.chunk(2, dim=1)
+    h = block_forward(x, p["block1.proj.weight"], p["block1.proj.bias"], p["block1.norm.weight"], p["block1.norm.bias"], scale, shift, groups)
+    h = block_forward(h, p["block2.proj.weight"], p["block2.proj.bias"], p["block2.norm.weight"], p["block2.norm.bias"], None, None, groups)
+    res = F.conv1d(x, p["res_conv.weight"], p["res_conv.bias"]) if "res_conv.weight" in p else x
+    return h + res

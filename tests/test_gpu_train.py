@@ -91,3 +91,18 @@ def test_adam_steps_match_torch_optim_adam():
         opt.step(T(g[f"adam.g{k}"]))
         assert float((p.cpu() - T(g[f"adam.p{k + 1}"])).abs().max()) < 3e-7, k      # |p| ~ 0.2, steps of 3e-4: a few ulp
     assert not bool(torch.isnan(p).any())
+
+
+def test_resnet_block_forward_backward_reference_vectors():
+    """A whole ResnetBlock with time embedding (unet.py:157-192), with and without res_conv, against the reference's autograd."""
+    g = load_golden("train_block")
+    e = engine("r84", "f32")
+    for tag in ("rb1", "rb2"):
+        p = {k[len(tag) + 3:]: T(g[k]) for k in list(g.keys()) if k.startswith(tag + ".p.")}
+        rb = TR.ResnetBlock(e, p)
+        y = rb.forward(T(g[f"{tag}.x"]), T(g[f"{tag}.temb"]))
+        assert rel(y.cpu().numpy(), g[f"{tag}.y"]) < TOL
+        grads = rb.backward(T(g[f"{tag}.dy"]))
+        assert rel(grads["dx"].cpu().numpy(), g[f"{tag}.dx"]) < TOL and rel(grads["dtime_emb"].cpu().numpy(), g[f"{tag}.dtemb"]) < TOL
+        for name in p:
+            assert rel(grads[name].cpu().numpy().reshape(g[f"{tag}.g.{name}"].shape), g[f"{tag}.g.{name}"]) < TOL, (tag, name)

@@ -45,3 +45,16 @@ def test_oracle_layernorm_and_adam_match_reference():
     for k in range(3):
         p, m, v = TO.adam_step(p, T(g[f"adam.g{k}"]), m, v, k + 1, 3e-4)
         assert float((p - T(g[f"adam.p{k + 1}"])).abs().max()) < 2e-7, k
+
+
+def test_oracle_resnet_block_matches_reference_autograd():
+    g = load_golden("train_block")
+    for tag in ("rb1", "rb2"):
+        p = {k[len(tag) + 3:]: T(g[k]).requires_grad_() for k in list(g.keys()) if k.startswith(tag + ".p.")}
+        x, temb = T(g[f"{tag}.x"]).requires_grad_(), T(g[f"{tag}.temb"]).requires_grad_()
+        y = TO.resnet_block_forward(p, x, temb)
+        assert rel_err(y.detach().numpy(), g[f"{tag}.y"]) < 1e-5
+        y.backward(T(g[f"{tag}.dy"]))
+        assert rel_err(x.grad.numpy(), g[f"{tag}.dx"]) < 5e-5 and rel_err(temb.grad.numpy(), g[f"{tag}.dtemb"]) < 5e-5
+        for name, t in p.items():
+            assert rel_err(t.grad.numpy(), g[f"{tag}.g.{name}"]) < 5e-5, (tag, name)

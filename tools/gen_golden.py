@@ -343,6 +343,24 @@ def main():
             opt.step()
             out[f"adam.g{k}"] = np32(gk)
             out[f"adam.p{k + 1}"] = np32(pa)
+        # a whole ResnetBlock with time embedding (unet.py:157-192) under autograd: with and without res_conv
+        from srcs.modules.unet import ResnetBlock
+        for tag, cin, cout, L in (("rb1", 32, 64, 96), ("rb2", 64, 64, 50)):
+            rb = ResnetBlock(cin, cout, time_emb_dim=128, groups=8)
+            with torch.no_grad():
+                for blk in (rb.block1, rb.block2):
+                    blk.norm.weight.copy_(torch.rand(cout, generator=gg) + 0.5)
+                    blk.norm.bias.copy_(torch.randn(cout, generator=gg) * 0.1)
+            x = torch.randn(2, cin, L, generator=gg, requires_grad=True)
+            temb = torch.randn(2, 128, generator=gg, requires_grad=True)
+            y = rb(x, temb)
+            dy = torch.randn(y.shape, generator=gg)
+            y.backward(dy)
+            out.update({f"{tag}.x": np32(x), f"{tag}.temb": np32(temb), f"{tag}.y": np32(y), f"{tag}.dy": np32(dy), f"{tag}.dx": np32(x.grad),
+                        f"{tag}.dtemb": np32(temb.grad)})
+            for name, prm in rb.named_parameters():
+                out[f"{tag}.p.{name}"] = np32(prm)
+                out[f"{tag}.g.{name}"] = np32(prm.grad)
         np.savez_compressed(os.path.join(OUT, "train_block.npz"), **out)
         print("train_block: loss", float(loss), "dw absmax", float(np.abs(out["a.dw"]).max()), "ln dg absmax", float(np.abs(out["ln.dg"]).max()))
 
