@@ -242,6 +242,14 @@ int ldc_train_pointwise_forward(ldc_ctx* ctx, const float* x, const float* w, co
 int ldc_train_pointwise_backward(ldc_ctx* ctx, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int pre_silu,
                                  float* dx, float* dw, float* db, void* stream);
 
+/* LinearAttention core (srcs/modules/unet.py:208-221: both softmaxes and both einsums, between to_qkv and to_out), forward and backward.
+ * qkv [B, 3*heads*dim_head, N] float32 = [q | k | v] (the to_qkv output), out [B, heads*dim_head, N]; `ws`:
+ * ldc_train_linattn_ws_floats() floats carrying the saved softmaxes and context to the backward pass; dqkv in the layout of qkv. */
+int64_t ldc_train_linattn_ws_floats(int B, int heads, int dim_head, int N);
+int ldc_train_linattn_forward(ldc_ctx* ctx, const float* qkv, int B, int heads, int dim_head, int N, float* out, float* ws, void* stream);
+int ldc_train_linattn_backward(ldc_ctx* ctx, const float* dout, const float* qkv, int B, int heads, int dim_head, int N, float* ws, float* dqkv,
+                               void* stream);
+
 /* One Adam step over flat device buffers, in place (srcs/train.py:365-371: optim.Adam(params, lr); torch's defaults are
  * beta1 0.9, beta2 0.999, eps 1e-8, no weight decay, no amsgrad).  `step` counts from 1 (bias correction). */
 int ldc_train_adam_step(ldc_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,

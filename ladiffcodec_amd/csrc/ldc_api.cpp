@@ -245,6 +245,8 @@ struct ldc_ctx {
   int side_streams = 0;
   int fuse_kmax = 1;
   int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
+  int coop_launch = 0;          // LDC_COOP_LAUNCH: hipLaunchCooperativeKernel for the cooperative LSTM (see seanet.hip)
+  int coop_resident[2] = {0, 0};   // [H == 512]: the cooperative LSTM's H/4 workgroups fit the device together (asked at ldc_create)
   int fuse_attn_tail = 1;       // LinearAttention out + to_out conv + LayerNorm + residual in one launch (bf16 engine)
   // Flow control of the step-graph replays: with more than ~10-20 multi-thousand-node graph launches outstanding the ROCm 7.2
   // runtime's enqueue path degrades (a decode queued behind a running one took 247 instead of 157 ms), so a replay waits on
@@ -973,6 +975,9 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->strip_mode = env_int("LDC_STRIP", 0);
   c->strip_min_wgs = env_int("LDC_STRIP_MIN", 96);
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
+  c->coop_launch = getenv("LDC_COOP_LAUNCH") ? 1 : 0;
+  c->coop_resident[0] = lstm_coop_resident(256) ? 1 : 0;
+  c->coop_resident[1] = lstm_coop_resident(512) ? 1 : 0;
   c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
   c->graph_steps = std::max(0, env_int("LDC_GRAPH_STEPS", 0));   // 0 = by chain count (denoise_loop)
   c->plan_bytes_cap = (size_t)std::max(1, env_int("LDC_PLAN_CACHE_GB", 48)) << 30;
@@ -1205,7 +1210,7 @@ static int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in
         for (size_t n = 0; n < op.lstm.size(); ++n) {
           void* pre = R.ar->alloc((size_t)R.B * L * 4 * H * 4);
           void* o = R.ar->alloc((size_t)R.B * L * H * 4);
-          const bool coop = op.lstm[n].w_rm && !R.c->lstm_stream_only;
+          const bool coop = op.lstm[n].w_rm && !R.c->lstm_stream_only && R.c->coop_resident[H == 512 ? 1 : 0];
           void* lws = coop ? R.ar->alloc(lstm_coop_ws_bytes(H)) : nullptr;
           if (!R.dry) {
             ConvCall cc;
@@ -1213,7 +1218,7 @@ static int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in
             HIPCHK(launch_conv(op.lstm[n].in_proj, cc, R.s));
             const bool lastl = n + 1 == op.lstm.size();
             hipError_t le = hipErrorCooperativeLaunchTooLarge;
-            if (coop) le = launch_lstm_coop(DT_F32, pre, op.lstm[n].w_rm, o, lastl ? x : nullptr, R.B, L, H, lws, R.c->dev_flag_dev, R.s);
+            if (coop) le = launch_lstm_coop(DT_F32, pre, op.lstm[n].w_rm, o, lastl ? x : nullptr, R.B, L, H, lws, R.c->dev_flag_dev, R.c->coop_launch, R.s);
             if (le == hipErrorCooperativeLaunchTooLarge) {   // (or not eligible): one workgroup per item, W_hh streamed from L2
               (void)hipGetLastError();
               le = launch_lstm_layer(DT_F32, pre, op.lstm[n].w_hh, o, lastl ? x : nullptr, R.B, L, H, R.s);
@@ -2504,6 +2509,29 @@ extern "C" int ldc_train_pointwise_backward(ldc_ctx* c, const float* dy, const f
   if (!dy || !x || !w || !dw || B < 1 || Cin < 1 || Cout < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
   hipStream_t s = pick_stream(c, stream);
   HIPCHK(launch_train_pw_backward(dy, x, w, B, Cin, Cout, L, pre_silu ? 1 : 0, dx, dw, db, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int64_t ldc_train_linattn_ws_floats(int B, int heads, int dim_head, int N) {
+  return (int64_t)train_linattn_ws_floats(B, heads, dim_head, N);
+}
+
+extern "C" int ldc_train_linattn_forward(ldc_ctx* c, const float* qkv, int B, int heads, int dim_head, int N, float* out, float* ws, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!qkv || !out || !ws || B < 1 || heads < 1 || N < 1 || dim_head < 1 || dim_head > 64 || 256 % dim_head)
+    return fail(LDC_E_INVALID, "bad arguments (dim_head must divide 256 and be <= 64)");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_linattn_forward(qkv, B, heads, dim_head, N, out, ws, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_linattn_backward(ldc_ctx* c, const float* dout, const float* qkv, int B, int heads, int dim_head, int N, float* ws,
+                                          float* dqkv, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!dout || !qkv || !ws || !dqkv || B < 1 || heads < 1 || N < 1 || dim_head < 1 || dim_head > 64 || 256 % dim_head)
+    return fail(LDC_E_INVALID, "bad arguments (dim_head must divide 256 and be <= 64)");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_linattn_backward(dout, qkv, B, heads, dim_head, N, ws, dqkv, s));
   return finish_stream(c, stream);
 }
 

@@ -223,8 +223,9 @@ size_t lstm_coop_ws_bytes(int H);
 // host_flag: device-visible mapped word set to 1 when the bounded h-exchange spin times out (the output is then NaN).
 // Launched cooperatively: returns hipErrorCooperativeLaunchTooLarge when the H/4 workgroups cannot be co-resident
 // (the caller falls back to launch_lstm_layer).
+bool lstm_coop_resident(int H);   // occupancy query x CU count (with a margin) >= the H/4 workgroups that must be co-resident
 hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* out, const void* skip, int B, int T, int H,
-                            void* ws, unsigned* host_flag, hipStream_t s);
+                            void* ws, unsigned* host_flag, int coop_launch, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // rvq.hip
@@ -250,6 +251,9 @@ hipError_t launch_train_pw_forward(const float* x, const float* w, const float* 
                                    hipStream_t s);
 hipError_t launch_train_pw_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int pre_silu, float* dx,
                                     float* dw, float* db, hipStream_t s);
+size_t train_linattn_ws_floats(int B, int H, int D, int N);
+hipError_t launch_train_linattn_forward(const float* qkv, int B, int H, int D, int N, float* o, float* ws, hipStream_t s);
+hipError_t launch_train_linattn_backward(const float* d_o, const float* qkv, int B, int H, int D, int N, float* ws, float* dqkv, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, hipStream_t s);
 hipError_t launch_train_ln_forward(const float* x, const float* g, int B, int C, int L, float* y, float* stats, hipStream_t s);
 hipError_t launch_train_ln_backward(const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L, float* dx,

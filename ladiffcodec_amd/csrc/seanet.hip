@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const f
 
 template <typename T>
 static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out, const void* skip, int B, int T_len, int H,
-                                   void* ws, unsigned* host_flag, hipStream_t s) {
+                                   void* ws, unsigned* host_flag, int coop_launch, hipStream_t s) {
   float* hbuf = reinterpret_cast<float*>(ws);
   unsigned* sync = reinterpret_cast<unsigned*>(hbuf + (size_t)2 * 32 * H);
   const size_t esz = sizeof(T);
@@ -366,28 +366,13 @@ static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out
     // ONCE per kernel against the occupancy query (below); the launch itself is a plain one.  hipLaunchCooperativeKernel
     // makes the same check per launch, but on ROCm 7.2 it goes through a device-wide cooperative queue: enqueued while an
     // earlier decode is still running it cost ~90 ms per decode (247 vs 157 ms with two decodes queued on a caller's
-    // stream).  LDC_COOP_LAUNCH=1 restores it.  A grid that does not become resident at run time (another process holding
+    // stream).  `coop_launch` (LDC_COOP_LAUNCH=1) restores it.  A grid that does not become resident at run time (another process holding
     // the CUs) still ends in the bounded spin's timeout: NaN output + the host-mapped failure flag.
     const void* pp = p; void* oo = o; const void* kk = k; int nbv = nb, tl = T_len;
     void* args[] = {&pp, &w_rm, &oo, &kk, &nbv, &tl, &hbuf, &sync, &host_flag};
     const void* fn = H == 512 ? reinterpret_cast<const void*>(lstm_coop_kernel<T, 512>) : reinterpret_cast<const void*>(lstm_coop_kernel<T, 256>);
-    static const bool coop_launch = getenv("LDC_COOP_LAUNCH") != nullptr;
-    if (coop_launch) {
-      e = hipLaunchCooperativeKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
-    } else {
-      static int fits[2] = {-1, -1};   // [H == 512]: -1 unknown, 0 no, 1 yes
-      int& f = fits[H == 512 ? 1 : 0];
-      if (f < 0) {
-        int dev = 0, per_cu = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess)
-          return hipErrorUnknown;
-        // the occupancy API can over-report by one block per CU for SGPR-heavy kernels (MI355X_MICROARCH.md): demand a margin
-        f = (long long)std::max(0, per_cu - 1) * cus >= H / 4 || ((long long)per_cu * cus >= 2 * (H / 4)) ? 1 : 0;
-      }
-      if (!f) return hipErrorCooperativeLaunchTooLarge;
-      e = hipLaunchKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
-    }
+    if (coop_launch) e = hipLaunchCooperativeKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
+    else e = hipLaunchKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -395,12 +380,26 @@ static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out
 
 bool lstm_coop_eligible(int H) { return H == 256 || H == 512; }
 
+// Can the H/4 workgroups of the cooperative kernel be resident together on the current device?  Asked once per context
+// (ldc_create); the occupancy API can over-report by one block per CU for SGPR-heavy kernels (MI355X_MICROARCH.md), hence the margin.
+bool lstm_coop_resident(int H) {
+  if (!lstm_coop_eligible(H)) return false;
+  const void* fn = H == 512 ? reinterpret_cast<const void*>(lstm_coop_kernel<float, 512>) : reinterpret_cast<const void*>(lstm_coop_kernel<float, 256>);
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return (long long)std::max(0, per_cu - 1) * cus >= H / 4 || (long long)per_cu * cus >= 2 * (H / 4);
+}
+
 // w_rm: row-major [4H][H] fp32; ws: lstm_coop_ws_bytes(H) bytes of device scratch owned by the caller
 hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* out, const void* skip, int B, int T, int H,
-                            void* ws, unsigned* host_flag, hipStream_t s) {
+                            void* ws, unsigned* host_flag, int coop_launch, hipStream_t s) {
   if (!lstm_coop_eligible(H)) return hipErrorInvalidValue;
-  return dt == DT_F32 ? lstm_coop_launch<float>(pre, w_rm, out, skip, B, T, H, ws, host_flag, s)
-                      : lstm_coop_launch<__bf16>(pre, w_rm, out, skip, B, T, H, ws, host_flag, s);
+  return dt == DT_F32 ? lstm_coop_launch<float>(pre, w_rm, out, skip, B, T, H, ws, host_flag, coop_launch, s)
+                      : lstm_coop_launch<__bf16>(pre, w_rm, out, skip, B, T, H, ws, host_flag, coop_launch, s);
 }
 
 // w_hh points at: [4H][H] row-major for the register variants (H = 64, 128), k-major [H/4][4H][4] otherwise.

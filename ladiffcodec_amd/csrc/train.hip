@@ -8,6 +8,8 @@
 //   channel LayerNorm fwd / bwd   unet.py:82-101 (PreNorm and to_out of the attention blocks)
 //   pointwise linear fwd / bwd    unet.py:163-166,171 (time-embedding MLP SiLU -> Linear, 1x1 res_conv): with the two Blocks the
 //                                 whole ResnetBlock (unet.py:157-192) runs forward and backward (ladiffcodec_amd/train.py)
+//   LinearAttention core fwd/bwd  unet.py:208-221 (both softmaxes and both einsums); with the pointwise maps and the LayerNorm the whole
+//                                 Residual(PreNorm(LinearAttention)) block runs forward and backward (ladiffcodec_amd/train.py)
 //   Adam step                     srcs/train.py:365-371 (optim.Adam(params, lr)), flat parameter / gradient / moment buffers
 //
 // fp32 throughout, reference layouts [B, C, L].  This slice is the correctness baseline of the training path (gradients
@@ -93,6 +95,14 @@ __device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threa
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {   // 256 threads
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 __global__ __launch_bounds__(256) void ws_forward_kernel(const float* w, int inner, float* wn, float* rstd) {
@@ -458,6 +468,140 @@ hipError_t launch_train_pw_backward(const float* dy, const float* x, const float
   if (dx) hipLaunchKernelGGL(pw_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, dy, x, w, Cin, Cout, L, pre_silu, dx);
   hipLaunchKernelGGL(pw_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, dy, x, B, Cin, Cout, L, pre_silu, dw);
   if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L, db);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LinearAttention core (srcs/modules/unet.py:208-221, between to_qkv and to_out), forward and backward, [B, C, L] fp32:
+//   qs = softmax_d(q) * scale,  ks = softmax_n(k),  ctx[d, e] = sum_n ks[d, n] v[e, n],  o[e, n] = sum_d ctx[d, e] qs[d, n]
+// per (item, head); qkv = [q | k | v] with channel = h * D + d.  Workspace (floats): qs, ks [B, H*D, N] each and ctx [B, H, D, D]
+// saved by the forward pass; the backward pass adds dctx [B, H, D, D] and a [B, H*D] row-dot buffer.  D <= 64.
+//   dctx[d, e] = sum_n do[e, n] qs[d, n]          dqs[d, n] = sum_e ctx[d, e] do[e, n]
+//   dks[d, n]  = sum_e dctx[d, e] v[e, n]         dv[e, n]  = sum_d ks[d, n] dctx[d, e]
+//   dq = s (g - sum_d s g), s = qs / scale, g = dqs * scale        dk = ks (dks - sum_n ks dks)
+// ---------------------------------------------------------------------------------------------
+size_t train_linattn_ws_floats(int B, int H, int D, int N) {
+  return (size_t)2 * B * H * D * N + (size_t)2 * B * H * D * D + (size_t)B * H * D + 64;
+}
+struct LaWs { float *qs, *ks, *ctx, *dctx, *rowdot; };
+static LaWs la_carve(float* ws, int B, int H, int D, int N) {
+  LaWs w;
+  float* p = ws;
+  w.qs = p; p += (size_t)B * H * D * N;
+  w.ks = p; p += (size_t)B * H * D * N;
+  w.ctx = p; p += (size_t)B * H * D * D;
+  w.dctx = p; p += (size_t)B * H * D * D;
+  w.rowdot = p;
+  return w;
+}
+// one block per (b, h, d): ks[d, :] = softmax over positions of k[d, :]
+__global__ __launch_bounds__(256) void la_ksoftmax_kernel(const float* qkv, int H, int D, int N, float* ks) {
+  __shared__ float red[4];
+  const int d = blockIdx.x, h = blockIdx.y, b = blockIdx.z, HD = H * D;
+  const float* kr = qkv + ((size_t)b * 3 * HD + HD + h * D + d) * N;
+  float m = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += 256) m = fmaxf(m, kr[n]);
+  m = block_max(m, red);
+  float sum = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) sum += expf(kr[n] - m);
+  sum = block_sum(sum, red);
+  float* out = ks + ((size_t)b * HD + h * D + d) * N;
+  for (int n = threadIdx.x; n < N; n += 256) out[n] = expf(kr[n] - m) / sum;
+}
+// one thread per (b, h, n): qs[:, n] = softmax over d of q[:, n], times scale
+__global__ __launch_bounds__(256) void la_qsoftmax_kernel(const float* qkv, int H, int D, int N, float scale, float* qs) {
+  const int n = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, b = blockIdx.z, HD = H * D;
+  if (n >= N) return;
+  const float* qr = qkv + ((size_t)b * 3 * HD + h * D) * N + n;
+  float m = -INFINITY;
+  for (int d = 0; d < D; ++d) m = fmaxf(m, qr[(size_t)d * N]);
+  float sum = 0.f;
+  for (int d = 0; d < D; ++d) sum += expf(qr[(size_t)d * N] - m);
+  float* out = qs + ((size_t)b * HD + h * D) * N + n;
+  for (int d = 0; d < D; ++d) out[(size_t)d * N] = expf(qr[(size_t)d * N] - m) / sum * scale;
+}
+// one block per (b, h, d): out[d, e] = sum_n a[d, n] * bsrc[e, n]   (ctx from (ks, v); dctx from (qs, do)); fixed-order reduction
+__global__ __launch_bounds__(256) void la_outer_kernel(const float* a, const float* bsrc, size_t a_item, size_t b_item, int H, int D, int N,
+                                                       float* out) {
+  __shared__ float part[256];
+  const int d = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const float* ar = a + (size_t)b * a_item + (size_t)(h * D + d) * N;
+  const int e = threadIdx.x % D, grp = threadIdx.x / D, ngrp = 256 / D;   // D divides 256 (32, 64)
+  const float* br = bsrc + (size_t)b * b_item + (size_t)(h * D + e) * N;
+  float acc = 0.f;
+  for (int n = grp; n < N; n += ngrp) acc = fmaf(ar[n], br[n], acc);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < D) {
+    float t = 0.f;
+    for (int g = 0; g < ngrp; ++g) t += part[g * D + threadIdx.x];
+    out[(((size_t)b * H + h) * D + d) * D + threadIdx.x] = t;
+  }
+}
+// one thread per (b, h, n): y[e, n] = sum_d m[d, e] * x[d, n]  (TRANS = false: o from (ctx, qs)) or y[d, n] = sum_e m[d, e] * x[e, n] (TRANS = true)
+template <bool TRANS>
+__global__ __launch_bounds__(256) void la_apply_kernel(const float* m, const float* x, size_t x_item, int H, int D, int N, float* y, size_t y_item) {
+  extern __shared__ float sm[];   // [D][D]
+  const int h = blockIdx.y, b = blockIdx.z;
+  for (int i = threadIdx.x; i < D * D; i += 256) sm[i] = m[((size_t)b * H + h) * D * D + i];
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* xr = x + (size_t)b * x_item + (size_t)(h * D) * N + n;
+  float* yr = y + (size_t)b * y_item + (size_t)(h * D) * N + n;
+  for (int o = 0; o < D; ++o) {
+    float acc = 0.f;
+    for (int i = 0; i < D; ++i) acc = fmaf(TRANS ? sm[o * D + i] : sm[i * D + o], xr[(size_t)i * N], acc);
+    yr[(size_t)o * N] = acc;
+  }
+}
+// dq from dqs (in place in `dq`, which holds dqs on entry): softmax over d backward; one thread per (b, h, n)
+__global__ __launch_bounds__(256) void la_dq_kernel(const float* qs, int H, int D, int N, float scale, float* dq, size_t dq_item) {
+  const int n = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, b = blockIdx.z, HD = H * D;
+  if (n >= N) return;
+  const float* sr = qs + ((size_t)b * HD + h * D) * N + n;
+  float* gr = dq + (size_t)b * dq_item + (size_t)(h * D) * N + n;
+  const float inv = 1.0f / scale;
+  float dot = 0.f;
+  for (int d = 0; d < D; ++d) dot = fmaf(sr[(size_t)d * N] * inv, gr[(size_t)d * N] * scale, dot);
+  for (int d = 0; d < D; ++d) { const float sv = sr[(size_t)d * N] * inv; gr[(size_t)d * N] = sv * (gr[(size_t)d * N] * scale - dot); }
+}
+// dk from dks (in place): softmax over n backward; one block per (b, h, d)
+__global__ __launch_bounds__(256) void la_dk_kernel(const float* ks, int H, int D, int N, float* dk, size_t dk_item) {
+  __shared__ float red[4];
+  const int d = blockIdx.x, h = blockIdx.y, b = blockIdx.z, HD = H * D;
+  const float* kr = ks + ((size_t)b * HD + h * D + d) * N;
+  float* gr = dk + (size_t)b * dk_item + (size_t)(h * D + d) * N;
+  float dot = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) dot = fmaf(kr[n], gr[n], dot);
+  dot = block_sum(dot, red);
+  for (int n = threadIdx.x; n < N; n += 256) gr[n] = kr[n] * (gr[n] - dot);
+}
+hipError_t launch_train_linattn_forward(const float* qkv, int B, int H, int D, int N, float* o, float* ws, hipStream_t s) {
+  if (D < 1 || D > 64 || 256 % D) return hipErrorInvalidValue;
+  const LaWs w = la_carve(ws, B, H, D, N);
+  const size_t HD = (size_t)H * D;
+  const float scale = 1.0f / sqrtf((float)D);
+  hipLaunchKernelGGL(la_ksoftmax_kernel, dim3(D, H, B), dim3(256), 0, s, qkv, H, D, N, w.ks);
+  hipLaunchKernelGGL(la_qsoftmax_kernel, dim3((N + 255) / 256, H, B), dim3(256), 0, s, qkv, H, D, N, scale, w.qs);
+  hipLaunchKernelGGL(la_outer_kernel, dim3(D, H, B), dim3(256), 0, s, w.ks, qkv + 2 * HD * N, HD * N, 3 * HD * N, H, D, N, w.ctx);
+  hipLaunchKernelGGL(la_apply_kernel<false>, dim3((N + 255) / 256, H, B), dim3(256), (size_t)D * D * 4, s, w.ctx, w.qs, HD * N, H, D, N, o, HD * N);
+  return hipGetLastError();
+}
+// dqkv [B, 3*H*D, N] = [dq | dk | dv]
+hipError_t launch_train_linattn_backward(const float* d_o, const float* qkv, int B, int H, int D, int N, float* ws, float* dqkv, hipStream_t s) {
+  if (D < 1 || D > 64 || 256 % D) return hipErrorInvalidValue;
+  const LaWs w = la_carve(ws, B, H, D, N);
+  const size_t HD = (size_t)H * D;
+  const float scale = 1.0f / sqrtf((float)D);
+  const dim3 gn((N + 255) / 256, H, B), gd(D, H, B);
+  hipLaunchKernelGGL(la_outer_kernel, gd, dim3(256), 0, s, w.qs, d_o, HD * N, HD * N, H, D, N, w.dctx);                       // dctx[d, e]
+  hipLaunchKernelGGL(la_apply_kernel<true>, gn, dim3(256), (size_t)D * D * 4, s, w.ctx, d_o, HD * N, H, D, N, dqkv, 3 * HD * N);   // dqs -> dq slot
+  hipLaunchKernelGGL(la_dq_kernel, gn, dim3(256), 0, s, w.qs, H, D, N, scale, dqkv, 3 * HD * N);
+  hipLaunchKernelGGL(la_apply_kernel<true>, gn, dim3(256), (size_t)D * D * 4, s, w.dctx, qkv + 2 * HD * N, 3 * HD * N, H, D, N, dqkv + HD * N,
+                     3 * HD * N);                                                                                          // dks -> dk slot
+  hipLaunchKernelGGL(la_dk_kernel, gd, dim3(256), 0, s, w.ks, H, D, N, dqkv + HD * N, 3 * HD * N);
+  hipLaunchKernelGGL(la_apply_kernel<false>, gn, dim3(256), (size_t)D * D * 4, s, w.dctx, w.ks, HD * N, H, D, N, dqkv + 2 * HD * N, 3 * HD * N);   // dv
   return hipGetLastError();
 }
 

@@ -237,3 +237,49 @@ class ResnetBlock:
             dx = dx + dy
         out["dx"] = dx
         return out
+
+
+class LinearAttention:
+    """Residual(PreNorm(dim, LinearAttention(dim))) of the UNet (srcs/modules/unet.py:194-222 inside :103-116's wrappers),
+    forward and backward: LayerNorm -> to_qkv (1x1, no bias) -> attention core -> to_out (1x1 + LayerNorm) -> + x."""
+
+    def __init__(self, eng, p: dict, heads: int = 4, dim_head: int = 32):
+        """p: 'norm.g' (PreNorm), 'to_qkv.weight', 'to_out.0.weight', 'to_out.0.bias', 'to_out.1.g'."""
+        self.eng, self.lib, self.torch = eng, eng.lib, eng.torch
+        self.heads, self.dim_head = heads, dim_head
+        self.norm = LayerNorm(eng, p["norm.g"])
+        self.to_qkv = Pointwise(eng, p["to_qkv.weight"], None)
+        self.to_out = Pointwise(eng, p["to_out.0.weight"], p["to_out.0.bias"])
+        self.out_norm = LayerNorm(eng, p["to_out.1.g"])
+
+    def forward(self, x):
+        t = self.torch
+        x = x.to(self.eng.device, t.float32).contiguous()
+        B, _, N = x.shape
+        qkv = self.to_qkv.forward(self.norm.forward(x))
+        hd = self.heads * self.dim_head
+        o = t.empty(B, hd, N, dtype=t.float32, device=self.eng.device)
+        ws = t.empty(int(self.lib.ldc_train_linattn_ws_floats(B, self.heads, self.dim_head, N)), dtype=t.float32, device=self.eng.device)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_linattn_forward(self.eng._ctx, qkv.data_ptr(), B, self.heads, self.dim_head, N, o.data_ptr(), ws.data_ptr(), s))
+        self.eng._exit()
+        self._saved = (qkv, ws)
+        return self.out_norm.forward(self.to_out.forward(o)) + x
+
+    def backward(self, dy):
+        """-> dict of parameter gradients plus dx"""
+        t = self.torch
+        dy = dy.to(self.eng.device, t.float32).contiguous()
+        qkv, ws = self._saved
+        B, _, N = qkv.shape
+        d_lin, dg_out = self.out_norm.backward(dy)
+        g_out = self.to_out.backward(d_lin)
+        dqkv = t.empty_like(qkv)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_linattn_backward(self.eng._ctx, g_out["dx"].data_ptr(), qkv.data_ptr(), B, self.heads, self.dim_head, N,
+                                                    ws.data_ptr(), dqkv.data_ptr(), s))
+        self.eng._exit()
+        g_qkv = self.to_qkv.backward(dqkv)
+        dxn, dg_pre = self.norm.backward(g_qkv["dx"])
+        return {"norm.g": dg_pre, "to_qkv.weight": g_qkv["dw"], "to_out.0.weight": g_out["dw"], "to_out.0.bias": g_out["db"],
+                "to_out.1.g": dg_out, "dx": dxn + dy}

@@ -54,3 +54,17 @@ def resnet_block_forward(p, x, time_emb, groups: int = 8):
     h = block_forward(h, p["block2.proj.weight"], p["block2.proj.bias"], p["block2.norm.weight"], p["block2.norm.bias"], None, None, groups)
     res = F.conv1d(x, p["res_conv.weight"], p["res_conv.bias"]) if "res_conv.weight" in p else x
     return h + res
+
+
+def linear_attention_block(p, x, heads: int = 4, dim_head: int = 32):
+    """Residual(PreNorm(dim, LinearAttention(dim))), unet.py:103-116 and 194-222; p keyed as train.LinearAttention expects."""
+    b, c, n = x.shape
+    xn = layer_norm(x, p["norm.g"].reshape(-1))
+    q, k, v = F.conv1d(xn, p["to_qkv.weight"]).chunk(3, dim=1)
+    q, k, v = (t.reshape(b, heads, dim_head, n) for t in (q, k, v))
+    q = q.softmax(dim=-2) * dim_head ** -0.5
+    k = k.softmax(dim=-1)
+    context = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", context, q).reshape(b, heads * dim_head, n)
+    out = F.conv1d(out, p["to_out.0.weight"], p["to_out.0.bias"])
+    return layer_norm(out, p["to_out.1.g"].reshape(-1)) + x

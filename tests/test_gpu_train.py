@@ -106,3 +106,17 @@ def test_resnet_block_forward_backward_reference_vectors():
         assert rel(grads["dx"].cpu().numpy(), g[f"{tag}.dx"]) < TOL and rel(grads["dtime_emb"].cpu().numpy(), g[f"{tag}.dtemb"]) < TOL
         for name in p:
             assert rel(grads[name].cpu().numpy().reshape(g[f"{tag}.g.{name}"].shape), g[f"{tag}.g.{name}"]) < TOL, (tag, name)
+
+
+def test_linear_attention_block_forward_backward_reference_vectors():
+    """Residual(PreNorm(LinearAttention)) (unet.py:103-116,194-222) against the reference's autograd."""
+    g = load_golden("train_block")
+    e = engine("r84", "f32")
+    p = {k[5:]: T(g[k]) for k in list(g.keys()) if k.startswith("la.p.")}
+    att = TR.LinearAttention(e, p)
+    y = att.forward(T(g["la.x"]))
+    assert rel(y.cpu().numpy(), g["la.y"]) < TOL
+    grads = att.backward(T(g["la.dy"]))
+    assert rel(grads["dx"].cpu().numpy(), g["la.dx"]) < TOL
+    for name in p:
+        assert rel(grads[name].cpu().numpy().reshape(g[f"la.g.{name}"].shape), g[f"la.g.{name}"]) < TOL, name

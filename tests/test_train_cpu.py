@@ -58,3 +58,15 @@ def test_oracle_resnet_block_matches_reference_autograd():
         assert rel_err(x.grad.numpy(), g[f"{tag}.dx"]) < 5e-5 and rel_err(temb.grad.numpy(), g[f"{tag}.dtemb"]) < 5e-5
         for name, t in p.items():
             assert rel_err(t.grad.numpy(), g[f"{tag}.g.{name}"]) < 5e-5, (tag, name)
+
+
+def test_oracle_linear_attention_block_matches_reference_autograd():
+    g = load_golden("train_block")
+    p = {k[5:]: T(g[k]).requires_grad_() for k in list(g.keys()) if k.startswith("la.p.")}
+    x = T(g["la.x"]).requires_grad_()
+    y = TO.linear_attention_block(p, x)
+    assert rel_err(y.detach().numpy(), g["la.y"]) < 1e-5
+    y.backward(T(g["la.dy"]))
+    assert rel_err(x.grad.numpy(), g["la.dx"]) < 5e-5
+    for name, t in p.items():
+        assert rel_err(t.grad.numpy(), g[f"la.g.{name}"]) < 5e-5, name

@@ -361,6 +361,21 @@ def main():
             for name, prm in rb.named_parameters():
                 out[f"{tag}.p.{name}"] = np32(prm)
                 out[f"{tag}.g.{name}"] = np32(prm.grad)
+        # Residual(PreNorm(dim, LinearAttention(dim))) under autograd (unet.py:103-116,194-222)
+        from srcs.modules.unet import LinearAttention, PreNorm, Residual
+        att = Residual(PreNorm(64, LinearAttention(64)))
+        with torch.no_grad():
+            att.fn.norm.g.copy_(torch.rand(1, 64, 1, generator=gg) + 0.5)
+            att.fn.fn.to_out[1].g.copy_(torch.rand(1, 64, 1, generator=gg) + 0.5)
+        xa = (torch.randn(2, 64, 150, generator=gg) * 1.5).requires_grad_()
+        ya = att(xa)
+        dya = torch.randn(ya.shape, generator=gg)
+        ya.backward(dya)
+        out.update({"la.x": np32(xa), "la.y": np32(ya), "la.dy": np32(dya), "la.dx": np32(xa.grad)})
+        for name, prm in att.fn.named_parameters():          # norm.g, fn.to_qkv.weight, fn.to_out.0.weight, fn.to_out.0.bias, fn.to_out.1.g
+            key = name[3:] if name.startswith("fn.") else name
+            out[f"la.p.{key}"] = np32(prm)
+            out[f"la.g.{key}"] = np32(prm.grad)
         np.savez_compressed(os.path.join(OUT, "train_block.npz"), **out)
         print("train_block: loss", float(loss), "dw absmax", float(np.abs(out["a.dw"]).max()), "ln dg absmax", float(np.abs(out["ln.dg"]).max()))
 
