@@ -250,6 +250,22 @@ int ldc_train_linattn_forward(ldc_ctx* ctx, const float* qkv, int B, int heads, 
 int ldc_train_linattn_backward(ldc_ctx* ctx, const float* dout, const float* qkv, int B, int heads, int dim_head, int N, float* ws, float* dqkv,
                                void* stream);
 
+/* The remaining layers of Unet1D (srcs/modules/unet.py:248-470) for the assembled forward / backward, [B, C, L] float32:
+ * plain Conv1d with any kernel size / stride / zero padding (init_conv k7 p3 :307, Downsample k4 s2 p1 :64-65, the k3 p1 convs of
+ * Upsample :58-62 and of the last levels, final_conv k1 :372); nearest x2 upsampling and its adjoint; tanh / GELU / SiLU
+ * (`kind` 0 / 1 / 2; dy == NULL: out = f(x), else out = dy * f'(x)); the bottleneck softmax Attention core (:234-245) with
+ * the [B, heads, N, N] attention matrix kept in `ws` (2 * B * heads * N * N floats) for the backward pass. */
+int ldc_train_conv_forward(ldc_ctx* ctx, const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int K, int stride,
+                           int pad, float* y, void* stream);
+int ldc_train_conv_backward(ldc_ctx* ctx, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int Lin, int K, int stride,
+                            int pad, float* dx, float* dw, float* db, void* stream);
+int ldc_train_upsample2(ldc_ctx* ctx, const float* in, int64_t rows, int L, int backward, float* out, void* stream);
+int ldc_train_activation(ldc_ctx* ctx, const float* x, const float* dy, int64_t n, int kind, float* out, void* stream);
+int64_t ldc_train_attn_ws_floats(int B, int heads, int N);
+int ldc_train_attn_forward(ldc_ctx* ctx, const float* qkv, int B, int heads, int dim_head, int N, float* out, float* ws, void* stream);
+int ldc_train_attn_backward(ldc_ctx* ctx, const float* dout, const float* qkv, int B, int heads, int dim_head, int N, float* ws, float* dqkv,
+                            void* stream);
+
 /* One Adam step over flat device buffers, in place (srcs/train.py:365-371: optim.Adam(params, lr); torch's defaults are
  * beta1 0.9, beta2 0.999, eps 1e-8, no weight decay, no amsgrad).  `step` counts from 1 (bias correction). */
 int ldc_train_adam_step(ldc_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,

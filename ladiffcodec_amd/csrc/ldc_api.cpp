@@ -2535,6 +2535,63 @@ extern "C" int ldc_train_linattn_backward(ldc_ctx* c, const float* dout, const f
   return finish_stream(c, stream);
 }
 
+extern "C" int ldc_train_conv_forward(ldc_ctx* c, const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int K,
+                                      int stride, int pad, float* y, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!x || !w || !y || B < 1 || Cin < 1 || Cout < 1 || Lin < 1 || K < 1 || stride < 1 || pad < 0 || (Lin + 2 * pad - K) / stride + 1 < 1)
+    return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_conv_forward(x, w, bias, B, Cin, Cout, Lin, K, stride, pad, y, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_conv_backward(ldc_ctx* c, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int Lin, int K,
+                                       int stride, int pad, float* dx, float* dw, float* db, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!dy || !x || !w || !dw || B < 1 || Cin < 1 || Cout < 1 || Lin < 1 || K < 1 || stride < 1 || pad < 0 || (Lin + 2 * pad - K) / stride + 1 < 1)
+    return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_conv_backward(dy, x, w, B, Cin, Cout, Lin, K, stride, pad, dx, dw, db, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_upsample2(ldc_ctx* c, const float* in, int64_t rows, int L, int backward, float* out, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!in || !out || rows < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_upsample2(in, rows, L, backward ? 1 : 0, out, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_activation(ldc_ctx* c, const float* x, const float* dy, int64_t n, int kind, float* out, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!x || !out || n < 1 || kind < 0 || kind > 2) return fail(LDC_E_INVALID, "bad arguments (kind: 0 tanh, 1 GELU, 2 SiLU)");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_act(x, dy, n, kind, out, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int64_t ldc_train_attn_ws_floats(int B, int heads, int N) { return (int64_t)train_attn_ws_floats(B, heads, N); }
+
+extern "C" int ldc_train_attn_forward(ldc_ctx* c, const float* qkv, int B, int heads, int dim_head, int N, float* out, float* ws, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!qkv || !out || !ws || B < 1 || heads < 1 || N < 1 || dim_head < 1 || dim_head > 64 || 256 % dim_head)
+    return fail(LDC_E_INVALID, "bad arguments (dim_head must divide 256 and be <= 64)");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_attn_forward(qkv, B, heads, dim_head, N, out, ws, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_attn_backward(ldc_ctx* c, const float* dout, const float* qkv, int B, int heads, int dim_head, int N, float* ws,
+                                       float* dqkv, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!dout || !qkv || !ws || !dqkv || B < 1 || heads < 1 || N < 1 || dim_head < 1 || dim_head > 64 || 256 % dim_head)
+    return fail(LDC_E_INVALID, "bad arguments (dim_head must divide 256 and be <= 64)");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_attn_backward(dout, qkv, B, heads, dim_head, N, ws, dqkv, s));
+  return finish_stream(c, stream);
+}
+
 extern "C" int ldc_train_adam_step(ldc_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                                    float lr, float beta1, float beta2, float eps, void* stream) {
   LDCCHK(check_dev(c));

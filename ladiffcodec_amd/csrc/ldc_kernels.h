@@ -254,6 +254,15 @@ hipError_t launch_train_pw_backward(const float* dy, const float* x, const float
 size_t train_linattn_ws_floats(int B, int H, int D, int N);
 hipError_t launch_train_linattn_forward(const float* qkv, int B, int H, int D, int N, float* o, float* ws, hipStream_t s);
 hipError_t launch_train_linattn_backward(const float* d_o, const float* qkv, int B, int H, int D, int N, float* ws, float* dqkv, hipStream_t s);
+hipError_t launch_train_conv_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int K, int S, int P,
+                                     float* y, hipStream_t s);
+hipError_t launch_train_conv_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int Lin, int K, int S, int P,
+                                      float* dx, float* dw, float* db, hipStream_t s);
+hipError_t launch_train_upsample2(const float* in, int64_t rows, int L, int backward, float* out, hipStream_t s);
+hipError_t launch_train_act(const float* x, const float* dy, int64_t n, int kind, float* out, hipStream_t s);
+size_t train_attn_ws_floats(int B, int H, int N);
+hipError_t launch_train_attn_forward(const float* qkv, int B, int H, int D, int N, float* out, float* ws, hipStream_t s);
+hipError_t launch_train_attn_backward(const float* d_o, const float* qkv, int B, int H, int D, int N, float* ws, float* dqkv, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, hipStream_t s);
 hipError_t launch_train_ln_forward(const float* x, const float* g, int B, int C, int L, float* y, float* stats, hipStream_t s);
 hipError_t launch_train_ln_backward(const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L, float* dx,

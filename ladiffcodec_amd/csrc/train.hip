@@ -605,4 +605,207 @@ hipError_t launch_train_linattn_backward(const float* d_o, const float* qkv, int
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The rest of Unet1D (srcs/modules/unet.py:248-470) for the assembled forward / backward:
+//   plain Conv1d with any kernel size / stride / zero padding (init_conv k7 p3, Downsample k4 s2 p1, the k3 p1 convs of
+//   Upsample and of the last levels, final_conv k1), nearest x2 upsampling, tanh / GELU, and the bottleneck softmax Attention core.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void convg_forward_kernel(const float* x, const float* w, const float* bias, int Cin, int Cout, int Lin, int Lout,
+                                                            int K, int S, int P, float* y) {
+  const int b = blockIdx.z, o = blockIdx.y;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < Lout; l += gridDim.x * 256) {
+    float acc = bias ? bias[o] : 0.f;
+    for (int i = 0; i < Cin; ++i) {
+      const float* xr = x + ((size_t)b * Cin + i) * Lin;
+      const float* wr = w + ((size_t)o * Cin + i) * K;
+      for (int t = 0; t < K; ++t) {
+        const int m = l * S + t - P;
+        if (m >= 0 && m < Lin) acc = fmaf(wr[t], xr[m], acc);
+      }
+    }
+    y[((size_t)b * Cout + o) * Lout + l] = acc;
+  }
+}
+// dx[b,i,m] = sum_{o,t : (m + P - t) % S == 0} w[o,i,t] * dy[b,o,(m + P - t) / S]
+__global__ __launch_bounds__(256) void convg_dx_kernel(const float* dy, const float* w, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
+                                                       float* dx) {
+  const int b = blockIdx.z, i = blockIdx.y;
+  for (int m = blockIdx.x * 256 + threadIdx.x; m < Lin; m += gridDim.x * 256) {
+    float acc = 0.f;
+    for (int t = 0; t < K; ++t) {
+      const int u = m + P - t;
+      if (u < 0 || u % S) continue;
+      const int l = u / S;
+      if (l >= Lout) continue;
+      for (int o = 0; o < Cout; ++o) acc = fmaf(w[((size_t)o * Cin + i) * K + t], dy[((size_t)b * Cout + o) * Lout + l], acc);
+    }
+    dx[((size_t)b * Cin + i) * Lin + m] = acc;
+  }
+}
+// dw[o,i,t] = sum_{b,l} dy[b,o,l] * x[b,i,l*S + t - P]; one block per (o, i, t), fixed-order reduction
+__global__ __launch_bounds__(256) void convg_dw_kernel(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S,
+                                                       int P, float* dw) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, o = blockIdx.y, t = blockIdx.z;
+  float a = 0.f;
+  for (int idx = threadIdx.x; idx < B * Lout; idx += 256) {
+    const int b = idx / Lout, l = idx - b * Lout, m = l * S + t - P;
+    if (m >= 0 && m < Lin) a = fmaf(dy[((size_t)b * Cout + o) * Lout + l], x[((size_t)b * Cin + i) * Lin + m], a);
+  }
+  const float tot = block_sum(a, red);
+  if (threadIdx.x == 0) dw[((size_t)o * Cin + i) * K + t] = tot;
+}
+hipError_t launch_train_conv_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int K, int S, int P,
+                                     float* y, hipStream_t s) {
+  const int Lout = (Lin + 2 * P - K) / S + 1;
+  if (Lout < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(convg_forward_kernel, dim3((Lout + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, Lin, Lout, K, S, P, y);
+  return hipGetLastError();
+}
+hipError_t launch_train_conv_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int Lin, int K, int S, int P,
+                                      float* dx, float* dw, float* db, hipStream_t s) {
+  const int Lout = (Lin + 2 * P - K) / S + 1;
+  if (Lout < 1) return hipErrorInvalidValue;
+  if (dx) hipLaunchKernelGGL(convg_dx_kernel, dim3((Lin + 255) / 256, Cin, B), dim3(256), 0, s, dy, w, Cin, Cout, Lin, Lout, K, S, P, dx);
+  hipLaunchKernelGGL(convg_dw_kernel, dim3(Cin, Cout, K), dim3(256), 0, s, dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw);
+  if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, Lout, db);
+  return hipGetLastError();
+}
+
+// nearest x2 upsampling along L (nn.Upsample(scale_factor = 2, mode = 'nearest')): y[.., 2l] = y[.., 2l+1] = x[.., l]; backward sums the pair
+__global__ __launch_bounds__(256) void up2_kernel(const float* in, size_t rows, int L, int backward, float* out) {
+  const size_t n = rows * (size_t)L;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+    const size_t r = idx / L;
+    const int l = (int)(idx - r * L);
+    if (backward) out[idx] = in[r * 2 * L + 2 * l] + in[r * 2 * L + 2 * l + 1];
+    else { out[r * 2 * L + 2 * l] = in[idx]; out[r * 2 * L + 2 * l + 1] = in[idx]; }
+  }
+}
+hipError_t launch_train_upsample2(const float* in, int64_t rows, int L, int backward, float* out, hipStream_t s) {
+  const size_t n = (size_t)rows * L;
+  hipLaunchKernelGGL(up2_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, in, (size_t)rows, L, backward, out);
+  return hipGetLastError();
+}
+
+// elementwise activations: kind 0 tanh, 1 GELU (exact, erf), 2 SiLU.  forward: y = f(x); backward: dx = dy * f'(x)
+__device__ __forceinline__ float act_fwd(float v, int kind) {
+  if (kind == 0) return tanhf(v);
+  if (kind == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  return silu_f(v);
+}
+__device__ __forceinline__ float act_bwd(float v, int kind) {
+  if (kind == 0) { const float t = tanhf(v); return 1.0f - t * t; }
+  if (kind == 1) return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+  return silu_grad_f(v);
+}
+__global__ __launch_bounds__(256) void act_train_kernel(const float* x, const float* dy, int64_t n, int kind, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = dy ? dy[i] * act_bwd(x[i], kind) : act_fwd(x[i], kind);
+}
+hipError_t launch_train_act(const float* x, const float* dy, int64_t n, int kind, float* out, hipStream_t s) {
+  if (kind < 0 || kind > 2) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(act_train_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, x, dy, n, kind, out);
+  return hipGetLastError();
+}
+
+// bottleneck Attention core (unet.py:234-245): per (item, head), sim[i, j] = scale * sum_d q[d, i] k[d, j], attn = softmax_j(sim),
+// out[d, i] = sum_j attn[i, j] v[d, j].  `attn` [B, H, N, N] is saved for the backward pass (N is the bottleneck length, <= ~1k).
+//   dv[d, j] = sum_i attn[i, j] do[d, i];  dattn[i, j] = sum_d do[d, i] v[d, j];  dsim = attn (dattn - sum_j attn dattn)
+//   dq[d, i] = scale * sum_j dsim[i, j] k[d, j];  dk[d, j] = scale * sum_i dsim[i, j] q[d, i]
+__global__ __launch_bounds__(256) void attn_scores_kernel(const float* qkv, int H, int D, int N, float scale, float* attn) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, HD = H * D;
+  const float* q = qkv + ((size_t)b * 3 * HD + h * D) * N;
+  const float* k = q + (size_t)HD * N;
+  float* row = attn + (((size_t)b * H + h) * N + i) * N;
+  float m = -INFINITY;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    float a = 0.f;
+    for (int d = 0; d < D; ++d) a = fmaf(q[(size_t)d * N + i] * scale, k[(size_t)d * N + j], a);
+    row[j] = a;
+    m = fmaxf(m, a);
+  }
+  m = block_max(m, red);
+  float sum = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
+  sum = block_sum(sum, red);
+  for (int j = threadIdx.x; j < N; j += 256) row[j] /= sum;
+}
+// out[d, i] = sum_j attn[i, j] v[d, j]: one block per (i, h, b), thread d-groups reduce over j
+__global__ __launch_bounds__(256) void attn_out_kernel(const float* attn, const float* qkv, int H, int D, int N, float* out) {
+  __shared__ float part[256];
+  const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, HD = H * D;
+  const float* v = qkv + ((size_t)b * 3 * HD + 2 * HD + h * D) * N;
+  const float* row = attn + (((size_t)b * H + h) * N + i) * N;
+  const int d = threadIdx.x % D, grp = threadIdx.x / D, ngrp = 256 / D;
+  float a = 0.f;
+  for (int j = grp; j < N; j += ngrp) a = fmaf(row[j], v[(size_t)d * N + j], a);
+  part[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < D) {
+    float t = 0.f;
+    for (int g = 0; g < ngrp; ++g) t += part[g * D + threadIdx.x];
+    out[((size_t)b * HD + h * D + threadIdx.x) * N + i] = t;
+  }
+}
+// dsim (in place of attn's copy `ds`): one block per (i, h, b): dattn[i, j] = sum_d do[d, i] v[d, j]; dsim = attn (dattn - dot)
+__global__ __launch_bounds__(256) void attn_dsim_kernel(const float* attn, const float* d_o, const float* qkv, int H, int D, int N, float* ds) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, HD = H * D;
+  const float* v = qkv + ((size_t)b * 3 * HD + 2 * HD + h * D) * N;
+  const float* dor = d_o + ((size_t)b * HD + h * D) * N + i;
+  const float* arow = attn + (((size_t)b * H + h) * N + i) * N;
+  float* drow = ds + (((size_t)b * H + h) * N + i) * N;
+  float dot = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    float a = 0.f;
+    for (int d = 0; d < D; ++d) a = fmaf(dor[(size_t)d * N], v[(size_t)d * N + j], a);
+    drow[j] = a;
+    dot = fmaf(arow[j], a, dot);
+  }
+  dot = block_sum(dot, red);
+  for (int j = threadIdx.x; j < N; j += 256) drow[j] = arow[j] * (drow[j] - dot);
+}
+// dq[d, i] = scale * sum_j ds[i, j] k[d, j]   (block per (i, h, b), like attn_out with k);  mode 0
+// dk[d, j] = scale * sum_i ds[i, j] q[d, i],  dv[d, j] = sum_i attn[i, j] do[d, i]          (block per (j, h, b));  mode 1 / 2
+__global__ __launch_bounds__(256) void attn_grad_kernel(const float* mat, const float* src, size_t src_item, int H, int D, int N, float mul, int mode,
+                                                        float* dst, size_t dst_item) {
+  __shared__ float part[256];
+  const int p = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const float* m = mat + ((size_t)b * H + h) * N * N;
+  const float* sr = src + (size_t)b * src_item + (size_t)(h * D) * N;
+  const int d = threadIdx.x % D, grp = threadIdx.x / D, ngrp = 256 / D;
+  float a = 0.f;
+  for (int r = grp; r < N; r += ngrp) a = fmaf(mode == 0 ? m[(size_t)p * N + r] : m[(size_t)r * N + p], sr[(size_t)d * N + r], a);
+  part[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < D) {
+    float t = 0.f;
+    for (int g = 0; g < ngrp; ++g) t += part[g * D + threadIdx.x];
+    dst[(size_t)b * dst_item + (size_t)(h * D + threadIdx.x) * N + p] = t * mul;
+  }
+}
+size_t train_attn_ws_floats(int B, int H, int N) { return (size_t)2 * B * H * N * N + 64; }
+hipError_t launch_train_attn_forward(const float* qkv, int B, int H, int D, int N, float* out, float* ws, hipStream_t s) {
+  if (D < 1 || D > 64 || 256 % D) return hipErrorInvalidValue;
+  const float scale = 1.0f / sqrtf((float)D);
+  hipLaunchKernelGGL(attn_scores_kernel, dim3(N, H, B), dim3(256), 0, s, qkv, H, D, N, scale, ws);
+  hipLaunchKernelGGL(attn_out_kernel, dim3(N, H, B), dim3(256), 0, s, ws, qkv, H, D, N, out);
+  return hipGetLastError();
+}
+hipError_t launch_train_attn_backward(const float* d_o, const float* qkv, int B, int H, int D, int N, float* ws, float* dqkv, hipStream_t s) {
+  if (D < 1 || D > 64 || 256 % D) return hipErrorInvalidValue;
+  const size_t HD = (size_t)H * D;
+  const float scale = 1.0f / sqrtf((float)D);
+  float* attn = ws;
+  float* ds = ws + (size_t)B * H * N * N;
+  const dim3 g(N, H, B);
+  hipLaunchKernelGGL(attn_dsim_kernel, g, dim3(256), 0, s, attn, d_o, qkv, H, D, N, ds);
+  hipLaunchKernelGGL(attn_grad_kernel, g, dim3(256), 0, s, ds, qkv + HD * N, 3 * HD * N, H, D, N, scale, 0, dqkv, 3 * HD * N);            // dq from k
+  hipLaunchKernelGGL(attn_grad_kernel, g, dim3(256), 0, s, ds, qkv, 3 * HD * N, H, D, N, scale, 1, dqkv + HD * N, 3 * HD * N);            // dk from q
+  hipLaunchKernelGGL(attn_grad_kernel, g, dim3(256), 0, s, attn, d_o, HD * N, H, D, N, 1.0f, 2, dqkv + 2 * HD * N, 3 * HD * N);          // dv from do
+  return hipGetLastError();
+}
+
 }  // namespace ldc

@@ -283,3 +283,253 @@ class LinearAttention:
         dxn, dg_pre = self.norm.backward(g_qkv["dx"])
         return {"norm.g": dg_pre, "to_qkv.weight": g_qkv["dw"], "to_out.0.weight": g_out["dw"], "to_out.0.bias": g_out["db"],
                 "to_out.1.g": dg_out, "dx": dxn + dy}
+
+
+class Conv1d:
+    """nn.Conv1d(Cin, Cout, K, stride, padding) forward / backward (init_conv, Downsample, the k3 convs, final_conv)."""
+
+    def __init__(self, eng, weight, bias, stride: int = 1, padding: int = 0):
+        t = eng.torch
+        self.eng, self.lib, self.torch = eng, eng.lib, t
+        self.weight = weight.to(eng.device, t.float32).contiguous()
+        self.bias = bias.to(eng.device, t.float32).contiguous() if bias is not None else None
+        self.stride, self.padding = int(stride), int(padding)
+
+    def forward(self, x):
+        t = self.torch
+        x = x.to(self.eng.device, t.float32).contiguous()
+        B, Cin, Lin = x.shape
+        Cout, _, K = self.weight.shape
+        Lout = (Lin + 2 * self.padding - K) // self.stride + 1
+        y = t.empty(B, Cout, Lout, dtype=t.float32, device=self.eng.device)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_conv_forward(self.eng._ctx, x.data_ptr(), self.weight.data_ptr(), self.bias.data_ptr() if self.bias is not None else None,
+                                                B, Cin, Cout, Lin, K, self.stride, self.padding, y.data_ptr(), s))
+        self.eng._exit()
+        self._saved = x
+        return y
+
+    def backward(self, dy, want_dx: bool = True):
+        t = self.torch
+        x = self._saved
+        B, Cin, Lin = x.shape
+        Cout, _, K = self.weight.shape
+        dy = dy.to(self.eng.device, t.float32).contiguous()
+        dx = t.empty_like(x) if want_dx else None
+        dw = t.empty_like(self.weight)
+        db = t.empty(Cout, dtype=t.float32, device=self.eng.device) if self.bias is not None else None
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_conv_backward(self.eng._ctx, dy.data_ptr(), x.data_ptr(), self.weight.data_ptr(), B, Cin, Cout, Lin, K, self.stride,
+                                                 self.padding, dx.data_ptr() if dx is not None else None, dw.data_ptr(),
+                                                 db.data_ptr() if db is not None else None, s))
+        self.eng._exit()
+        return {"dx": dx, "dw": dw, "db": db}
+
+
+def upsample2(eng, x, backward: bool = False):
+    """nn.Upsample(scale_factor=2, mode='nearest') on [B, C, L] and its adjoint (dy [B, C, 2L] -> dx [B, C, L])."""
+    t = eng.torch
+    x = x.to(eng.device, t.float32).contiguous()
+    B, Cc, Lx = x.shape
+    Lin = Lx // 2 if backward else Lx
+    out = t.empty(B, Cc, Lin if backward else 2 * Lx, dtype=t.float32, device=eng.device)
+    s = eng._enter()
+    L.check(eng.lib.ldc_train_upsample2(eng._ctx, x.data_ptr(), B * Cc, Lin, int(backward), out.data_ptr(), s))
+    eng._exit()
+    return out
+
+
+ACT_TANH, ACT_GELU, ACT_SILU = 0, 1, 2
+
+
+def activation(eng, x, kind: int, dy=None):
+    """y = f(x), or with dy: dx = dy * f'(x)."""
+    t = eng.torch
+    x = x.to(eng.device, t.float32).contiguous()
+    out = t.empty_like(x)
+    dyc = dy.to(eng.device, t.float32).contiguous() if dy is not None else None
+    s = eng._enter()
+    L.check(eng.lib.ldc_train_activation(eng._ctx, x.data_ptr(), dyc.data_ptr() if dyc is not None else None, x.numel(), int(kind), out.data_ptr(), s))
+    eng._exit()
+    return out
+
+
+class Attention:
+    """Residual(PreNorm(dim, Attention(dim))) of the bottleneck (unet.py:224-246 inside :103-116's wrappers)."""
+
+    def __init__(self, eng, p: dict, heads: int = 4, dim_head: int = 32):
+        """p: 'norm.g', 'to_qkv.weight', 'to_out.weight', 'to_out.bias'."""
+        self.eng, self.lib, self.torch = eng, eng.lib, eng.torch
+        self.heads, self.dim_head = heads, dim_head
+        self.norm = LayerNorm(eng, p["norm.g"])
+        self.to_qkv = Pointwise(eng, p["to_qkv.weight"], None)
+        self.to_out = Pointwise(eng, p["to_out.weight"], p["to_out.bias"])
+
+    def forward(self, x):
+        t = self.torch
+        x = x.to(self.eng.device, t.float32).contiguous()
+        B, _, N = x.shape
+        qkv = self.to_qkv.forward(self.norm.forward(x))
+        o = t.empty(B, self.heads * self.dim_head, N, dtype=t.float32, device=self.eng.device)
+        ws = t.empty(int(self.lib.ldc_train_attn_ws_floats(B, self.heads, N)), dtype=t.float32, device=self.eng.device)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_attn_forward(self.eng._ctx, qkv.data_ptr(), B, self.heads, self.dim_head, N, o.data_ptr(), ws.data_ptr(), s))
+        self.eng._exit()
+        self._saved = (qkv, ws)
+        return self.to_out.forward(o) + x
+
+    def backward(self, dy):
+        t = self.torch
+        dy = dy.to(self.eng.device, t.float32).contiguous()
+        qkv, ws = self._saved
+        B, _, N = qkv.shape
+        g_out = self.to_out.backward(dy)
+        dqkv = t.empty_like(qkv)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_attn_backward(self.eng._ctx, g_out["dx"].data_ptr(), qkv.data_ptr(), B, self.heads, self.dim_head, N, ws.data_ptr(),
+                                                 dqkv.data_ptr(), s))
+        self.eng._exit()
+        g_qkv = self.to_qkv.backward(dqkv)
+        dxn, dg_pre = self.norm.backward(g_qkv["dx"])
+        return {"norm.g": dg_pre, "to_qkv.weight": g_qkv["dw"], "to_out.weight": g_out["dw"], "to_out.bias": g_out["db"], "dx": dxn + dy}
+
+
+class Unet1D:
+    """Unet1D.forward (srcs/modules/unet.py:422-469) and its backward pass over the reference's own state dict
+    (`other_cond` layout: x_cond is concatenated in front of x; process_cond's upsampler / scaling are applied by the caller).
+    fp32 correctness path of the training step: every layer is one of this module's forward/backward pairs."""
+
+    def __init__(self, eng, sd: dict, dim: int, dim_mults=(1, 2, 4, 8), heads: int = 4, dim_head: int = 32, groups: int = 8):
+        self.eng, self.torch, self.dim = eng, eng.torch, dim
+        sub = lambda prefix: {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        att = lambda prefix: {"norm.g": sd[prefix + "fn.norm.g"], **{k: v for k, v in sub(prefix + "fn.fn.").items()}}
+        self.init_conv = Conv1d(eng, sd["init_conv.weight"], sd["init_conv.bias"], 1, 3)
+        self.t1 = Pointwise(eng, sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
+        self.t2 = Pointwise(eng, sd["time_mlp.3.weight"], sd["time_mlp.3.bias"])
+        n = len(dim_mults)
+        self.downs, self.ups = [], []
+        for i in range(n):
+            last = i == n - 1
+            res = Conv1d(eng, sd[f"downs.{i}.3.weight"], sd[f"downs.{i}.3.bias"], 1 if last else 2, 1)
+            self.downs.append((ResnetBlock(eng, sub(f"downs.{i}.0."), groups), ResnetBlock(eng, sub(f"downs.{i}.1."), groups),
+                               LinearAttention(eng, att(f"downs.{i}.2."), heads, dim_head), res))
+        self.mid1 = ResnetBlock(eng, sub("mid_block1."), groups)
+        self.mid_attn = Attention(eng, att("mid_attn."), heads, dim_head)
+        self.mid2 = ResnetBlock(eng, sub("mid_block2."), groups)
+        for i in range(n):
+            last = i == n - 1
+            key = f"ups.{i}.3." if last else f"ups.{i}.3.1."
+            self.ups.append((ResnetBlock(eng, sub(f"ups.{i}.0."), groups), ResnetBlock(eng, sub(f"ups.{i}.1."), groups),
+                             LinearAttention(eng, att(f"ups.{i}.2."), heads, dim_head), Conv1d(eng, sd[key + "weight"], sd[key + "bias"], 1, 1), not last))
+        self.final_res = ResnetBlock(eng, sub("final_res_block."), groups)
+        self.final_conv = Conv1d(eng, sd["final_conv.weight"], sd["final_conv.bias"], 1, 0)
+
+    def _sinusoidal(self, time):
+        """SinusoidalPosEmb (unet.py:104-116): parameter-free."""
+        import math
+        t = self.torch
+        half = self.dim // 2
+        emb = t.exp(t.arange(half, device=self.eng.device, dtype=t.float32) * -(math.log(10000) / (half - 1)))
+        emb = time.to(self.eng.device, t.float32)[:, None] * emb[None, :]
+        return t.cat((emb.sin(), emb.cos()), dim=-1).contiguous()
+
+    def forward(self, x, time, x_cond):
+        t = self.torch
+        self._ccond = x_cond.shape[1]
+        x = t.cat((x_cond.to(self.eng.device, t.float32), x.to(self.eng.device, t.float32)), dim=1).contiguous()
+        x = self.init_conv.forward(x)
+        r = x
+        self._t_pre = self.t1.forward(self._sinusoidal(time))
+        temb = self.t2.forward(activation(self.eng, self._t_pre, ACT_GELU))
+        h = []
+        for rb1, rb2, attn, down in self.downs:
+            x = rb1.forward(x, temb); h.append(x)
+            x = rb2.forward(x, temb)
+            x = attn.forward(x); h.append(x)
+            x = down.forward(x)
+        x = self.mid1.forward(x, temb)
+        x = self.mid_attn.forward(x)
+        x = self.mid2.forward(x, temb)
+        self._cat_splits = []
+        for rb1, rb2, attn, conv, up in self.ups:
+            skip = h.pop(); self._cat_splits.append(x.shape[1]); x = rb1.forward(t.cat((x, skip), dim=1), temb)
+            skip = h.pop(); self._cat_splits.append(x.shape[1]); x = rb2.forward(t.cat((x, skip), dim=1), temb)
+            x = attn.forward(x)
+            x = conv.forward(upsample2(self.eng, x) if up else x)
+        self._final_split = x.shape[1]
+        x = self.final_res.forward(t.cat((x, r), dim=1), temb)
+        self._pre_tanh = x
+        return self.final_conv.forward(activation(self.eng, x, ACT_TANH))
+
+    def backward(self, dy):
+        """-> (grads keyed like the state dict, dx of the noisy input, dx_cond)"""
+        t = self.torch
+        grads = {}
+        dtemb = None
+
+        def rb_back(rb, prefix, d):
+            nonlocal dtemb
+            g = rb.backward(d)
+            dtemb = g["dtime_emb"] if dtemb is None else dtemb + g["dtime_emb"]
+            for k, v in g.items():
+                if k not in ("dx", "dtime_emb"):
+                    grads[prefix + k] = v
+            return g["dx"]
+
+        def att_back(a, prefix, d, linear=True):
+            g = a.backward(d)
+            grads[prefix + "fn.norm.g"] = g["norm.g"]
+            for k, v in g.items():
+                if k not in ("dx", "norm.g"):
+                    grads[prefix + "fn.fn." + k] = v
+            return g["dx"]
+
+        g = self.final_conv.backward(dy)
+        grads["final_conv.weight"], grads["final_conv.bias"] = g["dw"], g["db"]
+        d = activation(self.eng, self._pre_tanh, ACT_TANH, dy=g["dx"])
+        d = rb_back(self.final_res, "final_res_block.", d)
+        d, dr = d[:, :self._final_split].contiguous(), d[:, self._final_split:].contiguous()
+        dh = []                                    # gradients of the skip tensors, in the order they were popped
+        n = len(self.ups)
+        for i in reversed(range(n)):
+            rb1, rb2, attn, conv, up = self.ups[i]
+            key = f"ups.{i}.3.1." if up else f"ups.{i}.3."
+            g = conv.backward(d)
+            grads[key + "weight"], grads[key + "bias"] = g["dw"], g["db"]
+            d = upsample2(self.eng, g["dx"], backward=True) if up else g["dx"]
+            d = att_back(attn, f"ups.{i}.2.", d)
+            d = rb_back(rb2, f"ups.{i}.1.", d)
+            c2 = self._cat_splits[2 * i + 1]
+            d, ds2 = d[:, :c2].contiguous(), d[:, c2:].contiguous()
+            d = rb_back(rb1, f"ups.{i}.0.", d)
+            c1 = self._cat_splits[2 * i]
+            d, ds1 = d[:, :c1].contiguous(), d[:, c1:].contiguous()
+            dh = [ds1, ds2] + dh                   # this level popped ds1's tensor first, then ds2's
+        d = rb_back(self.mid2, "mid_block2.", d)
+        g = self.mid_attn.backward(d)
+        grads["mid_attn.fn.norm.g"] = g["norm.g"]
+        for k in ("to_qkv.weight", "to_out.weight", "to_out.bias"):
+            grads["mid_attn.fn.fn." + k] = g[k]
+        d = rb_back(self.mid1, "mid_block1.", g["dx"])
+        # dh holds, for ups level 0..n-1, (grad of the tensor popped first, grad of the one popped second); the pops ran from
+        # the END of h: h = [d0.a, d0.b, d1.a, d1.b, ...] (a: after block1, b: after attention) -> ups level 0 popped d_{n-1}.b, d_{n-1}.a
+        for i in reversed(range(len(self.downs))):
+            rb1, rb2, attn, down = self.downs[i]
+            lvl = len(self.downs) - 1 - i                       # the ups level that consumed this level's skips
+            d_b, d_a = dh[2 * lvl], dh[2 * lvl + 1]
+            g = down.backward(d)
+            grads[f"downs.{i}.3.weight"], grads[f"downs.{i}.3.bias"] = g["dw"], g["db"]
+            d = g["dx"] + d_b
+            d = att_back(attn, f"downs.{i}.2.", d)
+            d = rb_back(rb2, f"downs.{i}.1.", d)
+            d = d + d_a
+            d = rb_back(rb1, f"downs.{i}.0.", d)
+        d = d + dr
+        g = self.init_conv.backward(d)
+        grads["init_conv.weight"], grads["init_conv.bias"] = g["dw"], g["db"]
+        g2 = self.t2.backward(dtemb)
+        grads["time_mlp.3.weight"], grads["time_mlp.3.bias"] = g2["dw"], g2["db"]
+        g1 = self.t1.backward(activation(self.eng, self._t_pre, ACT_GELU, dy=g2["dx"]), want_dx=False)
+        grads["time_mlp.1.weight"], grads["time_mlp.1.bias"] = g1["dw"], g1["db"]
+        cc = self._ccond
+        return grads, g["dx"][:, cc:].contiguous(), g["dx"][:, :cc].contiguous()

@@ -120,3 +120,61 @@ def test_linear_attention_block_forward_backward_reference_vectors():
     assert rel(grads["dx"].cpu().numpy(), g["la.dx"]) < TOL
     for name in p:
         assert rel(grads[name].cpu().numpy().reshape(g[f"la.g.{name}"].shape), g[f"la.g.{name}"]) < TOL, name
+
+
+def test_conv_upsample_activation_attention_against_autograd():
+    """The remaining Unet1D layers, each forward / backward against torch autograd of the same functional op on the CPU."""
+    import torch.nn.functional as F
+    e = engine("r84", "f32")
+    gen = torch.Generator().manual_seed(9)
+    for cin, cout, k, st, pd, Lx in ((16, 32, 7, 1, 3, 50), (32, 64, 4, 2, 1, 48), (24, 24, 3, 1, 1, 37), (32, 8, 1, 1, 0, 20)):
+        x = torch.randn(2, cin, Lx, generator=gen, requires_grad=True)
+        w = (torch.randn(cout, cin, k, generator=gen) * 0.2).requires_grad_()
+        b = (torch.randn(cout, generator=gen) * 0.1).requires_grad_()
+        y = F.conv1d(x, w, b, stride=st, padding=pd)
+        dy = torch.randn(y.shape, generator=gen)
+        y.backward(dy)
+        cv = TR.Conv1d(e, w.detach(), b.detach(), st, pd)
+        assert rel(cv.forward(x.detach()).cpu().numpy(), y.detach().numpy()) < 1e-5
+        gr = cv.backward(dy)
+        assert rel(gr["dx"].cpu().numpy(), x.grad.numpy()) < TOL and rel(gr["dw"].cpu().numpy(), w.grad.numpy()) < TOL
+        assert rel(gr["db"].cpu().numpy(), b.grad.numpy()) < TOL
+    x = torch.randn(2, 5, 11, generator=gen)
+    up = TR.upsample2(e, x)
+    assert torch.equal(up.cpu(), F.interpolate(x, scale_factor=2, mode="nearest"))
+    d = torch.randn(2, 5, 22, generator=gen)
+    assert rel(TR.upsample2(e, d, backward=True).cpu().numpy(), (d[..., 0::2] + d[..., 1::2]).numpy()) < 1e-6
+    for kind, fn in ((TR.ACT_TANH, torch.tanh), (TR.ACT_GELU, F.gelu), (TR.ACT_SILU, F.silu)):
+        x = (torch.randn(3, 40, generator=gen) * 2).requires_grad_()
+        y = fn(x)
+        dy = torch.randn(y.shape, generator=gen)
+        y.backward(dy)
+        assert rel(TR.activation(e, x.detach(), kind).cpu().numpy(), y.detach().numpy()) < 1e-5
+        assert rel(TR.activation(e, x.detach(), kind, dy=dy).cpu().numpy(), x.grad.numpy()) < 1e-5
+
+
+def test_assembled_unet_forward_backward_reference_vectors():
+    """Unet1D.forward / backward over the reference's own state dict (two levels, dim 16): output, input gradients and the
+    gradient of every one of the 160 parameters against the reference's autograd (tests/golden/train_unet.npz); then one Adam
+    step of the flattened parameters against torch.optim.Adam."""
+    g = load_golden("train_unet")
+    e = engine("r84", "f32")
+    sd = {k[2:]: T(g[k]) for k in list(g.keys()) if k.startswith("p.")}
+    net = TR.Unet1D(e, sd, dim=16, dim_mults=(1, 2))
+    y = net.forward(T(g["x"]), torch.from_numpy(g["time"]), T(g["xc"]))
+    assert rel(y.cpu().numpy(), g["y"]) < TOL
+    grads, dx, dxc = net.backward(T(g["dy"]))
+    assert rel(dx.cpu().numpy(), g["dx"]) < TOL and rel(dxc.cpu().numpy(), g["dxc"]) < TOL
+    assert set(grads) == set(sd), (set(sd) - set(grads), set(grads) - set(sd))
+    worst = max((rel(grads[k].cpu().numpy().reshape(g["g." + k].shape), g["g." + k]), k) for k in sd)
+    assert worst[0] < 2e-4, worst
+    # one optimiser step over the flat buffers (the layout parallel.allreduce_gradients reduces)
+    names = sorted(sd)
+    flat_p = torch.cat([sd[k].reshape(-1) for k in names]).cuda().contiguous()
+    flat_g = torch.cat([grads[k].reshape(-1) for k in names]).contiguous()
+    ref_p = torch.nn.Parameter(flat_p.cpu().clone())
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    ref_p.grad = torch.cat([T(g["g." + k]).reshape(-1) for k in names])
+    opt.step()
+    TR.Adam(e, flat_p, lr=1e-3).step(flat_g)
+    assert float((flat_p.cpu() - ref_p.detach()).abs().max()) < 2e-5       # Adam's first step is +-lr: a sign flip of a ~0 gradient would show

@@ -70,3 +70,21 @@ def test_oracle_linear_attention_block_matches_reference_autograd():
     assert rel_err(x.grad.numpy(), g["la.dx"]) < 5e-5
     for name, t in p.items():
         assert rel_err(t.grad.numpy(), g[f"la.g.{name}"]) < 5e-5, name
+
+
+def test_oracle_unet_gradients_match_reference_autograd():
+    """The assembled Unet1D under autograd: the oracle's functional forward (ldc_oracle.unet_forward) differentiated by torch must
+    reproduce the reference's output and EVERY parameter gradient (tests/golden/train_unet.npz, from the reference's own Unet1D)."""
+    from ladiffcodec_amd.spec import UnetConfig
+    from oracle import ldc_oracle as O
+    g = load_golden("train_unet")
+    u = UnetConfig(dim=16, dim_mults=(1, 2), inp_channels=8, cond_channels=8, upsampling_ratios=None, unet_scale_cond=False)
+    sd = {"diff_model." + k[2:]: T(g[k]).requires_grad_() for k in list(g.keys()) if k.startswith("p.")}
+    x, xc = T(g["x"]).requires_grad_(), T(g["xc"]).requires_grad_()
+    y = O.unet_forward(sd, u, x, torch.from_numpy(g["time"]), xc)
+    assert rel_err(y.detach().numpy(), g["y"]) < 1e-5
+    y.backward(T(g["dy"]))
+    assert rel_err(x.grad.numpy(), g["dx"]) < 1e-4 and rel_err(xc.grad.numpy(), g["dxc"]) < 1e-4
+    worst = max((rel_err(v.grad.numpy(), g["g." + k[len("diff_model."):]]), k) for k, v in sd.items() if v.grad is not None)
+    assert worst[0] < 1e-4, worst
+    assert sum(v.grad is not None for v in sd.values()) == len(sd)          # every parameter is on the path

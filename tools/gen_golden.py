@@ -379,7 +379,36 @@ def main():
         np.savez_compressed(os.path.join(OUT, "train_block.npz"), **out)
         print("train_block: loss", float(loss), "dw absmax", float(np.abs(out["a.dw"]).max()), "ln dg absmax", float(np.abs(out["ln.dg"]).max()))
 
+    def train_unet_case():
+        """The assembled Unet1D (unet.py:248-470) under autograd at a small width: two levels (dim 16, dim_mults (1, 2)), 8 + 8 input
+        channels (`other_cond`: the condition is concatenated in front of x; upsampling_ratios None and unet_scale_cond False, so
+        process_cond is the identity), forward output and the gradient of EVERY parameter and of both inputs."""
+        from srcs.modules.unet import Unet1D
+        torch.manual_seed(5150)
+        gg = torch.Generator().manual_seed(5151)
+        net = Unet1D(16, dim_mults=(1, 2), inp_channels=8, other_cond=True, cond_channels=8, upsampling_ratios=None, unet_scale_cond=False)
+        with torch.no_grad():
+            for name, prm in net.named_parameters():
+                if name.endswith(".g") or name.endswith("norm.weight"):
+                    prm.copy_(torch.rand(prm.shape, generator=gg) + 0.5)
+        x = torch.randn(2, 8, 32, generator=gg, requires_grad=True)
+        xc = torch.randn(2, 8, 32, generator=gg, requires_grad=True)
+        time = torch.tensor([17, 803])
+        y = net(x, time, xc)
+        dy = torch.randn(y.shape, generator=gg)
+        y.backward(dy)
+        out = {"x": np32(x), "xc": np32(xc), "time": time.numpy().astype(np.int64), "y": np32(y), "dy": np32(dy), "dx": np32(x.grad), "dxc": np32(xc.grad)}
+        for name, prm in net.named_parameters():
+            out["p." + name] = np32(prm)
+            out["g." + name] = np32(prm.grad) if prm.grad is not None else np.zeros(prm.shape, np.float32)
+        np.savez_compressed(os.path.join(OUT, "train_unet.npz"), **out)
+        print("train_unet:", len([k for k in out if k.startswith("p.")]), "parameters,", sum(v.size for k, v in out.items() if k.startswith("p.")), "elements")
+
+    if os.environ.get("GOLDEN_ONLY") == "train_unet":
+        train_unet_case()
+        return
     train_case()
+    train_unet_case()
     if os.environ.get("GOLDEN_ONLY") == "train":
         return
     variants_case()
