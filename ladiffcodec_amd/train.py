@@ -533,3 +533,44 @@ class Unet1D:
         grads["time_mlp.1.weight"], grads["time_mlp.1.bias"] = g1["dw"], g1["db"]
         cc = self._ccond
         return grads, g["dx"][:, cc:].contiguous(), g["dx"][:, :cc].contiguous()
+
+
+class DiffusionTrainer:
+    """One optimisation step of the diffusion UNet as srcs/train.py:110-177 runs it for --run_diff (the codec is frozen, only
+    model.diff_model's parameters are optimised, train.py:365): q_sample -> Unet1D forward -> p_losses objective -> Unet1D backward
+    -> gradient averaging over ranks (one flat reduce-scatter + all-gather) -> Adam.  `x_start` is the scaled latent
+    (model.py:165) and `cond` the processed condition (Unet1D.process_cond), both produced by the inference kernels; the
+    condition upsampler's own parameters are not trained here (next slice)."""
+
+    def __init__(self, eng, sd: dict, dim: int, dim_mults=(1, 2, 4, 8), lr: float = 1e-4, **kw):
+        t = eng.torch
+        self.eng, self.torch = eng, t
+        self.names = sorted(sd)
+        self.shapes = {k: tuple(sd[k].shape) for k in self.names}
+        self.flat = t.cat([sd[k].to(eng.device, t.float32).reshape(-1) for k in self.names]).contiguous()
+        self.dim, self.dim_mults, self.kw = dim, tuple(dim_mults), kw
+        self.opt = Adam(eng, self.flat, lr=lr)
+
+    def state_dict(self):
+        out, off = {}, 0
+        for k in self.names:
+            n = 1
+            for d in self.shapes[k]:
+                n *= d
+            out[k] = self.flat[off:off + n].reshape(self.shapes[k])
+            off += n
+        return out
+
+    def step(self, x_start, cond, t, noise):
+        """-> loss (float tensor [1]) of this step, evaluated before the update"""
+        from . import parallel
+        tt = self.torch
+        net = Unet1D(self.eng, self.state_dict(), self.dim, self.dim_mults, **self.kw)
+        x_t = q_sample(self.eng, x_start, t, noise)
+        out = net.forward(x_t, t, cond)
+        loss, grad = p_losses_objective(self.eng, out, noise, t)
+        grads, _, _ = net.backward(grad)
+        flat_g = tt.cat([grads[k].reshape(-1) for k in self.names]).contiguous()
+        parallel.allreduce_gradients(flat_g)           # no-op without a process group
+        self.opt.step(flat_g)
+        return loss

@@ -68,3 +68,22 @@ def linear_attention_block(p, x, heads: int = 4, dim_head: int = 32):
     out = torch.einsum("bhde,bhdn->bhen", context, q).reshape(b, heads * dim_head, n)
     out = F.conv1d(out, p["to_out.0.weight"], p["to_out.0.bias"])
     return layer_norm(out, p["to_out.1.g"].reshape(-1)) + x
+
+
+def training_steps(sd, u, x_start, cond, ts, noises, lr: float, sched):
+    """Reference training loop of the UNet (train.py:110-177 with --run_diff: optim.Adam over the UNet's parameters, loss =
+    p_losses' l1 objective) on the CPU: `sd` parameters keyed 'diff_model.*', one (t, noise) per step.  Returns the loss of
+    every step (before its update) and the final parameters."""
+    from oracle import ldc_oracle as O
+    params = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=lr)
+    losses = []
+    for t, noise in zip(ts, noises):
+        opt.zero_grad()
+        x_t = q_sample(sched, x_start, t, noise)
+        out = O.unet_forward(params, u, x_t, t, cond)
+        loss = p_losses_objective(sched, out, noise, t)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    return losses, {k: v.detach() for k, v in params.items()}

@@ -178,3 +178,31 @@ def test_assembled_unet_forward_backward_reference_vectors():
     opt.step()
     TR.Adam(e, flat_p, lr=1e-3).step(flat_g)
     assert float((flat_p.cpu() - ref_p.detach()).abs().max()) < 2e-5       # Adam's first step is +-lr: a sign flip of a ~0 gradient would show
+
+
+def test_training_steps_follow_the_reference_loop():
+    """Four optimisation steps of the diffusion UNet on the GPU (q_sample -> UNet forward -> objective -> UNet backward -> Adam)
+    against the same loop run by torch autograd + torch.optim.Adam on the oracle (CPU): the loss of every step and the final
+    parameters must agree, and the loss on the fixed batch must go down."""
+    from ladiffcodec_amd import synth
+    from ladiffcodec_amd.spec import UnetConfig
+    g = load_golden("train_unet")
+    e = engine("r84", "f32")
+    sd = {k[2:]: T(g[k]) for k in list(g.keys()) if k.startswith("p.")}
+    u = UnetConfig(dim=16, dim_mults=(1, 2), inp_channels=8, cond_channels=8, upsampling_ratios=None, unet_scale_cond=False)
+    sched = {"diffusion." + k: torch.from_numpy(v) for k, v in synth.cosine_schedule_buffers(1000).items()}
+    gen = torch.Generator().manual_seed(31)
+    x0 = torch.randn(2, 8, 32, generator=gen).clamp(-1, 1)
+    cond = torch.randn(2, 8, 32, generator=gen)
+    ts = [torch.tensor([40, 700]), torch.tensor([5, 333]), torch.tensor([40, 700]), torch.tensor([40, 700])]
+    noises = [torch.randn(2, 8, 32, generator=gen) for _ in ts]
+    noises[2] = noises[0]; noises[3] = noises[0]                       # steps 0, 2, 3 see the same sample: their loss must fall
+    want_losses, want_sd = TO.training_steps({"diff_model." + k: v for k, v in sd.items()}, u, x0, cond, ts, noises, 2e-3, sched)
+    tr = TR.DiffusionTrainer(e, sd, dim=16, dim_mults=(1, 2), lr=2e-3)
+    got = [float(tr.step(x0, cond, t, n).cpu()[0]) for t, n in zip(ts, noises)]
+    for a, b in zip(got, want_losses):
+        assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (got, want_losses)
+    assert got[3] < got[2] < got[0]
+    final = tr.state_dict()
+    worst = max((float((final[k].cpu() - want_sd["diff_model." + k]).abs().max()), k) for k in sd)
+    assert worst[0] < 2e-4, worst            # parameters move by ~lr per step; an Adam sign flip would be 4e-3
