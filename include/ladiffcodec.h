@@ -266,6 +266,15 @@ int ldc_train_attn_forward(ldc_ctx* ctx, const float* qkv, int B, int heads, int
 int ldc_train_attn_backward(ldc_ctx* ctx, const float* dout, const float* qkv, int B, int heads, int dim_head, int N, float* ws, float* dqkv,
                             void* stream);
 
+/* Unet1D.process_cond for training (srcs/modules/unet.py:372-377,401-420): the condition upsampler SConvTranspose1d(C, C, 2 * ratio,
+ * stride ratio, non-causal; srcs/modules/conv.py:235-274) forward / backward on [B, C, L] -> [B, C, L * ratio] (weight [Cin, Cout,
+ * 2 * ratio]), and the per-item max-abs scaling x / (max|x| + 1e-20): dy == NULL forward, else the gradient w.r.t. x. */
+int ldc_train_convtr_forward(ldc_ctx* ctx, const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int ratio, float* y,
+                             void* stream);
+int ldc_train_convtr_backward(ldc_ctx* ctx, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int ratio, float* dx,
+                              float* dw, float* db, void* stream);
+int ldc_train_maxscale(ldc_ctx* ctx, const float* x, const float* dy, int B, int64_t n_per_item, float* out, void* stream);
+
 /* One Adam step over flat device buffers, in place (srcs/train.py:365-371: optim.Adam(params, lr); torch's defaults are
  * beta1 0.9, beta2 0.999, eps 1e-8, no weight decay, no amsgrad).  `step` counts from 1 (bias correction). */
 int ldc_train_adam_step(ldc_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,

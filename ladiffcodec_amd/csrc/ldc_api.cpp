@@ -2592,6 +2592,32 @@ extern "C" int ldc_train_attn_backward(ldc_ctx* c, const float* dout, const floa
   return finish_stream(c, stream);
 }
 
+extern "C" int ldc_train_convtr_forward(ldc_ctx* c, const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int ratio,
+                                        float* y, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!x || !w || !y || B < 1 || Cin < 1 || Cout < 1 || L < 1 || ratio < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_convtr_forward(x, w, bias, B, Cin, Cout, L, ratio, y, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_convtr_backward(ldc_ctx* c, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int ratio,
+                                         float* dx, float* dw, float* db, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!dy || !x || !w || !dw || B < 1 || Cin < 1 || Cout < 1 || L < 1 || ratio < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_convtr_backward(dy, x, w, B, Cin, Cout, L, ratio, dx, dw, db, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_maxscale(ldc_ctx* c, const float* x, const float* dy, int B, int64_t n_per_item, float* out, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!x || !out || B < 1 || n_per_item < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_maxscale(x, dy, B, n_per_item, out, s));
+  return finish_stream(c, stream);
+}
+
 extern "C" int ldc_train_adam_step(ldc_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                                    float lr, float beta1, float beta2, float eps, void* stream) {
   LDCCHK(check_dev(c));

@@ -263,6 +263,11 @@ hipError_t launch_train_act(const float* x, const float* dy, int64_t n, int kind
 size_t train_attn_ws_floats(int B, int H, int N);
 hipError_t launch_train_attn_forward(const float* qkv, int B, int H, int D, int N, float* out, float* ws, hipStream_t s);
 hipError_t launch_train_attn_backward(const float* d_o, const float* qkv, int B, int H, int D, int N, float* ws, float* dqkv, hipStream_t s);
+hipError_t launch_train_convtr_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int r, float* y,
+                                       hipStream_t s);
+hipError_t launch_train_convtr_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int r, float* dx,
+                                        float* dw, float* db, hipStream_t s);
+hipError_t launch_train_maxscale(const float* x, const float* dy, int B, int64_t n_per_item, float* out, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, hipStream_t s);
 hipError_t launch_train_ln_forward(const float* x, const float* g, int B, int C, int L, float* y, float* stats, hipStream_t s);
 hipError_t launch_train_ln_backward(const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L, float* dx,

@@ -808,4 +808,95 @@ hipError_t launch_train_attn_backward(const float* d_o, const float* qkv, int B,
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Unet1D.process_cond (unet.py:407-420) for training: the condition upsampler SConvTranspose1d(C, C, kernel 2r, stride r,
+// non-causal: conv.py:235-274 trims r - r/2 samples on the left and r/2 on the right) forward / backward, and the per-item
+// max-abs scaling x / (max|x| + 1e-20) (unet.py:401-403) forward / backward.  ConvTranspose1d weight layout [Cin, Cout, 2r].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void convtr_forward_kernel(const float* x, const float* w, const float* bias, int Cin, int Cout, int L, int r,
+                                                             float* y) {
+  const int b = blockIdx.z, o = blockIdx.y, pl = r - r / 2, K = 2 * r, Lo = L * r;
+  for (int mp = blockIdx.x * 256 + threadIdx.x; mp < Lo; mp += gridDim.x * 256) {
+    const int m = mp + pl;
+    float acc = bias ? bias[o] : 0.f;
+    for (int t = m % r; t < K; t += r) {
+      const int l = (m - t) / r;
+      if (l < 0 || l >= L) continue;
+      for (int i = 0; i < Cin; ++i) acc = fmaf(x[((size_t)b * Cin + i) * L + l], w[((size_t)i * Cout + o) * K + t], acc);
+    }
+    y[((size_t)b * Cout + o) * Lo + mp] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void convtr_dx_kernel(const float* dy, const float* w, int Cin, int Cout, int L, int r, float* dx) {
+  const int b = blockIdx.z, i = blockIdx.y, pl = r - r / 2, K = 2 * r, Lo = L * r;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < L; l += gridDim.x * 256) {
+    float acc = 0.f;
+    for (int t = 0; t < K; ++t) {
+      const int mp = l * r + t - pl;
+      if (mp < 0 || mp >= Lo) continue;
+      for (int o = 0; o < Cout; ++o) acc = fmaf(dy[((size_t)b * Cout + o) * Lo + mp], w[((size_t)i * Cout + o) * K + t], acc);
+    }
+    dx[((size_t)b * Cin + i) * L + l] = acc;
+  }
+}
+// dw[i,o,t] = sum_{b,l} x[b,i,l] * dy[b,o,l*r + t - pl]; one block per (o, i, t)
+__global__ __launch_bounds__(256) void convtr_dw_kernel(const float* dy, const float* x, int B, int Cin, int Cout, int L, int r, float* dw) {
+  __shared__ float red[4];
+  const int o = blockIdx.x, i = blockIdx.y, t = blockIdx.z, pl = r - r / 2, K = 2 * r, Lo = L * r;
+  float a = 0.f;
+  for (int idx = threadIdx.x; idx < B * L; idx += 256) {
+    const int b = idx / L, l = idx - b * L, mp = l * r + t - pl;
+    if (mp >= 0 && mp < Lo) a = fmaf(x[((size_t)b * Cin + i) * L + l], dy[((size_t)b * Cout + o) * Lo + mp], a);
+  }
+  const float tot = block_sum(a, red);
+  if (threadIdx.x == 0) dw[((size_t)i * Cout + o) * K + t] = tot;
+}
+hipError_t launch_train_convtr_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int r, float* y,
+                                       hipStream_t s) {
+  hipLaunchKernelGGL(convtr_forward_kernel, dim3((L * r + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, L, r, y);
+  return hipGetLastError();
+}
+hipError_t launch_train_convtr_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int r, float* dx,
+                                        float* dw, float* db, hipStream_t s) {
+  if (dx) hipLaunchKernelGGL(convtr_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, dy, w, Cin, Cout, L, r, dx);
+  hipLaunchKernelGGL(convtr_dw_kernel, dim3(Cout, Cin, 2 * r), dim3(256), 0, s, dy, x, B, Cin, Cout, L, r, dw);
+  if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L * r, db);
+  return hipGetLastError();
+}
+// one block per item.  forward (dy == nullptr): out = x / (max|x| + 1e-20).  backward: out = dy / (s + eps) - [j == argmax] * sign(x_j) *
+// sum_k dy_k x_k / (s + eps)^2 (torch's max sends the gradient to the first maximal element)
+__global__ __launch_bounds__(256) void maxscale_kernel(const float* x, const float* dy, int64_t n, float* out) {
+  __shared__ float red[4];
+  __shared__ long long s_arg;
+  const float* xb = x + (size_t)blockIdx.x * n;
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(xb[i]));
+  m = block_max(m, red);
+  const float inv = 1.0f / (m + 1e-20f);
+  float* ob = out + (size_t)blockIdx.x * n;
+  if (!dy) {
+    for (int64_t i = threadIdx.x; i < n; i += 256) ob[i] = xb[i] * inv;
+    return;
+  }
+  const float* db = dy + (size_t)blockIdx.x * n;
+  float dot = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) dot = fmaf(db[i], xb[i], dot);
+  dot = block_sum(dot, red);
+  if (threadIdx.x == 0) s_arg = (long long)n;
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < n; i += 256)
+    if (fabsf(xb[i]) == m) atomicMin(&s_arg, (long long)i);
+  __syncthreads();
+  const long long arg = s_arg;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    float g = db[i] * inv;
+    if (i == arg) g -= (xb[i] < 0.f ? -1.0f : 1.0f) * dot * inv * inv;
+    ob[i] = g;
+  }
+}
+hipError_t launch_train_maxscale(const float* x, const float* dy, int B, int64_t n_per_item, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(maxscale_kernel, dim3(B), dim3(256), 0, s, x, dy, n_per_item, out);
+  return hipGetLastError();
+}
+
 }  // namespace ldc

@@ -394,13 +394,69 @@ class Attention:
         return {"norm.g": dg_pre, "to_qkv.weight": g_qkv["dw"], "to_out.weight": g_out["dw"], "to_out.bias": g_out["db"], "dx": dxn + dy}
 
 
+class ConvTranspose1d:
+    """SConvTranspose1d(C, C, kernel 2r, stride r, non-causal) of the condition upsampler (unet.py:372-377, conv.py:235-274)."""
+
+    def __init__(self, eng, weight, bias, ratio: int):
+        t = eng.torch
+        self.eng, self.lib, self.torch, self.ratio = eng, eng.lib, t, int(ratio)
+        self.weight = weight.to(eng.device, t.float32).contiguous()          # [Cin, Cout, 2r]
+        self.bias = bias.to(eng.device, t.float32).contiguous() if bias is not None else None
+        assert self.weight.shape[2] == 2 * self.ratio
+
+    def forward(self, x):
+        t = self.torch
+        x = x.to(self.eng.device, t.float32).contiguous()
+        B, Cin, Lx = x.shape
+        Cout = self.weight.shape[1]
+        y = t.empty(B, Cout, Lx * self.ratio, dtype=t.float32, device=self.eng.device)
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_convtr_forward(self.eng._ctx, x.data_ptr(), self.weight.data_ptr(), self.bias.data_ptr() if self.bias is not None else None,
+                                                  B, Cin, Cout, Lx, self.ratio, y.data_ptr(), s))
+        self.eng._exit()
+        self._saved = x
+        return y
+
+    def backward(self, dy):
+        t = self.torch
+        x = self._saved
+        B, Cin, Lx = x.shape
+        Cout = self.weight.shape[1]
+        dy = dy.to(self.eng.device, t.float32).contiguous()
+        dx, dw = t.empty_like(x), t.empty_like(self.weight)
+        db = t.empty(Cout, dtype=t.float32, device=self.eng.device) if self.bias is not None else None
+        s = self.eng._enter()
+        L.check(self.lib.ldc_train_convtr_backward(self.eng._ctx, dy.data_ptr(), x.data_ptr(), self.weight.data_ptr(), B, Cin, Cout, Lx, self.ratio,
+                                                   dx.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, s))
+        self.eng._exit()
+        return {"dx": dx, "dw": dw, "db": db}
+
+
+def maxscale(eng, x, dy=None):
+    """Unet1D.scaling (unet.py:401-403): x / (max|x| per item + 1e-20); with dy: the gradient w.r.t. x."""
+    t = eng.torch
+    x = x.to(eng.device, t.float32).contiguous()
+    out = t.empty_like(x)
+    dyc = dy.to(eng.device, t.float32).contiguous() if dy is not None else None
+    s = eng._enter()
+    L.check(eng.lib.ldc_train_maxscale(eng._ctx, x.data_ptr(), dyc.data_ptr() if dyc is not None else None, x.shape[0], x.numel() // x.shape[0],
+                                       out.data_ptr(), s))
+    eng._exit()
+    return out
+
+
 class Unet1D:
     """Unet1D.forward (srcs/modules/unet.py:422-469) and its backward pass over the reference's own state dict
     (`other_cond` layout: x_cond is concatenated in front of x; process_cond's upsampler / scaling are applied by the caller).
     fp32 correctness path of the training step: every layer is one of this module's forward/backward pairs."""
 
-    def __init__(self, eng, sd: dict, dim: int, dim_mults=(1, 2, 4, 8), heads: int = 4, dim_head: int = 32, groups: int = 8):
+    def __init__(self, eng, sd: dict, dim: int, dim_mults=(1, 2, 4, 8), heads: int = 4, dim_head: int = 32, groups: int = 8,
+                 upsampling_ratios=None, unet_scale_cond: bool = False):
         self.eng, self.torch, self.dim = eng, eng.torch, dim
+        # process_cond (unet.py:407-420): the upsampling layers are parameters of diff_model and are trained with it
+        self.upsampling = [ConvTranspose1d(eng, sd[f"upsampling_layers.{i}.convtr.convtr.weight"], sd[f"upsampling_layers.{i}.convtr.convtr.bias"], r)
+                           for i, r in enumerate(upsampling_ratios or ())]
+        self.scale_cond = bool(unet_scale_cond)
         sub = lambda prefix: {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
         att = lambda prefix: {"norm.g": sd[prefix + "fn.norm.g"], **{k: v for k, v in sub(prefix + "fn.fn.").items()}}
         self.init_conv = Conv1d(eng, sd["init_conv.weight"], sd["init_conv.bias"], 1, 3)
@@ -436,6 +492,11 @@ class Unet1D:
     def forward(self, x, time, x_cond):
         t = self.torch
         self._ccond = x_cond.shape[1]
+        for layer in self.upsampling:
+            x_cond = layer.forward(x_cond)
+        if self.scale_cond:
+            self._cond_pre_scale = x_cond.to(self.eng.device, t.float32).contiguous()
+            x_cond = maxscale(self.eng, self._cond_pre_scale)
         x = t.cat((x_cond.to(self.eng.device, t.float32), x.to(self.eng.device, t.float32)), dim=1).contiguous()
         x = self.init_conv.forward(x)
         r = x
@@ -532,17 +593,25 @@ class Unet1D:
         g1 = self.t1.backward(activation(self.eng, self._t_pre, ACT_GELU, dy=g2["dx"]), want_dx=False)
         grads["time_mlp.1.weight"], grads["time_mlp.1.bias"] = g1["dw"], g1["db"]
         cc = self._ccond
-        return grads, g["dx"][:, cc:].contiguous(), g["dx"][:, :cc].contiguous()
+        dx, dcond = g["dx"][:, cc:].contiguous(), g["dx"][:, :cc].contiguous()
+        if self.scale_cond:
+            dcond = maxscale(self.eng, self._cond_pre_scale, dy=dcond)
+        for i in reversed(range(len(self.upsampling))):
+            gu = self.upsampling[i].backward(dcond)
+            grads[f"upsampling_layers.{i}.convtr.convtr.weight"], grads[f"upsampling_layers.{i}.convtr.convtr.bias"] = gu["dw"], gu["db"]
+            dcond = gu["dx"]
+        return grads, dx, dcond
 
 
 class DiffusionTrainer:
     """One optimisation step of the diffusion UNet as srcs/train.py:110-177 runs it for --run_diff (the codec is frozen, only
     model.diff_model's parameters are optimised, train.py:365): q_sample -> Unet1D forward -> p_losses objective -> Unet1D backward
     -> gradient averaging over ranks (one flat reduce-scatter + all-gather) -> Adam.  `x_start` is the scaled latent
-    (model.py:165) and `cond` the processed condition (Unet1D.process_cond), both produced by the inference kernels; the
-    condition upsampler's own parameters are not trained here (next slice)."""
+    (model.py:165) produced by the inference kernels, `cond` the condition of model_for_cond.get_cond: with `upsampling_ratios` /
+    `unet_scale_cond` given, Unet1D.process_cond and the upsampler's own parameters are part of the step."""
 
     def __init__(self, eng, sd: dict, dim: int, dim_mults=(1, 2, 4, 8), lr: float = 1e-4, **kw):
+        """kw: heads, dim_head, groups, upsampling_ratios, unet_scale_cond of Unet1D (with upsampling_ratios the raw condition is passed to step)."""
         t = eng.torch
         self.eng, self.torch = eng, t
         self.names = sorted(sd)

@@ -206,3 +206,19 @@ def test_training_steps_follow_the_reference_loop():
     final = tr.state_dict()
     worst = max((float((final[k].cpu() - want_sd["diff_model." + k]).abs().max()), k) for k in sd)
     assert worst[0] < 2e-4, worst            # parameters move by ~lr per step; an Adam sign flip would be 4e-3
+
+
+def test_assembled_unet_with_process_cond_reference_vectors():
+    """Unet1D with upsampling_ratios [5, 2] and unet_scale_cond: the condition upsamplers' parameters and the raw condition get
+    their gradients through the max-abs scaling and both transposed convs (every parameter of diff_model is covered)."""
+    g = load_golden("train_unet")
+    e = engine("r84", "f32")
+    sd = {k[4:]: T(g[k]) for k in list(g.keys()) if k.startswith("u.p.")}
+    net = TR.Unet1D(e, sd, dim=16, dim_mults=(1, 2), upsampling_ratios=(5, 2), unet_scale_cond=True)
+    y = net.forward(T(g["u.x"]), torch.from_numpy(g["u.time"]), T(g["u.cond"]))
+    assert rel(y.cpu().numpy(), g["u.y"]) < TOL
+    grads, dx, dcond = net.backward(T(g["u.dy"]))
+    assert rel(dx.cpu().numpy(), g["u.dx"]) < TOL and rel(dcond.cpu().numpy(), g["u.dcond"]) < 2e-4
+    assert set(grads) == set(sd), (set(sd) - set(grads), set(grads) - set(sd))
+    worst = max((rel(grads[k].cpu().numpy().reshape(g["u.g." + k].shape), g["u.g." + k]), k) for k in sd)
+    assert worst[0] < 2e-4, worst

@@ -88,3 +88,19 @@ def test_oracle_unet_gradients_match_reference_autograd():
     worst = max((rel_err(v.grad.numpy(), g["g." + k[len("diff_model."):]]), k) for k, v in sd.items() if v.grad is not None)
     assert worst[0] < 1e-4, worst
     assert sum(v.grad is not None for v in sd.values()) == len(sd)          # every parameter is on the path
+
+
+def test_oracle_unet_with_process_cond_matches_reference_autograd():
+    """The same through Unet1D.process_cond: two SConvTranspose1d upsamplers and the per-item max-abs scaling are on the gradient path."""
+    from ladiffcodec_amd.spec import UnetConfig
+    from oracle import ldc_oracle as O
+    g = load_golden("train_unet")
+    u = UnetConfig(dim=16, dim_mults=(1, 2), inp_channels=8, cond_channels=8, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    sd = {"diff_model." + k[4:]: T(g[k]).requires_grad_() for k in list(g.keys()) if k.startswith("u.p.")}
+    x, c = T(g["u.x"]).requires_grad_(), T(g["u.cond"]).requires_grad_()
+    y = O.unet_forward(sd, u, x, torch.from_numpy(g["u.time"]), c)
+    assert rel_err(y.detach().numpy(), g["u.y"]) < 1e-5
+    y.backward(T(g["u.dy"]))
+    assert rel_err(x.grad.numpy(), g["u.dx"]) < 1e-4 and rel_err(c.grad.numpy(), g["u.dcond"]) < 1e-4
+    worst = max((rel_err(v.grad.numpy(), g["u.g." + k[len("diff_model."):]]), k) for k, v in sd.items())
+    assert worst[0] < 1e-4, worst

@@ -401,6 +401,19 @@ def main():
         for name, prm in net.named_parameters():
             out["p." + name] = np32(prm)
             out["g." + name] = np32(prm.grad) if prm.grad is not None else np.zeros(prm.shape, np.float32)
+        # the same net with process_cond in the path: upsampling_ratios [5, 2] (two SConvTranspose1d) and unet_scale_cond
+        torch.manual_seed(5252)
+        net2 = Unet1D(16, dim_mults=(1, 2), inp_channels=8, other_cond=True, cond_channels=8, upsampling_ratios=[5, 2], unet_scale_cond=True)
+        x2 = torch.randn(2, 8, 40, generator=gg, requires_grad=True)
+        c2 = torch.randn(2, 8, 4, generator=gg, requires_grad=True)
+        y2 = net2(x2, torch.tensor([250, 3]), c2)
+        dy2 = torch.randn(y2.shape, generator=gg)
+        y2.backward(dy2)
+        out.update({"u.x": np32(x2), "u.cond": np32(c2), "u.time": np.array([250, 3], np.int64), "u.y": np32(y2), "u.dy": np32(dy2),
+                    "u.dx": np32(x2.grad), "u.dcond": np32(c2.grad)})
+        for name, prm in net2.named_parameters():
+            out["u.p." + name] = np32(prm)
+            out["u.g." + name] = np32(prm.grad)
         np.savez_compressed(os.path.join(OUT, "train_unet.npz"), **out)
         print("train_unet:", len([k for k in out if k.startswith("p.")]), "parameters,", sum(v.size for k, v in out.items() if k.startswith("p.")), "elements")
 
