@@ -208,7 +208,7 @@ int ldc_ac_decode(ldc_ctx* ctx, const uint8_t* in, int64_t in_stride, const int6
 int64_t ldc_resample_out_len(int64_t T, int orig_freq, int new_freq);
 int ldc_resample(ldc_ctx* ctx, const float* wav, int C, int64_t T, int orig_freq, int new_freq, float* out, void* stream);
 
-/* training step, first slice -- SURVEY.md section 8(f) row 2 (BASELINE config 4); fp32, reference layouts [B,C,L] --------------
+/* training step of the diffusion UNet -- SURVEY.md section 8(f) row 2 (BASELINE config 4); fp32 correctness path, reference layouts [B,C,L]
  * diffusion.q_sample(x_start, t, noise) (ddpm_loss.py:386-392); t [B] int64 (device). */
 int ldc_train_q_sample(ldc_ctx* ctx, const float* x_start, const int64_t* t, const float* noise, int B, int C, int L, float* x_t,
                        void* stream);

@@ -1,4 +1,4 @@
-// train.hip -- first slice of the diffusion TRAINING step (BASELINE config 4):
+// train.hip -- the diffusion TRAINING step (BASELINE config 4), fp32 correctness path:
 //
 //   q_sample                      srcs/losses/ddpm_loss.py:386-392   x_t = sqrt(abar_t) x0 + sqrt(1 - abar_t) eps
 //   loss of p_losses              ddpm_loss.py:434-438               mean_b( p2w[t_b] * mean_{c,l} |out - target| ), and d/d out
@@ -10,12 +10,15 @@
 //                                 whole ResnetBlock (unet.py:157-192) runs forward and backward (ladiffcodec_amd/train.py)
 //   LinearAttention core fwd/bwd  unet.py:208-221 (both softmaxes and both einsums); with the pointwise maps and the LayerNorm the whole
 //                                 Residual(PreNorm(LinearAttention)) block runs forward and backward (ladiffcodec_amd/train.py)
+//   plain Conv1d, nearest x2, tanh / GELU / SiLU, softmax Attention core, condition upsampler (transposed conv) + max-abs scaling:
+//                                 the remaining layers of Unet1D (unet.py:248-470), each forward and backward
 //   Adam step                     srcs/train.py:365-371 (optim.Adam(params, lr)), flat parameter / gradient / moment buffers
+// ladiffcodec_amd/train.py assembles them into Unet1D.forward / backward and DiffusionTrainer.step.
 //
-// fp32 throughout, reference layouts [B, C, L].  This slice is the correctness baseline of the training path (gradients
-// pinned to the reference's autograd, tests/golden/train_block.npz); the three GEMM-shaped pieces (conv forward, dX, dW)
-// are plain tiled VALU kernels here -- the MFMA forms (the dX conv is conv_fast with flipped taps, dW is a
-// [Cout x Cin*3] x [B*L] contraction) are the next step and are not claimed.
+// fp32 throughout, reference layouts [B, C, L].  This is the correctness baseline of the training path: every layer, the assembled
+// UNet and a short optimisation run are pinned to the reference's autograd / torch.optim.Adam (tests/golden/train_block.npz,
+// train_unet.npz).  The GEMM-shaped pieces (conv forward, dX, dW) are plain VALU kernels here -- the MFMA forms (the dX conv is
+// conv_fast with flipped taps, dW is a [Cout x Cin*k] x [B*L] contraction) are the next step; no training throughput is claimed.
 #include <algorithm>
 
 #include "ldc_kernels.h"
