@@ -643,3 +643,19 @@ class DiffusionTrainer:
         parallel.allreduce_gradients(flat_g)           # no-op without a process group
         self.opt.step(flat_g)
         return loss
+
+    def step_from_wav(self, wav, t=None, noise=None, latent_scale: float = 18.0, generator=None):
+        """The step as srcs/train.py:110-160 + DiffAudioRep.forward (model.py:146-182) drive it from audio: cond =
+        model_for_cond.get_cond(x); x_rep = encoder(x) (frozen) / 18 (--scaling_global); t ~ U{0..T-1}, noise ~ N(0, I)
+        (ddpm_loss.py:443-449) unless given; then `step`.  The engine's inference kernels run the two frozen encoders."""
+        from . import lib as LL
+        tt = self.torch
+        wav = wav.to(self.eng.device, tt.float32).contiguous()
+        cond = self.eng.get_cond(wav)
+        x_rep = self.eng.encode(LL.MODEL_MAIN, wav) / float(latent_scale)
+        B = x_rep.shape[0]
+        if t is None:
+            t = tt.randint(0, 1000, (B,), generator=generator)
+        if noise is None:
+            noise = tt.randn(x_rep.shape, generator=generator)
+        return self.step(x_rep, cond, t, noise)

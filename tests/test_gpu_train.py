@@ -222,3 +222,40 @@ def test_assembled_unet_with_process_cond_reference_vectors():
     assert set(grads) == set(sd), (set(sd) - set(grads), set(grads) - set(sd))
     worst = max((rel(grads[k].cpu().numpy().reshape(g["u.g." + k].shape), g["u.g." + k]), k) for k in sd)
     assert worst[0] < 2e-4, worst
+
+
+def test_training_step_from_audio_matches_oracle():
+    """train.py's step driven from audio on the small fixture model (five UNet levels, two upsamplers, scaled condition): frozen
+    SEANet encoder + condition codec on the inference kernels, then q_sample -> UNet -> objective -> backward -> Adam; the loss
+    and the updated parameters against the oracle's encoders + autograd + torch.optim.Adam."""
+    from ladiffcodec_amd import synth
+    from oracle import ldc_oracle as O
+    from helpers import CASES, COND_CFG, cond_sd_np, main_sd_np
+    mc, u, _ = CASES["r84"]
+    e = engine("r84", "f32")
+    full = main_sd_np("r84")
+    sd_np = {k[len("diff_model."):]: v for k, v in full.items() if k.startswith("diff_model.")}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+    tr = TR.DiffusionTrainer(e, sd, dim=u.dim, dim_mults=u.dim_mults, lr=1e-3, upsampling_ratios=u.upsampling_ratios, unet_scale_cond=u.unet_scale_cond)
+    T_ = 2560
+    wav = torch.from_numpy(synth.synthetic_wav(2, T_, seed=77))
+    gen = torch.Generator().manual_seed(8)
+    t = torch.tensor([123, 871])
+    noise = torch.randn(2, 128, T_ // mc.hop_length, generator=gen)
+    loss = float(tr.step_from_wav(wav, t=t, noise=noise).cpu()[0])
+    # oracle
+    sdm, sdc = synth.to_torch(full), synth.to_torch(cond_sd_np())
+    with torch.no_grad():
+        cond = O.get_cond(sdc, COND_CFG, wav)[0]
+        x0 = O.seanet_encode(sdm, mc, wav) / 18.0
+    params = {k: v.clone().requires_grad_() for k, v in sdm.items() if k.startswith("diff_model.")}
+    sched = {k: v for k, v in sdm.items() if k.startswith("diffusion.")}
+    x_t = TO.q_sample(sched, x0, t, noise)
+    want = TO.p_losses_objective(sched, O.unet_forward(params, u, x_t, t, cond), noise, t)
+    assert abs(loss - float(want.detach())) < 2e-4 * max(1.0, abs(float(want.detach())))
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    want.backward()
+    opt.step()
+    final = tr.state_dict()
+    worst = max((float((final[k[len("diff_model."):]].cpu() - v.detach()).abs().max()), k) for k, v in params.items())
+    assert worst[0] < 2e-4, worst          # first Adam step moves every parameter by ~lr = 1e-3
