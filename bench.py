@@ -85,16 +85,90 @@ def cpu_baseline(cc, mc, u, sd_cond, sd_main, n_steps, seconds, batch, budget_s=
                       f"rest extrapolated"}
 
 
+def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, dev, result_fd):
+    """BASELINE configs[3]: one optimisation step of the diffusion UNet per bench step (srcs/train.py --run_diff: frozen encoders,
+    q_sample, UNet forward, l1 objective, UNet backward, gradient averaging over ranks, Adam) on B utterances per GPU.  The training
+    path is the fp32 VALU correctness path of csrc/train.hip (pinned to the reference's autograd), not a tuned one."""
+    from ladiffcodec_amd import train as TR
+    B = wav.shape[0]
+    sd = {k[len("diff_model."):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_main.items() if k.startswith("diff_model.")}
+    tr = TR.DiffusionTrainer(eng, sd, dim=u.dim, dim_mults=u.dim_mults, lr=1e-4, upsampling_ratios=u.upsampling_ratios,
+                             unet_scale_cond=u.unet_scale_cond)
+    for i in range(args.warmup):
+        tr.step_from_wav(wav)
+        torch.cuda.synchronize(dev)
+        log(f"warmup {i} done")
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step_from_wav(wav)
+    torch.cuda.synchronize(dev)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+    assert bool(torch.isfinite(loss).all()), "non-finite loss"
+    log(f"timed region: {elapsed:.3f} s for {args.steps} optimisation step(s), last loss {float(loss.cpu()[0]):.4f}")
+    n_par = sum(v.numel() for v in sd.values())
+    fwd_flops, _ = eng.unet_step_cost(B, T // mc.hop_length)
+    ach = 3.0 * fwd_flops * args.steps / elapsed / 1e12           # forward + dX + dW of every conv-shaped layer
+    result = {
+        "metric": "audio-sec per wall-sec through ONE optimisation step of the diffusion UNet (training, --run_diff)",
+        "value": world * B * (T / 16000.0) * args.steps / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio, device-drawn t / noise)",
+        "config": {"workload": f"diffusion training step, diff_dims={u.dim}, seq_length {T // mc.hop_length}, batch={B}x{T / 16000.0:.1f} s per GPU, "
+                               f"Adam over {n_par / 1e6:.1f} M parameters", "name": "c4", "global_batch": world * B,
+                   "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                   "parallelism": f"dp{world} (flat fp32 gradient reduce-scatter + all-gather per step: {4 * n_par / 1e6:.0f} MB)"},
+        "roofline": {"bound": "mfma", "kernel": "conv / pointwise forward, dX and dW of csrc/train.hip (fp32 VALU reference kernels, no MFMA yet)",
+                     "achieved": ach, "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS["f32"], "traffic": None,
+                     "note": "whole-step average: 3 x the UNet's forward conv flops / step time; the correctness path is priced against the "
+                             "roof its MFMA successor will have"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ldc_oracle as O, train_oracle as TO
+        cores = host_threads()
+        torch.set_num_threads(cores)
+        nb = min(2, B)
+        a, b = synth.to_torch(sd_cond), synth.to_torch(sd_main)
+        w = wav[:nb].cpu()
+        params = {k: v.clone().requires_grad_() for k, v in b.items() if k.startswith("diff_model.")}
+        sched = {k: v for k, v in b.items() if k.startswith("diffusion.")}
+        opt = torch.optim.Adam(list(params.values()), lr=1e-4)
+        g = torch.Generator().manual_seed(1)
+        times = []
+        for _ in range(2):
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                cond = O.get_cond(a, cc, w)[0]
+                x0 = O.seanet_encode(b, mc, w) / 18.0
+            t = torch.randint(0, 1000, (nb,), generator=g)
+            noise = torch.randn(x0.shape, generator=g)
+            opt.zero_grad()
+            lo = TO.p_losses_objective(sched, O.unet_forward(params, u, TO.q_sample(sched, x0, t, noise), t, cond), noise, t)
+            lo.backward()
+            opt.step()
+            times.append(time.perf_counter() - t1)
+        result["cpu_baseline"] = {"value": nb * (T / 16000.0) / times[-1], "unit": "audio-s/wall-s", "cores": cores, "kind": "port",
+                                  "sample": f"{nb} x {T / 16000.0:.1f} s utterance(s), fp32 oracle under torch autograd + torch.optim.Adam, second of two steps ({times[-1]:.2f} s)"}
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
+    os.close(result_fd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c8", "c5"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c8", "c5", "c4"],
                     help="c2 = BASELINE configs[1] (the metric's config: 3 kbps, enc_ratios 8 4, 50 steps); c3 = configs[2] per GPU "
                          "(1.5 kbps condition, 200 steps); c8 = the released checkpoints' layout (enc_ratios 8, latent L = 4800, "
                          "upsampling 5 4 2; README.md:30,35), 3 kbps, 50 steps; c5 = configs[4]: one 30 s recording as 13 chunks of "
-                         "2.4 s (batch items), fp8 UNet weights")
+                         "2.4 s (batch items), fp8 UNet weights; c4 = configs[3] per GPU: one optimisation step of the diffusion UNet per bench step (fp32 correctness path of the training row)")
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (0 = the config's own: 32; c5: 13)")
     ap.add_argument("--seconds", type=float, default=2.4)
     ap.add_argument("--denoise-steps", type=int, default=0, help="0 = the config's own (50; c3: 200)")
@@ -110,7 +184,9 @@ def main():
                          "the timed region (supplementary number, see DESIGN.md section 7)")
     args = ap.parse_args()
     args.batch = args.batch or (13 if args.config == "c5" else 32)
-    args.dtype = args.dtype or ("fp8" if args.config == "c5" else "bf16")
+    args.dtype = args.dtype or ("fp8" if args.config == "c5" else ("f32" if args.config == "c4" else "bf16"))
+    if args.config == "c4":
+        args.in_flight, args.no_pipelined = 1, True
 
     # stdout carries exactly ONE line, the JSON result: RCCL prints a banner (version / hostname / library path) on
     # file descriptor 1 when the process group comes up, so route fd 1 to stderr until the result is written
@@ -167,6 +243,13 @@ def main():
 
     B = args.batch
     wav = torch.from_numpy(synth.synthetic_wav(B, T, seed=1234 + rank)).to(dev)   # resident in HBM before timing
+
+    if args.config == "c4":
+        bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, dev, result_fd)
+        eng.close()
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
 
     step_no = [0]
 

@@ -656,6 +656,6 @@ class DiffusionTrainer:
         B = x_rep.shape[0]
         if t is None:
             t = tt.randint(0, 1000, (B,), generator=generator)
-        if noise is None:
-            noise = tt.randn(x_rep.shape, generator=generator)
+        if noise is None:      # on the device unless a (CPU) generator asks for a reproducible host draw
+            noise = tt.randn(x_rep.shape, generator=generator) if generator is not None else tt.randn(x_rep.shape, device=self.eng.device)
         return self.step(x_rep, cond, t, noise)
