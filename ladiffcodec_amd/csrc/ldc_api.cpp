@@ -976,6 +976,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->strip_min_wgs = env_int("LDC_STRIP_MIN", 96);
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
   c->coop_launch = getenv("LDC_COOP_LAUNCH") ? 1 : 0;
+  g_train_valu = getenv("LDC_TRAIN_VALU") ? 1 : 0;
   c->coop_resident[0] = lstm_coop_resident(256) ? 1 : 0;
   c->coop_resident[1] = lstm_coop_resident(512) ? 1 : 0;
   c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;

@@ -140,6 +140,104 @@ __global__ __launch_bounds__(256) void ws_backward_kernel(const float* dwn, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// The three GEMM shapes of a Conv1d (any kernel size K, stride S, zero padding P) on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32:
+// bitwise an fmaf chain), [B, C, L] layouts, weights [Cout, Cin, K] -- no packing, the weights change every step:
+//   MODE 0 forward  y[b]  [Cout x Lout] = sum_t  W_t [Cout x Cin]   . x[b] shifted by t   [Cin x Lout]     (+ bias)
+//   MODE 1 dX       dx[b] [Cin x Lin]   = sum_t  W_t^T [Cin x Cout] . dy[b] shifted by -t [Cout x Lin]
+//   MODE 2 dW       dW_t  [Cout x Cin]  = sum_b  dy[b] [Cout x Lout] . x[b]^T shifted by t [Lout x Cin]     (grid z = tap)
+// 64 x 64 output tile per workgroup (2 x 2 waves of 32 x 32), reduction in chunks of 16 through LDS (k-major, so the 32 lanes
+// of a fragment read consecutive words).  The VALU forms above stay as the reference (LDC_TRAIN_VALU=1) and for L < 16.
+// ---------------------------------------------------------------------------------------------
+int g_train_valu = 0;   // set by ldc_create from LDC_TRAIN_VALU (process-wide tuning aid, like g_conv_stamps)
+
+typedef float tf32x16 __attribute__((ext_vector_type(16)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float* src, const float* bias, float* out, int B, int Cin, int Cout,
+                                                     int Lin, int Lout, int K, int S, int P) {
+  constexpr int PITCH = 64 + 4;
+  __shared__ float As[16][PITCH];
+  __shared__ float Bs[16][PITCH];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, i32 = lane & 31, g = lane >> 5;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, z = blockIdx.z;
+  // M, N of this mode
+  const int M = MODE == 1 ? Cin : Cout;
+  const int N = MODE == 0 ? Lout : (MODE == 1 ? Lin : Cin);
+  tf32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // outer / inner reduction ranges: (tap, channel chunks) for MODE 0 / 1, (item, position chunks) for MODE 2
+  const int outer_n = MODE == 2 ? B : K;
+  const int inner_n = MODE == 0 ? Cin : (MODE == 1 ? Cout : Lout);
+  for (int outer = 0; outer < outer_n; ++outer) {
+    for (int k0 = 0; k0 < inner_n; k0 += 16) {
+      // ---- A tile [64 m][16 k] -> As[k][m] ----
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float v = 0.f;
+        if (MODE == 2) {   // A(o, l) = dy[b][o][l]: consecutive threads walk l
+          const int k = tid & 15, m = (tid >> 4) + 16 * p, o = m0 + m, l = k0 + k;
+          if (o < Cout && l < Lout) v = src[((size_t)outer * Cout + o) * Lout + l];
+          As[k][m] = v;
+        } else {           // A(m, c) = w[o][i][t]: consecutive threads walk the reduction channel
+          const int k = tid & 15, m = (tid >> 4) + 16 * p, c = k0 + k;
+          const int o = MODE == 0 ? m0 + m : c, i = MODE == 0 ? c : m0 + m;
+          if (o < Cout && i < Cin) v = w[((size_t)o * Cin + i) * K + outer];
+          As[k][m] = v;
+        }
+      }
+      // ---- B tile [16 k][64 n] -> Bs[k][n] ----
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float v = 0.f;
+        if (MODE == 0) {          // B(i, l) = x[b][i][l*S + t - P]
+          const int n = tid & 63, k = (tid >> 6) + 4 * p, i = k0 + k, l = n0 + n, pos = l * S + outer - P;
+          if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = src[((size_t)z * Cin + i) * Lin + pos];
+          Bs[k][n] = v;
+        } else if (MODE == 1) {   // B(o, m) = dy[b][o][(m + P - t) / S]
+          const int n = tid & 63, k = (tid >> 6) + 4 * p, o = k0 + k, mpos = n0 + n, u = mpos + P - outer;
+          if (o < Cout && mpos < Lin && u >= 0 && (S == 1 || u % S == 0)) {
+            const int l = S == 1 ? u : u / S;
+            if (l < Lout) v = src[((size_t)z * Cout + o) * Lout + l];
+          }
+          Bs[k][n] = v;
+        } else {                  // B(l, i) = x[b][i][l*S + t - P]: consecutive threads walk l
+          const int k = tid & 15, n = (tid >> 4) + 16 * p, l = k0 + k, i = n0 + n, pos = l * S + z - P;
+          if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = w[((size_t)outer * Cin + i) * Lin + pos];   // (w carries x in MODE 2)
+          Bs[k][n] = v;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sx = 0; sx < 8; ++sx)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * sx + g][32 * wm + i32], Bs[2 * sx + g][32 * wn + i32], acc, 0, 0, 0);
+      __syncthreads();
+    }
+  }
+  // C/D layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int n = n0 + 32 * wn + i32;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * g;
+    if (m >= M || n >= N) continue;
+    if (MODE == 0) out[((size_t)z * Cout + m) * Lout + n] = acc[r] + (bias ? bias[m] : 0.f);
+    else if (MODE == 1) out[((size_t)z * Cin + m) * Lin + n] = acc[r];
+    else out[((size_t)m * Cin + n) * K + z] = acc[r];
+  }
+}
+static bool convmm_ok(int Lin, int Lout) { return !g_train_valu && Lin >= 16 && Lout >= 16; }
+static void convmm_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
+                           float* y, hipStream_t s) {
+  hipLaunchKernelGGL(convmm_kernel<0>, dim3((Lout + 63) / 64, (Cout + 63) / 64, B), dim3(256), 0, s, w, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P);
+}
+static void convmm_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s) {
+  hipLaunchKernelGGL(convmm_kernel<1>, dim3((Lin + 63) / 64, (Cin + 63) / 64, B), dim3(256), 0, s, w, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P);
+}
+static void convmm_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s) {
+  hipLaunchKernelGGL(convmm_kernel<2>, dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, x, dy, nullptr, dw, B, Cin, Cout, Lin, Lout, K, S, P);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Conv1d k = 3, padding 1: forward, dX, dW, db  ([B, C, L] fp32)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv3_forward_kernel(const float* x, const float* w, const float* bias, int Cin, int Cout, int L,
@@ -304,7 +402,8 @@ hipError_t launch_train_block_forward(const float* x, const float* w, const floa
                                       const float* ss, int B, int Cin, int Cout, int L, int groups, float* y, float* ws, hipStream_t s) {
   const BlockWs k = carve(ws, B, Cin, Cout, L, groups);
   hipLaunchKernelGGL(ws_forward_kernel, dim3(Cout), dim3(256), 0, s, w, Cin * 3, k.wn, k.rstd_w);
-  hipLaunchKernelGGL(conv3_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, k.wn, bias, Cin, Cout, L, k.h);
+  if (convmm_ok(L, L)) convmm_forward(x, k.wn, bias, B, Cin, Cout, L, L, 3, 1, 1, k.h, s);
+  else hipLaunchKernelGGL(conv3_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, k.wn, bias, Cin, Cout, L, k.h);
   hipLaunchKernelGGL(gn_silu_forward_kernel, dim3(groups, B), dim3(256), 0, s, k.h, gamma, beta, ss, Cout, L, groups, y, k.stats);
   return hipGetLastError();
 }
@@ -319,9 +418,13 @@ hipError_t launch_train_block_backward(const float* dy, const float* x, const fl
   hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pbet, B, Cout, dbeta);
   hipLaunchKernelGGL(gn_silu_backward2_kernel, dim3(groups, B), dim3(256), 0, s, k.h, k.stats, Cout, L, groups, k.tmp);   // tmp := dh
   hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, k.tmp, B, Cout, L, db);
-  hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, k.tmp, x, B, Cin, Cout, L, k.dwn);
+  if (convmm_ok(L, L)) convmm_dw(k.tmp, x, B, Cin, Cout, L, L, 3, 1, 1, k.dwn, s);
+  else hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, k.tmp, x, B, Cin, Cout, L, k.dwn);
   hipLaunchKernelGGL(ws_backward_kernel, dim3(Cout), dim3(256), 0, s, k.dwn, k.wn, k.rstd_w, Cin * 3, dw);
-  if (dx) hipLaunchKernelGGL(conv3_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, k.tmp, k.wn, Cin, Cout, L, dx);
+  if (dx) {
+    if (convmm_ok(L, L)) convmm_dx(k.tmp, k.wn, B, Cin, Cout, L, L, 3, 1, 1, dx, s);
+    else hipLaunchKernelGGL(conv3_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, k.tmp, k.wn, Cin, Cout, L, dx);
+  }
   return hipGetLastError();
 }
 
@@ -463,13 +566,19 @@ __global__ __launch_bounds__(256) void pw_dw_kernel(const float* dy, const float
 }
 hipError_t launch_train_pw_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int pre_silu, float* y,
                                    hipStream_t s) {
-  hipLaunchKernelGGL(pw_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, L, pre_silu, y);
+  if (!pre_silu && convmm_ok(L, L)) convmm_forward(x, w, bias, B, Cin, Cout, L, L, 1, 1, 0, y, s);
+  else hipLaunchKernelGGL(pw_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, L, pre_silu, y);
   return hipGetLastError();
 }
 hipError_t launch_train_pw_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int pre_silu, float* dx,
                                     float* dw, float* db, hipStream_t s) {
-  if (dx) hipLaunchKernelGGL(pw_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, dy, x, w, Cin, Cout, L, pre_silu, dx);
-  hipLaunchKernelGGL(pw_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, dy, x, B, Cin, Cout, L, pre_silu, dw);
+  const bool mm = !pre_silu && convmm_ok(L, L);
+  if (dx) {
+    if (mm) convmm_dx(dy, w, B, Cin, Cout, L, L, 1, 1, 0, dx, s);
+    else hipLaunchKernelGGL(pw_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, dy, x, w, Cin, Cout, L, pre_silu, dx);
+  }
+  if (mm) convmm_dw(dy, x, B, Cin, Cout, L, L, 1, 1, 0, dw, s);
+  else hipLaunchKernelGGL(pw_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, dy, x, B, Cin, Cout, L, pre_silu, dw);
   if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L, db);
   return hipGetLastError();
 }
@@ -662,15 +771,21 @@ hipError_t launch_train_conv_forward(const float* x, const float* w, const float
                                      float* y, hipStream_t s) {
   const int Lout = (Lin + 2 * P - K) / S + 1;
   if (Lout < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(convg_forward_kernel, dim3((Lout + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, Lin, Lout, K, S, P, y);
+  if (convmm_ok(Lin, Lout)) convmm_forward(x, w, bias, B, Cin, Cout, Lin, Lout, K, S, P, y, s);
+  else hipLaunchKernelGGL(convg_forward_kernel, dim3((Lout + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, Lin, Lout, K, S, P, y);
   return hipGetLastError();
 }
 hipError_t launch_train_conv_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int Lin, int K, int S, int P,
                                       float* dx, float* dw, float* db, hipStream_t s) {
   const int Lout = (Lin + 2 * P - K) / S + 1;
   if (Lout < 1) return hipErrorInvalidValue;
-  if (dx) hipLaunchKernelGGL(convg_dx_kernel, dim3((Lin + 255) / 256, Cin, B), dim3(256), 0, s, dy, w, Cin, Cout, Lin, Lout, K, S, P, dx);
-  hipLaunchKernelGGL(convg_dw_kernel, dim3(Cin, Cout, K), dim3(256), 0, s, dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw);
+  const bool mm = convmm_ok(Lin, Lout);
+  if (dx) {
+    if (mm) convmm_dx(dy, w, B, Cin, Cout, Lin, Lout, K, S, P, dx, s);
+    else hipLaunchKernelGGL(convg_dx_kernel, dim3((Lin + 255) / 256, Cin, B), dim3(256), 0, s, dy, w, Cin, Cout, Lin, Lout, K, S, P, dx);
+  }
+  if (mm) convmm_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s);
+  else hipLaunchKernelGGL(convg_dw_kernel, dim3(Cin, Cout, K), dim3(256), 0, s, dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw);
   if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, Lout, db);
   return hipGetLastError();
 }
