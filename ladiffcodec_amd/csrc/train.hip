@@ -154,12 +154,14 @@ typedef float tf32x16 __attribute__((ext_vector_type(16)));
 
 template <int MODE>
 __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float* src, const float* bias, float* out, int B, int Cin, int Cout,
-                                                     int Lin, int Lout, int K, int S, int P) {
+                                                     int Lin, int Lout, int K, int S, int P, int nsplit) {
   constexpr int PITCH = 64 + 4;
   __shared__ float As[16][PITCH];
   __shared__ float Bs[16][PITCH];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, i32 = lane & 31, g = lane >> 5;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, z = blockIdx.z;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  // MODE 2: grid z = tap * nsplit + part; every part reduces its own items and adds its tile to the (pre-zeroed) gradient
+  const int z = MODE == 2 ? (int)blockIdx.z / nsplit : (int)blockIdx.z, part = MODE == 2 ? (int)blockIdx.z % nsplit : 0;
   // M, N of this mode
   const int M = MODE == 1 ? Cin : Cout;
   const int N = MODE == 0 ? Lout : (MODE == 1 ? Lin : Cin);
@@ -169,7 +171,9 @@ __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float
   // outer / inner reduction ranges: (tap, channel chunks) for MODE 0 / 1, (item, position chunks) for MODE 2
   const int outer_n = MODE == 2 ? B : K;
   const int inner_n = MODE == 0 ? Cin : (MODE == 1 ? Cout : Lout);
-  for (int outer = 0; outer < outer_n; ++outer) {
+  const int outer_lo = MODE == 2 ? (int)((long long)B * part / nsplit) : 0;
+  const int outer_hi = MODE == 2 ? (int)((long long)B * (part + 1) / nsplit) : outer_n;
+  for (int outer = outer_lo; outer < outer_hi; ++outer) {
     for (int k0 = 0; k0 < inner_n; k0 += 16) {
       // ---- A tile [64 m][16 k] -> As[k][m] ----
 #pragma unroll
@@ -222,19 +226,26 @@ __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float
     if (m >= M || n >= N) continue;
     if (MODE == 0) out[((size_t)z * Cout + m) * Lout + n] = acc[r] + (bias ? bias[m] : 0.f);
     else if (MODE == 1) out[((size_t)z * Cin + m) * Lin + n] = acc[r];
-    else out[((size_t)m * Cin + n) * K + z] = acc[r];
+    else if (nsplit == 1) out[((size_t)m * Cin + n) * K + z] = acc[r];
+    else atomicAdd(&out[((size_t)m * Cin + n) * K + z], acc[r]);
   }
 }
 static bool convmm_ok(int Lin, int Lout) { return !g_train_valu && Lin >= 16 && Lout >= 16; }
 static void convmm_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
                            float* y, hipStream_t s) {
-  hipLaunchKernelGGL(convmm_kernel<0>, dim3((Lout + 63) / 64, (Cout + 63) / 64, B), dim3(256), 0, s, w, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P);
+  hipLaunchKernelGGL(convmm_kernel<0>, dim3((Lout + 63) / 64, (Cout + 63) / 64, B), dim3(256), 0, s, w, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, 1);
 }
 static void convmm_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s) {
-  hipLaunchKernelGGL(convmm_kernel<1>, dim3((Lin + 63) / 64, (Cin + 63) / 64, B), dim3(256), 0, s, w, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P);
+  hipLaunchKernelGGL(convmm_kernel<1>, dim3((Lin + 63) / 64, (Cin + 63) / 64, B), dim3(256), 0, s, w, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, 1);
 }
 static void convmm_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s) {
-  hipLaunchKernelGGL(convmm_kernel<2>, dim3((Cin + 63) / 64, (Cout + 63) / 64, K), dim3(256), 0, s, x, dy, nullptr, dw, B, Cin, Cout, Lin, Lout, K, S, P);
+  // few output tiles, a long reduction over the items: split the items over workgroups (fp32 atomics into the zeroed gradient:
+  // the sum order varies from run to run at the 1e-7 level) until the grid fills the chip
+  const int tiles = ((Cin + 63) / 64) * ((Cout + 63) / 64) * K;
+  const int nsplit = std::max(1, std::min(B, (768 + tiles - 1) / tiles));
+  if (nsplit > 1) (void)hipMemsetAsync(dw, 0, (size_t)Cout * Cin * K * sizeof(float), s);
+  hipLaunchKernelGGL(convmm_kernel<2>, dim3((Cin + 63) / 64, (Cout + 63) / 64, K * nsplit), dim3(256), 0, s, x, dy, nullptr, dw, B, Cin, Cout, Lin, Lout, K, S,
+                     P, nsplit);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,15 +575,56 @@ __global__ __launch_bounds__(256) void pw_dw_kernel(const float* dy, const float
   const float t = block_sum(a, red);
   if (threadIdx.x == 0) dw[(size_t)o * Cin + i] = t;
 }
+// L == 1 (nn.Linear on [B, Cin], the time-embedding MLPs): one block per output, the reduction spread over the threads
+__global__ __launch_bounds__(256) void lin_forward_kernel(const float* x, const float* w, const float* bias, int Cin, int Cout, int pre_silu, float* y) {
+  __shared__ float red[4];
+  const int o = blockIdx.x, b = blockIdx.y;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < Cin; i += 256) {
+    float v = x[(size_t)b * Cin + i];
+    if (pre_silu) v = silu_f(v);
+    a = fmaf(w[(size_t)o * Cin + i], v, a);
+  }
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) y[(size_t)b * Cout + o] = a + (bias ? bias[o] : 0.f);
+}
+__global__ __launch_bounds__(256) void lin_dx_kernel(const float* dy, const float* x, const float* w, int Cin, int Cout, int pre_silu, float* dx) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, b = blockIdx.y;
+  float a = 0.f;
+  for (int o = threadIdx.x; o < Cout; o += 256) a = fmaf(w[(size_t)o * Cin + i], dy[(size_t)b * Cout + o], a);
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) dx[(size_t)b * Cin + i] = pre_silu ? a * silu_grad_f(x[(size_t)b * Cin + i]) : a;
+}
+// dw[o, i] = sum_b dy[b, o] * a(x[b, i]): one block per o, threads over i
+__global__ __launch_bounds__(256) void lin_dw_kernel(const float* dy, const float* x, int B, int Cin, int Cout, int pre_silu, float* dw) {
+  const int o = blockIdx.x;
+  for (int i = threadIdx.x; i < Cin; i += 256) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float v = x[(size_t)b * Cin + i];
+      if (pre_silu) v = silu_f(v);
+      a = fmaf(dy[(size_t)b * Cout + o], v, a);
+    }
+    dw[(size_t)o * Cin + i] = a;
+  }
+}
 hipError_t launch_train_pw_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int pre_silu, float* y,
                                    hipStream_t s) {
-  if (!pre_silu && convmm_ok(L, L)) convmm_forward(x, w, bias, B, Cin, Cout, L, L, 1, 1, 0, y, s);
+  if (L == 1 && !g_train_valu) hipLaunchKernelGGL(lin_forward_kernel, dim3(Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, pre_silu, y);
+  else if (!pre_silu && convmm_ok(L, L)) convmm_forward(x, w, bias, B, Cin, Cout, L, L, 1, 1, 0, y, s);
   else hipLaunchKernelGGL(pw_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, L, pre_silu, y);
   return hipGetLastError();
 }
 hipError_t launch_train_pw_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int pre_silu, float* dx,
                                     float* dw, float* db, hipStream_t s) {
   const bool mm = !pre_silu && convmm_ok(L, L);
+  if (L == 1 && !g_train_valu) {
+    if (dx) hipLaunchKernelGGL(lin_dx_kernel, dim3(Cin, B), dim3(256), 0, s, dy, x, w, Cin, Cout, pre_silu, dx);
+    hipLaunchKernelGGL(lin_dw_kernel, dim3(Cout), dim3(256), 0, s, dy, x, B, Cin, Cout, pre_silu, dw);
+    if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L, db);
+    return hipGetLastError();
+  }
   if (dx) {
     if (mm) convmm_dx(dy, w, B, Cin, Cout, L, L, 1, 1, 0, dx, s);
     else hipLaunchKernelGGL(pw_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, dy, x, w, Cin, Cout, L, pre_silu, dx);
