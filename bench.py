@@ -88,7 +88,7 @@ def cpu_baseline(cc, mc, u, sd_cond, sd_main, n_steps, seconds, batch, budget_s=
 def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, dev, result_fd):
     """BASELINE configs[3]: one optimisation step of the diffusion UNet per bench step (srcs/train.py --run_diff: frozen encoders,
     q_sample, UNet forward, l1 objective, UNet backward, gradient averaging over ranks, Adam) on B utterances per GPU.  The training
-    path is the fp32 VALU correctness path of csrc/train.hip (pinned to the reference's autograd), not a tuned one."""
+    path is csrc/train.hip (fp32; GEMM shapes on the exact-fp32 MFMA), pinned to the reference's autograd."""
     from ladiffcodec_amd import train as TR
     B = wav.shape[0]
     sd = {k[len("diff_model."):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_main.items() if k.startswith("diff_model.")}
@@ -122,10 +122,10 @@ def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, 
                                f"Adam over {n_par / 1e6:.1f} M parameters", "name": "c4", "global_batch": world * B,
                    "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                    "parallelism": f"dp{world} (flat fp32 gradient reduce-scatter + all-gather per step: {4 * n_par / 1e6:.0f} MB)"},
-        "roofline": {"bound": "mfma", "kernel": "conv / pointwise forward, dX and dW of csrc/train.hip (fp32 VALU reference kernels, no MFMA yet)",
+        "roofline": {"bound": "mfma", "kernel": "convmm_kernel<0|1|2>: forward, dX and dW of every conv / pointwise layer on the exact-fp32 MFMA (csrc/train.hip)",
                      "achieved": ach, "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS["f32"], "traffic": None,
-                     "note": "whole-step average: 3 x the UNet's forward conv flops / step time; the correctness path is priced against the "
-                             "roof its MFMA successor will have"},
+                     "note": "whole-step average: 3 x the UNet's forward conv flops / step time (frozen encoders, norms, attention cores and "
+                             "Adam included in the time)"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ldc_oracle as O, train_oracle as TO
