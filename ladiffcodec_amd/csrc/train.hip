@@ -15,10 +15,10 @@
 //   Adam step                     srcs/train.py:365-371 (optim.Adam(params, lr)), flat parameter / gradient / moment buffers
 // ladiffcodec_amd/train.py assembles them into Unet1D.forward / backward and DiffusionTrainer.step.
 //
-// fp32 throughout, reference layouts [B, C, L].  This is the correctness baseline of the training path: every layer, the assembled
-// UNet and a short optimisation run are pinned to the reference's autograd / torch.optim.Adam (tests/golden/train_block.npz,
-// train_unet.npz).  The GEMM-shaped pieces (conv forward, dX, dW) are plain VALU kernels here -- the MFMA forms (the dX conv is
-// conv_fast with flipped taps, dW is a [Cout x Cin*k] x [B*L] contraction) are the next step; no training throughput is claimed.
+// fp32 throughout, reference layouts [B, C, L].  Every layer, the assembled UNet and a short optimisation run are pinned to the
+// reference's autograd / torch.optim.Adam (tests/golden/train_block.npz, train_unet.npz).  The GEMM-shaped pieces (conv / pointwise
+// forward, dX, dW) run on the exact-fp32 MFMA (convmm_kernel below); their first VALU forms stay as the reference (LDC_TRAIN_VALU=1)
+// and for sequences shorter than 16.  bench.py --config c4 times the step; a bf16 path on conv_fast is the next slice.
 #include <algorithm>
 
 #include "ldc_kernels.h"
