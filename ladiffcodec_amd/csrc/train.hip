@@ -173,50 +173,59 @@ __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float
   const int inner_n = MODE == 0 ? Cin : (MODE == 1 ? Cout : Lout);
   const int outer_lo = MODE == 2 ? (int)((long long)B * part / nsplit) : 0;
   const int outer_hi = MODE == 2 ? (int)((long long)B * (part + 1) / nsplit) : outer_n;
-  for (int outer = outer_lo; outer < outer_hi; ++outer) {
-    for (int k0 = 0; k0 < inner_n; k0 += 16) {
-      // ---- A tile [64 m][16 k] -> As[k][m] ----
+  const int nchunk = (inner_n + 15) / 16;
+  const int n_it = (outer_hi - outer_lo) * nchunk;
+  // the tiles of reduction step `it` -> registers (the global loads of step it + 1 are in flight under the MFMAs of step it)
+  auto fetch = [&](int it, float (&ra)[4], float (&rb)[4]) {
+    const int outer = outer_lo + it / nchunk, k0 = (it % nchunk) * 16;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        float v = 0.f;
-        if (MODE == 2) {   // A(o, l) = dy[b][o][l]: consecutive threads walk l
-          const int k = tid & 15, m = (tid >> 4) + 16 * p, o = m0 + m, l = k0 + k;
-          if (o < Cout && l < Lout) v = src[((size_t)outer * Cout + o) * Lout + l];
-          As[k][m] = v;
-        } else {           // A(m, c) = w[o][i][t]: consecutive threads walk the reduction channel
-          const int k = tid & 15, m = (tid >> 4) + 16 * p, c = k0 + k;
-          const int o = MODE == 0 ? m0 + m : c, i = MODE == 0 ? c : m0 + m;
-          if (o < Cout && i < Cin) v = w[((size_t)o * Cin + i) * K + outer];
-          As[k][m] = v;
-        }
+    for (int p = 0; p < 4; ++p) {
+      float v = 0.f;
+      const int k = tid & 15, m = (tid >> 4) + 16 * p;
+      if (MODE == 2) {   // A(o, l) = dy[b][o][l]: consecutive threads walk l
+        const int o = m0 + m, l = k0 + k;
+        if (o < Cout && l < Lout) v = src[((size_t)outer * Cout + o) * Lout + l];
+      } else {           // A(m, c) = w[o][i][t]: consecutive threads walk the reduction channel
+        const int c = k0 + k;
+        const int o = MODE == 0 ? m0 + m : c, i = MODE == 0 ? c : m0 + m;
+        if (o < Cout && i < Cin) v = w[((size_t)o * Cin + i) * K + outer];
       }
-      // ---- B tile [16 k][64 n] -> Bs[k][n] ----
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        float v = 0.f;
-        if (MODE == 0) {          // B(i, l) = x[b][i][l*S + t - P]
-          const int n = tid & 63, k = (tid >> 6) + 4 * p, i = k0 + k, l = n0 + n, pos = l * S + outer - P;
-          if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = src[((size_t)z * Cin + i) * Lin + pos];
-          Bs[k][n] = v;
-        } else if (MODE == 1) {   // B(o, m) = dy[b][o][(m + P - t) / S]
-          const int n = tid & 63, k = (tid >> 6) + 4 * p, o = k0 + k, mpos = n0 + n, u = mpos + P - outer;
-          if (o < Cout && mpos < Lin && u >= 0 && (S == 1 || u % S == 0)) {
-            const int l = S == 1 ? u : u / S;
-            if (l < Lout) v = src[((size_t)z * Cout + o) * Lout + l];
-          }
-          Bs[k][n] = v;
-        } else {                  // B(l, i) = x[b][i][l*S + t - P]: consecutive threads walk l
-          const int k = tid & 15, n = (tid >> 4) + 16 * p, l = k0 + k, i = n0 + n, pos = l * S + z - P;
-          if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = w[((size_t)outer * Cin + i) * Lin + pos];   // (w carries x in MODE 2)
-          Bs[k][n] = v;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int sx = 0; sx < 8; ++sx)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * sx + g][32 * wm + i32], Bs[2 * sx + g][32 * wn + i32], acc, 0, 0, 0);
-      __syncthreads();
+      ra[p] = v;
     }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float v = 0.f;
+      if (MODE == 0) {          // B(i, l) = x[b][i][l*S + t - P]
+        const int n = tid & 63, k = (tid >> 6) + 4 * p, i = k0 + k, l = n0 + n, pos = l * S + outer - P;
+        if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = src[((size_t)z * Cin + i) * Lin + pos];
+      } else if (MODE == 1) {   // B(o, m) = dy[b][o][(m + P - t) / S]
+        const int n = tid & 63, k = (tid >> 6) + 4 * p, o = k0 + k, mpos = n0 + n, u = mpos + P - outer;
+        if (o < Cout && mpos < Lin && u >= 0 && (S == 1 || u % S == 0)) {
+          const int l = S == 1 ? u : u / S;
+          if (l < Lout) v = src[((size_t)z * Cout + o) * Lout + l];
+        }
+      } else {                  // B(l, i) = x[b][i][l*S + t - P]: consecutive threads walk l   (w carries x in MODE 2)
+        const int k = tid & 15, n = (tid >> 4) + 16 * p, l = k0 + k, i = n0 + n, pos = l * S + z - P;
+        if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = w[((size_t)outer * Cin + i) * Lin + pos];
+      }
+      rb[p] = v;
+    }
+  };
+  float ra[4], rb[4];
+  if (n_it > 0) fetch(0, ra, rb);
+  for (int it = 0; it < n_it; ++it) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      As[tid & 15][(tid >> 4) + 16 * p] = ra[p];
+      if (MODE == 2) Bs[tid & 15][(tid >> 4) + 16 * p] = rb[p];
+      else Bs[(tid >> 6) + 4 * p][tid & 63] = rb[p];
+    }
+    __syncthreads();
+    if (it + 1 < n_it) fetch(it + 1, ra, rb);
+#pragma unroll
+    for (int sx = 0; sx < 8; ++sx)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * sx + g][32 * wm + i32], Bs[2 * sx + g][32 * wn + i32], acc, 0, 0, 0);
+    __syncthreads();
   }
   // C/D layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int n = n0 + 32 * wn + i32;
