@@ -110,6 +110,12 @@ const char* ldc_version(void);
 int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out);
 int ldc_destroy(ldc_ctx* ctx);
 
+/* Per-context run-time options (instead of environment variables read at ldc_create): "split" = independent chains a batch is
+ * decoded as (1..4, default 2; the reference has no counterpart: utterances never interact inside the UNet), "lstm_stream" =
+ * 1: never use the cooperative (co-resident workgroups) LSTM kernel, "side_streams" = 1: res_conv on a side stream (split 1
+ * only).  Cached plans and graphs are dropped when a value changes. */
+int ldc_set_option(ldc_ctx* ctx, const char* name, int value);
+
 /* Device-drawn noise (noise == NULL): Philox4x32-10 keyed by (noise_seed, call counter); every sampler call that
  * draws advances the counter, as every torch.randn_like of the reference (ddpm_loss.py:249) advances the global
  * generator.  ldc_reseed sets the seed and rewinds the counter (the counterpart of torch.manual_seed). */
@@ -212,6 +218,16 @@ int ldc_resample(ldc_ctx* ctx, const float* wav, int C, int64_t T, int orig_freq
  * diffusion.q_sample(x_start, t, noise) (ddpm_loss.py:386-392); t [B] int64 (device). */
 int ldc_train_q_sample(ldc_ctx* ctx, const float* x_start, const int64_t* t, const float* noise, int B, int C, int L, float* x_t,
                        void* stream);
+/* Number of diffusion timesteps T of the loaded schedule (len(diffusion.betas)); device-side t is clamped to [0, T). */
+int ldc_train_num_timesteps(ldc_ctx* ctx);
+/* predicted_x_start of p_losses (ddpm_loss.py:416-420 -> :175-179, no clamp): x0 = sqrt(1/abar_t) x_t - sqrt(1/abar_t - 1) eps. */
+int ldc_train_predict_x_start(ldc_ctx* ctx, const float* x_t, const float* eps, const int64_t* t, int B, int C, int L, float* x0_out,
+                              void* stream);
+/* Monitoring loss of DiffAudioRep.forward (model.py:194): per item clamp(-SD-SDR(est, tgt), min clip_min) -- ClippedSDR
+ * (losses_fn.py:56-66) over asteroid 0.6.0's MultiSrcNegSDR("sdsdr"), one source; the reference calls it as (x, x_hat). */
+int ldc_train_neg_sdsdr(ldc_ctx* ctx, const float* est, const float* tgt, int B, int64_t n_per_item, float clip_min, float* per_item_out,
+                        void* stream);
+
 /* The objective of p_losses (ddpm_loss.py:434-438, loss_type l1): loss = mean_b(p2_loss_weight[t_b] * mean_{c,l}|out - target|);
  * loss_out [1]; grad_out (nullable) = d loss / d model_out. */
 int ldc_train_l1_loss(ldc_ctx* ctx, const float* model_out, const float* target, const int64_t* t, int B, int C, int L, float* loss_out,
@@ -306,16 +322,17 @@ int ldc_profile_enable(ldc_ctx* ctx, int on);
  * clock at its first and last kernel.  ldc_timeline_read: ticks[2j], ticks[2j+1] = begin / end of step j of `part`. */
 int ldc_timeline_enable(ldc_ctx* ctx, int on);
 int ldc_timeline_read(ldc_ctx* ctx, int part, int n, uint64_t* ticks);
-/* Tuning aid: times `iters` launches of one conv-GEMM (random weights/inputs) of the given shape with
- * hipEvents on the context's stream; dtype LDC_F32 | LDC_BF16; ups = 1 folds nearest x2 upsampling. */
 /* Tuning aid: times the GroupNorm-apply kernel on [B,L,C] (random data, fixed statistics). */
 int ldc_gn_microbench(ldc_ctx* ctx, int dtype, int B, int L, int C, int with_residual, int iters, double* ms_per_launch);
+/* Tuning aid: times `iters` launches of one conv-GEMM (random weights/inputs) of the given shape with
+ * hipEvents on the context's stream; dtype LDC_F32 | LDC_BF16; ups = 1 folds nearest x2 upsampling. */
 int ldc_conv_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups,
                         int iters, double* ms_per_launch);
-/* Tuning aid: times one strip-form ResnetBlock half (Conv1d k=3 + GroupNorm + scale/shift + SiLU, optionally followed by the
- * 1x1 res_conv on the same accumulators; conv_strip.inc) on pseudo-random data. */
-int ldc_strip_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int with_res, int iters,
-                         double* ms_per_launch);
+/* Self-check: the same layer and pseudo-random operands through the pipelined conv-GEMM with tile shape `tile_cfg` forced
+ * (-1: the launcher's choice) and through the generic kernel; largest output difference, largest |output|, largest relative
+ * difference of the fused GroupNorm statistics / column maxima. */
+int ldc_conv_compare(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups, int tile_cfg,
+                     int with_gn, int with_colmax, int with_residual, double* max_abs_diff, double* max_abs_ref, double* max_rel_stat);
 int ldc_profile_read(ldc_ctx* ctx, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
 /* Per kernel class (LDC_CLASS_*) totals of the same profiling pass: event-timed milliseconds, launches, algorithmic
  * flops and algorithmic HBM bytes; arrays of n >= LDC_N_CLASSES entries (any may be NULL). */

@@ -143,24 +143,36 @@ class Bitstream:
 
     # ---- container: compress.py:28-84 / 87-156 with use_lm = False (plain packing) or a static per-codebook model ----------
     def compress_codes(self, codes, audio_length: int, model_name: str = "ladiffcodec_16khz", bits: int = 10,
-                       static_cdf=None) -> tp.List[bytes]:
-        """codes [n_q, B, F] -> one ECDC byte string per utterance (header + payload)."""
+                       static_cdf=None, hop_length: int = 320) -> tp.List[bytes]:
+        """codes [n_q, B, F] -> one ECDC byte string per utterance (header + payload).
+
+        Header fields as compress.py:47-71 writes them; `lm` keeps the reference's meaning (payload arithmetic-coded with the
+        model's LM pdfs, compress.py:118-141), which this library never produces, so it is always false.  A payload coded with
+        a caller-supplied static per-codebook table says so in its own field `ac: "static"`; a reference decoder that meets
+        it reads `lm: false`, plain-unpacks and finds the stream too short instead of silently mis-decoding."""
         n_q, B, F = codes.shape
         if static_cdf is None:
             payloads = [bytes(r) for r in self.pack_codes(codes, bits).cpu().numpy()]
         else:
+            if static_cdf.shape[0] != n_q:
+                raise ValueError(f"static_cdf has {static_cdf.shape[0]} tables for {n_q} codebooks (symbol s uses table s % n_q)")
             sym = codes.permute(1, 2, 0).reshape(B, F * n_q)          # push order: t outer, k inner
             payloads = self.ac_encode(sym, static_cdf, static=True)
+        if -(-int(audio_length) // int(hop_length)) != F:
+            raise ValueError(f"audio_length {audio_length} does not give {F} frames at hop {hop_length}")
         out = []
         for b in range(B):
             fo = io.BytesIO()
-            write_ecdc_header(fo, {"m": model_name, "al": int(audio_length), "nc": int(n_q), "lm": static_cdf is not None})
+            meta = {"m": model_name, "al": int(audio_length), "nc": int(n_q), "lm": False, "hop": int(hop_length)}
+            if static_cdf is not None:
+                meta["ac"] = "static"
+            write_ecdc_header(fo, meta)
             fo.write(payloads[b])
             out.append(fo.getvalue())
         return out
 
-    def decompress_codes(self, blobs: tp.Sequence[bytes], F: int, bits: int = 10, static_cdf=None):
-        """-> (codes [n_q, B, F] int64, list of metadata)."""
+    def decompress_codes(self, blobs: tp.Sequence[bytes], F: tp.Optional[int] = None, bits: int = 10, static_cdf=None):
+        """-> (codes [n_q, B, F] int64, list of metadata).  F is derived from the header (`al`, `hop`) and, when given, must agree."""
         import numpy as np
         metas, payloads = [], []
         for blob in blobs:
@@ -170,6 +182,20 @@ class Bitstream:
         n_q = metas[0]["nc"]
         if any(m["nc"] != n_q for m in metas):
             raise ValueError("streams of one batch must share the number of codebooks")
+        for m in metas:
+            if m.get("lm"):
+                raise ValueError("stream is coded with a language model (lm: true): not produced nor decodable here")
+            mode = m.get("ac", "none")
+            if mode not in ("none", "static"):
+                raise ValueError(f"unknown entropy-coding mode {mode!r}")
+            if (mode == "static") != (static_cdf is not None):
+                raise ValueError("stream is static-table arithmetic-coded: pass the table it was coded with" if mode == "static"
+                                 else "stream is plainly packed: static_cdf must not be given")
+            frames = -(-int(m["al"]) // int(m.get("hop", 320)))
+            if F is None:
+                F = frames
+            if frames != F:
+                raise ValueError(f"header says {frames} frames (al {m['al']}), caller expects {F}")
         if static_cdf is None:
             width = max(len(p) for p in payloads)
             host = np.zeros((len(payloads), max(width, 1)), np.uint8)
@@ -178,5 +204,7 @@ class Bitstream:
             if min(len(p) for p in payloads) < int(self.lib.ldc_packed_bytes(n_q, F, bits)):
                 raise EOFError("The stream ended sooner than expected.")
             return self.unpack_codes(self.torch.from_numpy(host), n_q, F, bits), metas
+        if static_cdf.shape[0] != n_q:
+            raise ValueError(f"static_cdf has {static_cdf.shape[0]} tables for {n_q} codebooks")
         sym = self.ac_decode(payloads, F * n_q, static_cdf, static=True)
         return sym.reshape(len(payloads), F, n_q).permute(2, 0, 1).contiguous().to(self.torch.int64), metas

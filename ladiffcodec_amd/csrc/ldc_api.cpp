@@ -135,7 +135,6 @@ struct Codec {
 };
 
 struct ResnetW {
-  StripLayer s1, s2, sres;      // the same three convs packed for the strip kernel (conv_strip.inc)
   ConvLayer c1, c2, res;
   bool has_res = false;
   float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
@@ -256,8 +255,6 @@ struct ldc_ctx {
   unsigned long long flow_n = 0;
   int flow_depth = 8;           // LDC_FLOW_DEPTH (0 = unbounded look-ahead)
   int fuse_gn_stats = 1;
-  int strip_mode = 0;           // LDC_STRIP: 0 never (default: measured 5 % slower end to end) | 1 when the grid fills the chip | 2 whenever eligible
-  int strip_min_wgs = 96;       // LDC_STRIP_MIN: workgroups (items x strips) from which mode 1 picks the strip form
   // knobs read from the environment once, at ldc_create (per context, not process-global)
   ConvTune tune;
   int lstm_stream_only = 0;     // LDC_LSTM_STREAM: never use the cooperative LSTM
@@ -447,25 +444,6 @@ static int make_convtr(ldc_ctx* c, int dt, int cin, int cout, int stride, int tr
     for (int p = 0; p < stride; ++p)
       for (int co = 0; co < cout; ++co) b[(size_t)p * cout + co] = bias[co];
   LDCCHK(c->wmem.upload(&ly.bias, b));
-  *out = ly;
-  return LDC_OK;
-}
-
-static int make_strip(ldc_ctx* c, int dt, int cin, int cout, int taps, const float* w_oik, const float* bias, StripLayer* out) {
-  StripLayer ly;
-  ly.dt = dt; ly.cin = cin; ly.n = cout; ly.taps = taps;
-  const int che = 64 / (int)dt_size(dt);
-  if (cin % che || cout % 32) return LDC_OK;   // not packable: the plan never picks the strip form for it (ly.w stays null)
-  std::vector<char> packed(strip_packed_weight_bytes(dt, cin, cout, taps));
-  pack_strip_weights(dt, cin, cout, taps, w_oik, packed.data());
-  void* dw = nullptr;
-  LDCCHK(c->wmem.alloc(&dw, packed.size()));
-  HIPCHK(hipMemcpy(dw, packed.data(), packed.size(), hipMemcpyHostToDevice));
-  ly.w = dw;
-  if (bias) {
-    std::vector<float> b(bias, bias + cout);
-    LDCCHK(c->wmem.upload(&ly.bias, b));
-  }
   *out = ly;
   return LDC_OK;
 }
@@ -695,20 +673,17 @@ static int build_resnet(ldc_ctx* c, WeightReader& wr, const std::string& p, int 
   {
     std::vector<float> w = fold_weight_std(*w1);
     LDCCHK(make_conv(c, sp, w.data(), b1->data.data(), &r->c1));
-    LDCCHK(make_strip(c, c->dt, cin, cout, 3, w.data(), b1->data.data(), &r->s1));
   }
   {
     std::vector<float> w = fold_weight_std(*w2);
     ConvSpec s2 = sp;
     s2.cin1 = cout; s2.cin2 = 0;
     LDCCHK(make_conv(c, s2, w.data(), b2->data.data(), &r->c2));
-    LDCCHK(make_strip(c, c->dt, cout, cout, 3, w.data(), b2->data.data(), &r->s2));
   }
   if (r->has_res) {
     ConvSpec s3 = sp;
     s3.k = 1; s3.pad_left = 0;
     LDCCHK(make_conv(c, s3, wr_->data.data(), br_->data.data(), &r->res));
-    LDCCHK(make_strip(c, c->dt, cin, cout, 1, wr_->data.data(), br_->data.data(), &r->sres));
   }
   LDCCHK(c->wmem.upload(&r->g1, g1->data));
   LDCCHK(c->wmem.upload(&r->b1, be1->data));
@@ -972,8 +947,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->tune.sk_u3 = env_int("LDC_SK_U3", c->tune.sk_u3);
   c->tune.m_fastest = env_int("LDC_CONV_MFAST", c->tune.m_fastest);
   c->tune.debug = env_int("LDC_CONV_DEBUG", 0);
-  c->strip_mode = env_int("LDC_STRIP", 0);
-  c->strip_min_wgs = env_int("LDC_STRIP_MIN", 96);
+  c->tune.force_tile = env_int("LDC_TILE_CFG", -1);
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
   c->coop_launch = getenv("LDC_COOP_LAUNCH") ? 1 : 0;
   g_train_valu = getenv("LDC_TRAIN_VALU") ? 1 : 0;
@@ -1059,6 +1033,33 @@ extern "C" void ldc_quantize_e4m3(const float* in, int64_t n, uint8_t* out_codes
     if (out_codes) out_codes[i] = q;
     if (out_values) out_values[i] = host_e4m3_to_f32(q);
   }
+}
+
+// Per-context knobs that the host side used to pass through the process environment (mutating os.environ around
+// ldc_create changes every other engine created in that window).  "split": independent chains a batch is decoded as (1..4;
+// plans and graphs are cached per chain count, so it may change between calls); "lstm_stream": 1 = never take the cooperative
+// LSTM kernel (the streamed one needs no co-residency: the fallback after a device-side failure, or when several contexts or
+// processes share the device); "side_streams": 1 = res_conv on a side stream (single chain only).
+extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
+  if (!c || !name) return fail(LDC_E_INVALID, "null context or option name");
+  const std::string n(name);
+  if (n == "split") {
+    if (value < 1 || value > kMaxParts) return fail(LDC_E_INVALID, "split must be in 1..%d", kMaxParts);
+    if (value != c->split_batch) {
+      HIPCHK(hipSetDevice(c->device));
+      drop_plans(c);                 // plans of one shape differ by part size: start clean
+      c->split_batch = value;
+      if (value != 1) c->side_streams = 0;
+    }
+    return LDC_OK;
+  }
+  if (n == "lstm_stream") { c->lstm_stream_only = value ? 1 : 0; return LDC_OK; }
+  if (n == "side_streams") {
+    if (value && c->split_batch != 1) return fail(LDC_E_INVALID, "side streams need a single chain (split 1)");
+    if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
+    return LDC_OK;
+  }
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams)", name);
 }
 
 extern "C" int ldc_reseed(ldc_ctx* c, uint64_t seed) {
@@ -1514,53 +1515,6 @@ struct PlanBuilder {
     pl->conv_bytes += cbytes;
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out, LDC_CLASS_CONV, cbytes);
   }
-  // ResnetBlock as two strip launches (conv_strip.inc): conv1+GN+scale/shift+SiLU, then conv2+GN+SiLU+res_conv/identity
-  bool strip_ok(const ResnetW& r, int L) const {
-    if (c->strip_mode <= 0 || c->w8 || !r.s1.w || !r.s2.w || (r.has_res && !r.sres.w)) return false;
-    const int cin = r.cin1 + r.cin2;
-    if (!conv_strip_eligible(c->dt, r.cout, c->unet.groups, L, cin, 0)) return false;
-    if (!conv_strip_eligible(c->dt, r.cout, c->unet.groups, L, r.cout, r.has_res ? cin : 0)) return false;
-    if (c->strip_mode >= 2) return true;
-    const int cpg = r.cout / c->unet.groups;
-    return (long)B * (r.cout / std::max(32, cpg)) >= c->strip_min_wgs;
-  }
-  void* resnet_strip(const ResnetW& r, const void* x1, const void* x2, int L) {
-    const int rows = B * L;
-    const long long e = (long long)es;
-    void* h = act(rows, r.cout);
-    void* out = act(rows, r.cout);
-    const ResnetW* rp = &r;
-    const int cin = r.cin1 + r.cin2;
-    StripCall a;
-    a.conv = &rp->s1; a.x1 = x1; a.x2 = x2; a.C1 = r.cin1; a.C2 = r.cin2;
-    a.x1_rs = r.cin1 * e; a.x1_cs = 64; a.x2_rs = r.cin2 * e; a.x2_cs = 64;
-    a.gamma = r.g1; a.beta = r.b1; a.ss = pl->cur_ss + r.ss_off; a.groups = c->unet.groups;
-    a.y = h; a.y_rs = r.cout * e; a.y_cs = 64; a.B = B; a.L = L;
-    char buf[96];
-    snprintf(buf, sizeof(buf), "strip_k3_c%d+%d->%d_L%d_gn_ss", r.cin1, r.cin2, r.cout, L);
-    info = buf;
-    const double by1 = ((double)rows * (cin + r.cout)) * es + (double)strip_packed_weight_bytes(c->dt, cin, r.cout, 3);
-    pl->conv_bytes += by1;
-    add([a](hipStream_t s) { return launch_conv_strip(a, s); }, true, 2.0 * rows * r.cout * 3.0 * cin, LDC_CLASS_CONV, by1);
-    StripCall b;
-    b.conv = &rp->s2; b.x1 = h; b.C1 = r.cout; b.x1_rs = r.cout * e; b.x1_cs = 64;
-    b.gamma = r.g2; b.beta = r.b2; b.ss = nullptr; b.groups = c->unet.groups;
-    if (r.has_res) {
-      b.res = &rp->sres; b.r1 = x1; b.r2 = x2; b.RC1 = r.cin1; b.RC2 = r.cin2;
-      b.r1_rs = r.cin1 * e; b.r1_cs = 64; b.r2_rs = r.cin2 * e; b.r2_cs = 64;
-    } else {
-      b.res_id = x1; b.res_rs = r.cout * e; b.res_cs = 64;
-    }
-    b.y = out; b.y_rs = r.cout * e; b.y_cs = 64; b.B = B; b.L = L;
-    snprintf(buf, sizeof(buf), "strip_k3_c%d->%d_L%d_gn_%s", r.cout, r.cout, L, r.has_res ? "resconv" : "resid");
-    info = buf;
-    const double by2 = ((double)rows * (2 * r.cout + cin)) * es + (double)strip_packed_weight_bytes(c->dt, r.cout, r.cout, 3) +
-                       (r.has_res ? (double)strip_packed_weight_bytes(c->dt, cin, r.cout, 1) : 0.0);
-    pl->conv_bytes += by2;
-    add([b](hipStream_t s) { return launch_conv_strip(b, s); }, true, 2.0 * rows * r.cout * (3.0 * r.cout + (r.has_res ? cin : 0)),
-        LDC_CLASS_CONV, by2);
-    return out;
-  }
   float* next_stats() {
     const int g = c->unet.groups;
     return stats_pool + (size_t)(stats_used++) * B * g * kGnPad;
@@ -1572,7 +1526,6 @@ struct PlanBuilder {
     const int rows = B * L, dt = c->dt, g = c->unet.groups, Bn = B;
     const UnetW* u = &c->unet;
     const float* cur_ss = pl->cur_ss;
-    if (strip_ok(r, L)) return resnet_strip(r, x1, x2, L);
     void* a = act(rows, r.cout);
     void* b = act(rows, r.cout);
     void* d = act(rows, r.cout);
@@ -2451,7 +2404,28 @@ extern "C" int ldc_train_q_sample(ldc_ctx* c, const float* x0, const int64_t* t,
   LDCCHK(check_ready(c, LDC_MODEL_MAIN));
   if (!x0 || !t || !noise || !x_t || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
   hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_q_sample(x0, noise, t, c->sqrt_alphas_cumprod, c->sqrt_one_minus_alphas_cumprod, B, (int64_t)C * L, x_t, s));
+  HIPCHK(launch_q_sample(x0, noise, t, c->sqrt_alphas_cumprod, c->sqrt_one_minus_alphas_cumprod, B, (int64_t)C * L, x_t, c->unet.timesteps, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_num_timesteps(ldc_ctx* c) { return c ? c->unet.timesteps : 0; }
+
+extern "C" int ldc_train_predict_x_start(ldc_ctx* c, const float* x_t, const float* eps, const int64_t* t, int B, int C, int L, float* x0_out,
+                                         void* stream) {
+  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
+  if (!x_t || !eps || !t || !x0_out || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_predict_x_start(x_t, eps, t, c->sched.sqrt_recip_alphas_cumprod, c->sched.sqrt_recipm1_alphas_cumprod, B, (int64_t)C * L, x0_out,
+                                c->unet.timesteps, s));
+  return finish_stream(c, stream);
+}
+
+extern "C" int ldc_train_neg_sdsdr(ldc_ctx* c, const float* est, const float* tgt, int B, int64_t n_per_item, float clip_min, float* per_item_out,
+                                   void* stream) {
+  LDCCHK(check_dev(c));
+  if (!est || !tgt || !per_item_out || B < 1 || n_per_item < 1) return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_neg_sdsdr(est, tgt, B, n_per_item, clip_min, per_item_out, s));
   return finish_stream(c, stream);
 }
 
@@ -2462,7 +2436,7 @@ extern "C" int ldc_train_l1_loss(ldc_ctx* c, const float* model_out, const float
   hipStream_t s = pick_stream(c, stream);
   LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
     void* ws = ar.alloc(l1_loss_ws_bytes(B));
-    if (!dry) HIPCHK(launch_l1_loss(model_out, target, t, c->p2_loss_weight, B, (int64_t)C * L, loss_out, grad_out, ws, s));
+    if (!dry) HIPCHK(launch_l1_loss(model_out, target, t, c->p2_loss_weight, B, (int64_t)C * L, loss_out, grad_out, ws, c->unet.timesteps, s));
     return LDC_OK;
   }));
   return finish_stream(c, stream);
@@ -2884,6 +2858,26 @@ extern "C" int ldc_profile_read(ldc_ctx* c, double* conv_ms_total, int64_t* conv
 
 namespace ldc { extern unsigned long long* g_conv_stamps; }
 
+// uniform [-1, 1) values of the given dtype (host LCG, uploaded)
+static int fill_random(void* dev, size_t n, int dt, unsigned seed) {
+  const size_t es = dt_size(dt);
+  std::vector<char> h(n * es);
+  for (size_t i = 0; i < n; ++i) {
+    seed = seed * 1664525u + 1013904223u;
+    const float v = ((seed >> 8) * (1.0f / 8388608.0f)) - 1.0f;
+    if (dt == DT_F32) {
+      reinterpret_cast<float*>(h.data())[i] = v;
+    } else {
+      uint32_t u;
+      memcpy(&u, &v, 4);
+      reinterpret_cast<uint16_t*>(h.data())[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+  }
+  HIPCHK(hipMemcpy(dev, h.data(), h.size(), hipMemcpyHostToDevice));
+  return LDC_OK;
+}
+
+
 extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride,
                                    int ups, int iters, double* ms_per_launch) {
   if (!c || !ms_per_launch || iters < 1) return fail(LDC_E_INVALID, "bad arguments");
@@ -2911,8 +2905,9 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
   LDCCHK(keep.alloc(&x1, (size_t)B * L * cin1 * es));
   if (cin2) LDCCHK(keep.alloc(&x2, (size_t)B * L * cin2 * es));
   LDCCHK(keep.alloc(&y, (size_t)B * L_out * cout * es));
-  HIPCHK(hipMemset(x1, 0x3c, (size_t)B * L * cin1 * es));     // 0x3c3c.. is a small normal number in bf16 and f32
-  if (cin2) HIPCHK(hipMemset(x2, 0x3c, (size_t)B * L * cin2 * es));
+  // full-range pseudo-random operands: constant or zero fills let the chip clock ~15-20 % higher than real data does
+  LDCCHK(fill_random(x1, (size_t)B * L * cin1, dt, 777u));
+  if (cin2) LDCCHK(fill_random(x2, (size_t)B * L * cin2, dt, 778u));
   ConvCall cc;
   cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.y_ld = cout;
   {   // split-K workspace as the plan builder provides it
@@ -2964,88 +2959,108 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
   return LDC_OK;
 }
 
-// Tuning aid: one ResnetBlock-half in strip form (conv k3 + GN + SiLU [+ 1x1 res_conv]) on random data.
-extern "C" int ldc_strip_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1, int cin2, int cout, int with_res, int iters,
-                                    double* ms_per_launch) {
-  if (!c || !ms_per_launch || iters < 1) return fail(LDC_E_INVALID, "bad arguments");
+// Self-check of the pipelined conv-GEMM: the same layer and pseudo-random operands through conv_fast.inc with tile shape
+// `tile_cfg` forced (-1: the launcher's own choice) and through the generic kernel (conv_gemm.hip, itself pinned to the
+// reference's SConv1d vectors); reports the largest output difference, the largest |reference output|, and the largest relative
+// difference of the fused GroupNorm statistics (with_gn) / the fused column maxima (with_colmax).
+extern "C" int ldc_conv_compare(ldc_ctx* c, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups,
+                                int tile_cfg, int with_gn, int with_colmax, int with_residual, double* max_abs_diff, double* max_abs_ref,
+                                double* max_rel_stat) {
+  if (!c || !max_abs_diff || !max_abs_ref || !max_rel_stat) return fail(LDC_E_INVALID, "bad arguments");
   HIPCHK(hipSetDevice(c->device));
-  const int dt = dtype == LDC_BF16 ? DT_BF16 : DT_F32;
-  const int cin = cin1 + cin2, g = 8;
-  if (!conv_strip_eligible(dt, cout, g, L, cin, 0) || (with_res && !conv_strip_eligible(dt, cout, g, L, cin, cin)))
-    return fail(LDC_E_INVALID, "shape not eligible for the strip kernel");
-  std::vector<float> w((size_t)cout * cin * 3), wr((size_t)cout * cin), bias(cout, 0.1f), gam(cout, 1.0f), bet(cout, 0.05f), ss(2 * cout, 0.1f);
-  unsigned seed = 12345u;
-  for (auto& v : w) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f; }
-  for (auto& v : wr) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f; }
+  const int dt = dtype == LDC_F32 ? DT_F32 : DT_BF16;
+  const bool saved_w8 = c->w8;
+  c->w8 = dtype == LDC_BF16_W8;
+  const int cin = cin1 + cin2;
+  std::vector<float> w((size_t)cout * cin * k), bias(cout);
+  unsigned seed = 4242u;
+  for (auto& v : w) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.2f; }
+  for (auto& v : bias) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f); }
   DevMem keep;
   std::swap(keep.ptrs, c->wmem.ptrs);
-  StripLayer s1, sr;
-  int rc = make_strip(c, dt, cin, cout, 3, w.data(), bias.data(), &s1);
-  if (rc == LDC_OK && with_res) rc = make_strip(c, dt, cin, cout, 1, wr.data(), bias.data(), &sr);
+  ConvLayer ly;
+  ConvSpec sp;
+  sp.dt = dt; sp.cin1 = cin1; sp.cin2 = cin2; sp.cout = cout; sp.k = k; sp.stride = stride; sp.ups = ups;
+  sp.pad_left = (k == 4 && stride == 2) ? 1 : (k - 1) / 2;
+  int rc = make_conv(c, sp, w.data(), bias.data(), &ly);
   std::swap(keep.ptrs, c->wmem.ptrs);
+  c->w8 = saved_w8;
   LDCCHK(rc);
+  const int L_out = ups ? 2 * L : (stride == 2 ? (L + 2 * sp.pad_left - k) / 2 + 1 : L);
   const size_t es = dt_size(dt);
-  void *x1 = nullptr, *x2 = nullptr, *y = nullptr;
-  float *dg = nullptr, *db = nullptr, *dss = nullptr;
+  const int groups = 8;
+  const size_t n_out = (size_t)B * L_out * cout, stat_n = (size_t)B * groups * kGnPad, cm_n = (size_t)B * cout;
+  void *x1 = nullptr, *x2 = nullptr, *res = nullptr, *y[2] = {nullptr, nullptr}, *st[2] = {nullptr, nullptr}, *cm[2] = {nullptr, nullptr};
   LDCCHK(keep.alloc(&x1, (size_t)B * L * cin1 * es));
-  if (cin2) LDCCHK(keep.alloc(&x2, (size_t)B * L * cin2 * es));
-  LDCCHK(keep.alloc(&y, (size_t)B * L * cout * es));
-  LDCCHK(keep.upload(&dg, gam)); LDCCHK(keep.upload(&db, bet)); LDCCHK(keep.upload(&dss, ss));
-  {   // pseudo-random activations (a constant fill would flatter the clock: guide rule 25)
-    std::vector<unsigned short> hx((size_t)B * L * std::max(cin1, cin2) * (es / 2));
-    for (auto& v : hx) { seed = seed * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((seed >> 20) & 0x3ffu) + ((seed >> 3) & 0x8000u)); }
-    HIPCHK(hipMemcpy(x1, hx.data(), (size_t)B * L * cin1 * es, hipMemcpyHostToDevice));
-    if (cin2) HIPCHK(hipMemcpy(x2, hx.data(), (size_t)B * L * cin2 * es, hipMemcpyHostToDevice));
+  LDCCHK(fill_random(x1, (size_t)B * L * cin1, dt, 901u));
+  if (cin2) {
+    LDCCHK(keep.alloc(&x2, (size_t)B * L * cin2 * es));
+    LDCCHK(fill_random(x2, (size_t)B * L * cin2, dt, 902u));
   }
-  StripCall sc;
-  sc.conv = &s1; sc.x1 = x1; sc.x2 = x2; sc.C1 = cin1; sc.C2 = cin2;
-  sc.x1_rs = (long long)cin1 * es; sc.x1_cs = 64; sc.x2_rs = (long long)cin2 * es; sc.x2_cs = 64;
-  sc.gamma = dg; sc.beta = db; sc.ss = dss; sc.groups = g;
-  if (with_res) {
-    sc.res = &sr; sc.r1 = x1; sc.r2 = x2; sc.RC1 = cin1; sc.RC2 = cin2;
-    sc.r1_rs = sc.x1_rs; sc.r1_cs = 64; sc.r2_rs = sc.x2_rs; sc.r2_cs = 64;
+  if (with_residual) {
+    LDCCHK(keep.alloc(&res, n_out * es));
+    LDCCHK(fill_random(res, n_out, dt, 903u));
   }
-  sc.y = y; sc.y_rs = (long long)cout * es; sc.y_cs = 64; sc.B = B; sc.L = L;
-  sc.debug = getenv("LDC_STRIP_DEBUG") ? atoi(getenv("LDC_STRIP_DEBUG")) : 0;
-  if (getenv("LDC_STRIP_PLANES")) {   // plane-major operands [chunk][row][64 B] (timing experiment: contents do not matter)
-    sc.x1_rs = 64; sc.x1_cs = (long long)B * L * 64; sc.x2_rs = 64; sc.x2_cs = (long long)B * L * 64;
-    sc.r1_rs = 64; sc.r1_cs = sc.x1_cs; sc.r2_rs = 64; sc.r2_cs = sc.x1_cs;
-    sc.y_rs = 64; sc.y_cs = (long long)B * L * 64;
-  }
+  void *part = nullptr, *cnt = nullptr;
+  LDCCHK(keep.alloc(&part, (size_t)(8 << 20) * 4));
+  LDCCHK(keep.alloc(&cnt, 1024 * 4));
+  HIPCHK(hipMemset(cnt, 0, 1024 * 4));
   hipStream_t s = c->own_stream;
-  for (int i = 0; i < 3; ++i) HIPCHK(launch_conv_strip(sc, s));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) HIPCHK(launch_conv_strip(sc, s));
-  HIPCHK(hipEventRecord(e1, s));
-  HIPCHK(hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  *ms_per_launch = ms / iters;
-  if (getenv("LDC_CONV_STAMPS")) {
-    const int nblk = B * 64;
-    void* st = nullptr;
-    LDCCHK(keep.alloc(&st, (size_t)nblk * 8 * 8));
-    HIPCHK(hipMemset(st, 0, (size_t)nblk * 8 * 8));
-    sc.stamps = (unsigned long long*)st;
-    HIPCHK(launch_conv_strip(sc, s));
-    HIPCHK(hipStreamSynchronize(s));
-    std::vector<unsigned long long> h((size_t)nblk * 8);
-    HIPCHK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
-    double d[5] = {0, 0, 0, 0, 0};
-    unsigned long long tmin = ~0ull, tmax = 0;
-    int n = 0;
-    for (int b = 0; b < nblk; ++b) {
-      if (!h[8 * b + 5]) continue;
-      for (int k = 0; k < 5; ++k) d[k] += (double)(h[8 * b + k + 1] - h[8 * b + k]);
-      tmin = std::min(tmin, h[8 * b]); tmax = std::max(tmax, h[8 * b + 5]);
-      ++n;
-    }
-    if (n) fprintf(stderr, "  stamps (s_memtime ticks per workgroup, %d WGs): prologue %.0f  conv loop %.0f  GN+SiLU %.0f  res loop %.0f  store %.0f | first start -> last end %.0f\n",
-                   n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, (double)(tmax - tmin));
+  ConvTune tune = c->tune;
+  for (int v = 0; v < 2; ++v) {
+    LDCCHK(keep.alloc(&y[v], n_out * es));
+    LDCCHK(keep.alloc(&st[v], stat_n * 4));
+    LDCCHK(keep.alloc(&cm[v], cm_n * 4));
+    HIPCHK(hipMemset(y[v], 0, n_out * es));
+    HIPCHK(hipMemset(st[v], 0, stat_n * 4));
+    HIPCHK(hipMemset(cm[v], 0, cm_n * 4));
+    tune.force_generic = v == 0 ? 1 : 0;
+    tune.force_tile = tile_cfg;
+    ConvCall cc;
+    cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y[v]; cc.y_ld = cout; cc.residual = res;
+    if (with_gn) { cc.gn_sum = (float*)st[v]; cc.gn_groups = groups; }
+    if (with_colmax) { cc.colmax = (unsigned*)cm[v]; cc.colmax_lo = 0; cc.colmax_hi = cout; cc.colmax_stride = cout; }
+    cc.sk_part = (float*)part; cc.sk_part_cap = (long long)8 << 20; cc.sk_count = (unsigned*)cnt; cc.sk_count_cap = 1024;
+    cc.tune = &tune;
+    HIPCHK(launch_conv(ly, cc, s));
   }
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<char> h0(n_out * es), h1(n_out * es);
+  HIPCHK(hipMemcpy(h0.data(), y[0], h0.size(), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(h1.data(), y[1], h1.size(), hipMemcpyDeviceToHost));
+  auto val = [&](const std::vector<char>& h, size_t i) {
+    if (dt == DT_F32) return (double)reinterpret_cast<const float*>(h.data())[i];
+    const uint32_t u = (uint32_t)reinterpret_cast<const uint16_t*>(h.data())[i] << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return (double)f;
+  };
+  double d = 0, m = 0;
+  for (size_t i = 0; i < n_out; ++i) {
+    const double a = val(h0, i), b = val(h1, i);
+    if (!(b == b)) { d = 1e30; break; }
+    d = std::max(d, fabs(a - b));
+    m = std::max(m, fabs(a));
+  }
+  *max_abs_diff = d;
+  *max_abs_ref = m;
+  double rs = 0;
+  if (with_gn) {
+    std::vector<float> s0(stat_n), s1(stat_n);
+    HIPCHK(hipMemcpy(s0.data(), st[0], stat_n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s1.data(), st[1], stat_n * 4, hipMemcpyDeviceToHost));
+    double smax = 0;
+    for (size_t i = 0; i < stat_n; ++i) smax = std::max(smax, (double)fabsf(s0[i]));
+    for (size_t i = 0; i < stat_n; ++i) rs = std::max(rs, fabs((double)s0[i] - s1[i]) / (smax + 1e-30));
+  }
+  if (with_colmax) {
+    std::vector<unsigned> c0(cm_n), c1(cm_n);
+    HIPCHK(hipMemcpy(c0.data(), cm[0], cm_n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c1.data(), cm[1], cm_n * 4, hipMemcpyDeviceToHost));
+    auto unkey = [](unsigned kx) { const unsigned b = (kx & 0x80000000u) ? (kx & 0x7fffffffu) : ~kx; float f; memcpy(&f, &b, 4); return (double)f; };
+    for (size_t i = 0; i < cm_n; ++i) rs = std::max(rs, fabs(unkey(c0[i]) - unkey(c1[i])) / (m + 1e-30));
+  }
+  *max_rel_stat = rs;
   return LDC_OK;
 }
 

@@ -53,7 +53,8 @@ struct ConvTune {
   int splitk = 1;               // LDC_CONV_SPLITK: 0 off | 1 by layer | 2 | 3
   int sk_tiles = 200, sk_u2 = 24, sk_u3 = 60;   // LDC_SK_TILES / LDC_SK_U2 / LDC_SK_U3
   int m_fastest = 1;            // LDC_CONV_MFAST: 0 N-tile fastest | 1 by operand size | 2 M-tile fastest
-  int debug = 0;                // LDC_CONV_DEBUG
+  int debug = 0;                // LDC_CONV_DEBUG (bits, see conv_fast.inc)
+  int force_tile = -1;          // self-check / tuning: 0 = 64x64, 1 = 128x64, 2 = 128x128 tiles wherever the layer's N allows
 };
 
 struct ConvCall {
@@ -89,42 +90,6 @@ uint8_t host_f32_to_e4m3(float f);
 float host_e4m3_to_f32(uint8_t v);
 void pack_convtr_weights(const ConvLayer& ly, const float* w_iok, int cin, int cout, int stride, void* dst_host);
 int conv_pick_bn(int n);
-
-// ------------------------------------------------------------------------------------------------
-// conv_strip_{bf16,f32}.hip : ResnetBlock convs in "strip" form -- Conv1d(k=3, pad 1) + GroupNorm + timestep
-// scale/shift + SiLU (+ 1x1 res_conv / identity residual) in ONE launch, one workgroup per (item, group strip)
-// ------------------------------------------------------------------------------------------------
-struct StripLayer {
-  int dt = DT_F32;
-  int cin = 0, n = 0, taps = 3;
-  void* w = nullptr;          // pack_strip_weights image
-  float* bias = nullptr;      // [n] fp32
-};
-struct StripCall {
-  const StripLayer* conv = nullptr;   // the k=3 conv
-  const void* x1 = nullptr; const void* x2 = nullptr;   // its (concatenated) inputs
-  int C1 = 0, C2 = 0;
-  long long x1_rs = 0, x1_cs = 0, x2_rs = 0, x2_cs = 0; // byte strides: row / 64-byte channel chunk
-  const float* gamma = nullptr; const float* beta = nullptr;
-  const float* ss = nullptr;          // [2n] timestep scale | shift, or null
-  int groups = 8;
-  const StripLayer* res = nullptr;    // optional 1x1 res_conv over cat(r1, r2), added after the activation
-  const void* r1 = nullptr; const void* r2 = nullptr;
-  int RC1 = 0, RC2 = 0;
-  long long r1_rs = 0, r1_cs = 0, r2_rs = 0, r2_cs = 0;
-  const void* res_id = nullptr;       // optional identity residual [rows][n]
-  long long res_rs = 0, res_cs = 0;
-  void* y = nullptr;
-  long long y_rs = 0, y_cs = 0;
-  int B = 0, L = 0;
-  int debug = 0;                      // tuning aid, see conv_strip.inc
-  unsigned long long* stamps = nullptr;
-};
-// cin: channels of the k=3 conv's input, cres: of the res_conv's (0: none)
-bool conv_strip_eligible(int dt, int N, int groups, int L, int cin, int cres);
-hipError_t launch_conv_strip(const StripCall& sc, hipStream_t s);
-size_t strip_packed_weight_bytes(int dt, int cin, int n, int taps);
-void pack_strip_weights(int dt, int cin, int n, int taps, const float* w_oik, void* dst_host);
 
 // ------------------------------------------------------------------------------------------------
 // norm_act.hip
@@ -241,11 +206,16 @@ hipError_t launch_sqnorm_rows(const float* x, int rows, int D, float* out, hipSt
 // ------------------------------------------------------------------------------------------------
 // train.hip : first slice of the training step (q_sample, L1 objective, Block forward / backward), fp32, [B, C, L]
 // ------------------------------------------------------------------------------------------------
+// (T = number of timesteps: device-side t is clamped to [0, T) before it indexes a schedule table)
 hipError_t launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, int B,
-                           int64_t n_per_item, float* out, hipStream_t s);
+                           int64_t n_per_item, float* out, int T, hipStream_t s);
+hipError_t launch_predict_x_start(const float* x_t, const float* eps, const int64_t* t, const float* sqrt_recip_ac, const float* sqrt_recipm1_ac,
+                                  int B, int64_t n_per_item, float* out, int T, hipStream_t s);
+// per item: clamp(-SD-SDR(est, tgt), min clip_min)  (ClippedSDR over asteroid's MultiSrcNegSDR("sdsdr"), one source)
+hipError_t launch_neg_sdsdr(const float* est, const float* tgt, int B, int64_t n_per_item, float clip_min, float* per_item, hipStream_t s);
 size_t l1_loss_ws_bytes(int B);
 hipError_t launch_l1_loss(const float* pred, const float* target, const int64_t* t, const float* p2w, int B, int64_t n_per_item,
-                          float* loss, float* grad, void* ws, hipStream_t s);
+                          float* loss, float* grad, void* ws, int T, hipStream_t s);
 size_t train_block_ws_floats(int B, int Cin, int Cout, int L, int groups);
 hipError_t launch_train_pw_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int pre_silu, float* y,
                                    hipStream_t s);

@@ -29,19 +29,86 @@ namespace ldc {
 // ---------------------------------------------------------------------------------------------
 // q_sample and the L1 objective
 // ---------------------------------------------------------------------------------------------
+// t comes from device memory: an index outside [0, T) would read past the schedule tables, so it is clamped (the host entry
+// points refuse such t when they can see it; device-drawn t cannot be checked there)
+__device__ __forceinline__ int64_t clamp_t(int64_t t, int T) { return t < 0 ? 0 : (t >= T ? (int64_t)T - 1 : t); }
+
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* x0, const float* noise, const int64_t* t, const float* sa,
-                                                       const float* s1ma, int64_t n_per_item, float* out) {
+                                                       const float* s1ma, int64_t n_per_item, float* out, int T) {
   const int b = blockIdx.y;
-  const float a = sa[t[b]], c = s1ma[t[b]];
+  const int64_t tb = clamp_t(t[b], T);
+  const float a = sa[tb], c = s1ma[tb];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256) {
     const size_t k = (size_t)b * n_per_item + i;
     out[k] = a * x0[k] + c * noise[k];
   }
 }
 hipError_t launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, int B,
-                           int64_t n_per_item, float* out, hipStream_t s) {
+                           int64_t n_per_item, float* out, int T, hipStream_t s) {
   hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)std::min<int64_t>((n_per_item + 255) / 256, 256), B), dim3(256), 0, s, x0, noise, t,
-                     sqrt_ac, sqrt_1mac, n_per_item, out);
+                     sqrt_ac, sqrt_1mac, n_per_item, out, T);
+  return hipGetLastError();
+}
+
+// predicted_x_start of p_losses (ddpm_loss.py:416-420 -> model_predictions -> predict_start_from_noise, :175-179; no clamp on this
+// path: clip_x_start defaults to False): x0 = sqrt(1 / abar_t) x_t - sqrt(1 / abar_t - 1) eps, per item t
+__global__ __launch_bounds__(256) void predict_x_start_kernel(const float* x_t, const float* eps, const int64_t* t, const float* r,
+                                                              const float* rm1, int64_t n_per_item, float* out, int T) {
+  const int b = blockIdx.y;
+  const int64_t tb = clamp_t(t[b], T);
+  const float a = r[tb], c = rm1[tb];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256) {
+    const size_t k = (size_t)b * n_per_item + i;
+    out[k] = a * x_t[k] - c * eps[k];
+  }
+}
+hipError_t launch_predict_x_start(const float* x_t, const float* eps, const int64_t* t, const float* sqrt_recip_ac, const float* sqrt_recipm1_ac,
+                                  int B, int64_t n_per_item, float* out, int T, hipStream_t s) {
+  hipLaunchKernelGGL(predict_x_start_kernel, dim3((unsigned)std::min<int64_t>((n_per_item + 255) / 256, 256), B), dim3(256), 0, s, x_t, eps,
+                     t, sqrt_recip_ac, sqrt_recipm1_ac, n_per_item, out, T);
+  return hipGetLastError();
+}
+
+// The monitoring loss of DiffAudioRep.forward (model.py:194): ClippedSDR (losses_fn.py:56-66) = clamp(MultiSrcNegSDR("sdsdr"), min
+// -30) with est_targets = the clean input x and targets = x_hat (the reference passes them in this order).  asteroid 0.6.0's
+// published algorithm, one source per item: zero-mean both, s = <e, g> g / (|g|^2 + EPS), noise = e - g,
+// loss = -10 log10(|s|^2 / (|noise|^2 + EPS) + EPS), EPS = 1e-8.  One workgroup per item, double accumulators, two passes.
+__global__ __launch_bounds__(256) void neg_sdsdr_kernel(const float* est, const float* tgt, int64_t n, float clip_min, float* out) {
+  __shared__ double red[4][4];
+  const int b = blockIdx.x;
+  const float* e = est + (size_t)b * n;
+  const float* g = tgt + (size_t)b * n;
+  auto reduce4 = [&](double& v0, double& v1, double& v2, double& v3) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); v2 += __shfl_xor(v2, o); v3 += __shfl_xor(v3, o); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = v0; red[threadIdx.x >> 6][1] = v1; red[threadIdx.x >> 6][2] = v2; red[threadIdx.x >> 6][3] = v3; }
+    __syncthreads();
+    v0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    v1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    v2 = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+    v3 = (red[0][3] + red[1][3]) + (red[2][3] + red[3][3]);
+  };
+  double se = 0, sg = 0, z0 = 0, z1 = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) { se += e[i]; sg += g[i]; }
+  reduce4(se, sg, z0, z1);
+  const double me = se / (double)n, mg = sg / (double)n;
+  double dot = 0, eg = 0, en = 0, z = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const double a = (double)e[i] - me, c = (double)g[i] - mg;
+    dot += a * c; eg += c * c; en += (a - c) * (a - c);
+  }
+  reduce4(dot, eg, en, z);
+  if (threadIdx.x == 0) {
+    const double eps = 1e-8;
+    const double k = dot / (eg + eps);                 // scaled target = k * g: |s|^2 = k^2 |g|^2
+    const double ratio = k * k * eg / (en + eps);
+    const double loss = -10.0 * log10(ratio + eps);
+    out[b] = fmaxf((float)loss, clip_min);
+  }
+}
+hipError_t launch_neg_sdsdr(const float* est, const float* tgt, int B, int64_t n_per_item, float clip_min, float* per_item, hipStream_t s) {
+  hipLaunchKernelGGL(neg_sdsdr_kernel, dim3(B), dim3(256), 0, s, est, tgt, n_per_item, clip_min, per_item);
   return hipGetLastError();
 }
 
@@ -58,20 +125,20 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* pred, cons
   __syncthreads();
   if (threadIdx.x == 0) part[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ void l1_final_kernel(const double* part, int nblk, int B, int64_t n_per_item, const int64_t* t, const float* p2w, float* loss) {
+__global__ void l1_final_kernel(const double* part, int nblk, int B, int64_t n_per_item, const int64_t* t, const float* p2w, float* loss, int T) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double tot = 0.0;
   for (int b = 0; b < B; ++b) {
     double s = 0.0;
     for (int k = 0; k < nblk; ++k) s += part[(size_t)b * nblk + k];
-    tot += (double)(float)(s / (double)n_per_item) * (double)p2w[t[b]];
+    tot += (double)(float)(s / (double)n_per_item) * (double)p2w[clamp_t(t[b], T)];
   }
   loss[0] = (float)(tot / (double)B);
 }
 __global__ __launch_bounds__(256) void l1_grad_kernel(const float* pred, const float* target, const int64_t* t, const float* p2w,
-                                                      int B, int64_t n_per_item, float* grad) {
+                                                      int B, int64_t n_per_item, float* grad, int T) {
   const int b = blockIdx.y;
-  const float w = p2w[t[b]] / ((float)n_per_item * (float)B);
+  const float w = p2w[clamp_t(t[b], T)] / ((float)n_per_item * (float)B);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per_item; i += (int64_t)gridDim.x * 256) {
     const size_t k = (size_t)b * n_per_item + i;
     const float d = pred[k] - target[k];
@@ -80,11 +147,11 @@ __global__ __launch_bounds__(256) void l1_grad_kernel(const float* pred, const f
 }
 size_t l1_loss_ws_bytes(int B) { return (size_t)B * 64 * sizeof(double); }
 hipError_t launch_l1_loss(const float* pred, const float* target, const int64_t* t, const float* p2w, int B, int64_t n_per_item,
-                          float* loss, float* grad, void* ws, hipStream_t s) {
+                          float* loss, float* grad, void* ws, int T, hipStream_t s) {
   const int nblk = (int)std::min<int64_t>((n_per_item + 255) / 256, 64);
   hipLaunchKernelGGL(l1_partial_kernel, dim3(nblk, B), dim3(256), 0, s, pred, target, n_per_item, (double*)ws);
-  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, nblk, B, n_per_item, t, p2w, loss);
-  if (grad) hipLaunchKernelGGL(l1_grad_kernel, dim3(nblk, B), dim3(256), 0, s, pred, target, t, p2w, B, n_per_item, grad);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, nblk, B, n_per_item, t, p2w, loss, T);
+  if (grad) hipLaunchKernelGGL(l1_grad_kernel, dim3(nblk, B), dim3(256), 0, s, pred, target, t, p2w, B, n_per_item, grad, T);
   return hipGetLastError();
 }
 

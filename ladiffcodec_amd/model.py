@@ -70,6 +70,10 @@ class Engine:
         self.stream = torch.cuda.Stream(device=self.device)
         self._finalized = False
 
+    def set_option(self, name: str, value: int) -> None:
+        """ldc_set_option: 'split' (chains per batch), 'lstm_stream' (no cooperative LSTM), 'side_streams'."""
+        L.check(self.lib.ldc_set_option(self._ctx, name.encode(), int(value)))
+
     def reseed(self, seed: int) -> None:
         """torch.manual_seed counterpart for the device-drawn noise: sets the Philox seed and rewinds the call counter."""
         L.check(self.lib.ldc_reseed(self._ctx, int(seed)))

@@ -156,23 +156,36 @@ def synthesis(inp_args) -> List[str]:
     n_eng = max(1, int(getattr(inp_args, "in_flight", 1)))
     if len(files) <= inp_args.batch_size * world:        # a single batch per rank: nothing to pipeline
         n_eng = 1
-    had_env = os.environ.get("LDC_NO_SPLIT")
-    if n_eng > 1:
-        os.environ["LDC_NO_SPLIT"] = "1"                  # read at ldc_create: with batches in flight each batch is one chain
     sd_main, sd_cond = checkpoint.read_amlt(inp_args.model_path), checkpoint.read_amlt(inp_args.model_for_cond)
     engines = []
     for k in range(n_eng):
         eng = Engine(main_codec, unet, cond_codec, dtype=inp_args.dtype, device=local_rank, noise_seed=inp_args.seed + rank + 7919 * k)
-        eng.load_state_dict(L.MODEL_MAIN, sd_main)       # load_model(model, path, strict=True)
-        eng.load_state_dict(L.MODEL_COND, sd_cond)
+        if n_eng > 1:
+            eng.set_option("split", 1)                   # with batches in flight each batch is one chain (a per-context option,
+        eng.load_state_dict(L.MODEL_MAIN, sd_main)       # not an environment variable: other engines of the process keep theirs)
+        eng.load_state_dict(L.MODEL_COND, sd_cond)       # load_model(model, path, strict=True)
         eng.finalize(strict=True)
         engines.append(eng)
-    if n_eng > 1 and had_env is None:
-        os.environ.pop("LDC_NO_SPLIT", None)
     written = decode_files(engines if n_eng > 1 else engines[0], files, inp_args, rank, world, local_rank)
     for eng in engines:
         eng.close()
     return written
+
+
+def decode_with_retry(eng, batch, n_steps: int, noise, per_item: bool):
+    """One engine call.  The cond codec's LSTM runs as co-resident workgroups exchanging h through memory (seanet.hip); when
+    other work on the device keeps them from being co-resident its bounded spin gives up, poisons the output and raises the
+    context's device-side failure flag (LDC_E_HIP).  That batch is then decoded again on the streamed LSTM kernel, which needs
+    no co-residency, and the engine stays on it."""
+    from . import lib as L
+    try:
+        out = eng.decode(batch, n_steps, noise=noise, per_item=per_item)
+        return out
+    except L.LdcError as e:
+        if "device-side failure" not in str(e):
+            raise
+        eng.set_option("lstm_stream", 1)
+        return eng.decode(batch, n_steps, noise=noise, per_item=per_item)
 
 
 def plan_batches(lengths: List[int], channels: List[int], rank: int, world: int, batch_size: int) -> List[Tuple[List[int], bool]]:
@@ -275,15 +288,22 @@ def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_r
     written = []
     dev = torch.device("cuda", local_rank)
     streams = [torch.cuda.Stream(device=dev) for _ in engines] if len(engines) > 1 else [None]
-    pending: List[tuple] = []                 # (output tensor on the device, file indices, joint, stream), oldest first
+    pending: List[tuple] = []                 # (output tensor on the device, file indices, joint, stream, redo), oldest first
+    hop = int(np.prod(getattr(inp_args, "enc_ratios", [8])))   # samples per latent frame of the main codec (noise seam only)
 
     def retire(item):
-        out, idxs, joint, stream = item
+        out, idxs, joint, stream, redo = item
         if stream is not None:
             stream.synchronize()               # the producer stream, not the current one: waits for that engine's batch only
         out = out.cpu()
         if not bool(torch.isfinite(out).all()):
-            raise RuntimeError(f"non-finite audio decoded for {[files[i] for i in idxs]}")
+            # the device-side failure of this batch (cooperative LSTM timed out: its output is poisoned with NaN) is reported by
+            # the engine's NEXT call; decode the batch again on the streamed LSTM instead of losing the run
+            eng_k, batch_k, per_item_k, noise_k = redo
+            eng_k.set_option("lstm_stream", 1)
+            out = eng_k.decode(batch_k.to(dev), inp_args.midway_t, noise=noise_k, per_item=per_item_k).cpu()
+            if not bool(torch.isfinite(out).all()):
+                raise RuntimeError(f"non-finite audio decoded for {[files[i] for i in idxs]}")
         out = out.numpy()
         for k, i in enumerate(idxs):
             path = output_path(files[i], inp_args.input_dir, inp_args.output_dir)
@@ -301,12 +321,15 @@ def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_r
         slot = j % len(engines)
         if len(pending) >= len(engines):
             retire(pending.pop(0))             # the batch this engine decoded last: its output is read before the slot is reused
+        # test seam: a callable (file indices, steps, latent length) -> noise [steps, B, 128, L] replaces the device-drawn noise
+        provider = getattr(inp_args, "noise_provider", None)
+        noise = provider(idxs, inp_args.midway_t, n // hop).to(dev) if provider is not None else None
         if streams[slot] is not None:
             with torch.cuda.stream(streams[slot]):
-                out = engines[slot].decode(batch.to(dev, non_blocking=True), inp_args.midway_t, noise=None, per_item=not joint)
+                out = decode_with_retry(engines[slot], batch.to(dev, non_blocking=True), inp_args.midway_t, noise, not joint)
         else:
-            out = engines[slot].decode(batch.to(dev), inp_args.midway_t, noise=None, per_item=not joint)
-        pending.append((out, idxs, joint, streams[slot]))
+            out = decode_with_retry(engines[slot], batch.to(dev), inp_args.midway_t, noise, not joint)
+        pending.append((out, idxs, joint, streams[slot], (engines[slot], batch, not joint, noise)))
     while pending:
         retire(pending.pop(0))
     return written_long + written

@@ -53,3 +53,39 @@ def driver_noises(g):
     g2 = torch.Generator().manual_seed(seed_in + 3)
     fill = torch.stack([torch.randn(1, 128, L, generator=g2) for _ in range(2 * midway_t)])
     return loop, fill, midway_t
+
+
+def sub_stride(size, cap):
+    return max(1, -(-int(size) // int(cap)))
+
+
+def sub(a, stride):
+    """Strided sample of a large tensor along its last axis: the full-width fixtures of tests/golden/bench256.npz keep a
+    sample of every large tensor (its stride is stored beside it) plus float64 checksums of the whole; the same function
+    samples the GPU result."""
+    return np.ascontiguousarray(np.asarray(a)[..., ::int(stride)])
+
+
+def checksums(a):
+    a = np.asarray(a, np.float64)
+    return np.array([a.sum(), np.abs(a).sum()], np.float64)
+
+
+class BenchGolden:
+    """tests/golden/bench256.npz (tools/gen_golden_bench.py): expectations of the dim-256 GPU tests, from the reference."""
+
+    def __init__(self):
+        self.g = load_golden("bench256")
+
+    def compare(self, key, got):
+        """max |got - ref| / max |ref| on the stored sample; also checks the shape"""
+        got = np.asarray(got)
+        assert tuple(got.shape) == tuple(int(v) for v in self.g[key + ".shape"]), (key, got.shape, self.g[key + ".shape"])
+        ref = self.g[key]
+        return rel_err(sub(got, self.g[key + ".stride"]), ref)
+
+    def checksum_err(self, key, got):
+        """relative error of (sum, sum |.|) over the WHOLE tensor: catches damage outside the strided sample"""
+        c = checksums(got)
+        r = self.g[key + ".sum"]
+        return float(np.abs(c - r).max() / (np.abs(r[1]) + 1e-30))

@@ -98,8 +98,12 @@ def test_bench_size_codes_round_trip_and_container():
         assert packed[i].tobytes() == BO.pack_bits(BO.frame_code_order(codes[:, i].numpy()).tolist(), 10)
     blobs = b.compress_codes(codes.cuda(), audio_length=38400)
     meta, off = BO.read_ecdc_header(blobs[5])
-    assert meta == {"m": "ladiffcodec_16khz", "al": 38400, "nc": 6, "lm": False} and blobs[5][off:] == packed[5].tobytes()
+    assert meta == {"m": "ladiffcodec_16khz", "al": 38400, "nc": 6, "lm": False, "hop": 320} and blobs[5][off:] == packed[5].tobytes()
     back, metas = b.decompress_codes(blobs, 120)
+    back2, _ = b.decompress_codes(blobs)                    # F from the header (al / hop)
+    assert torch.equal(back2.cpu(), codes)
+    with pytest.raises(ValueError):
+        b.decompress_codes(blobs, 119)                      # caller's F disagrees with the header
     assert torch.equal(back.cpu(), codes) and metas[0]["al"] == 38400
     pdf = torch.softmax(torch.randn(6, 1024, generator=g) * 2.0, dim=-1)
     skew = torch.stack([torch.multinomial(pdf[k], 32 * 120, replacement=True, generator=g).reshape(32, 120) for k in range(6)])
@@ -107,6 +111,16 @@ def test_bench_size_codes_round_trip_and_container():
     blobs = b.compress_codes(skew.cuda(), 38400, static_cdf=cdf)
     back, _ = b.decompress_codes(blobs, 120, static_cdf=cdf)
     assert torch.equal(back.cpu(), skew)
+    # a static-table stream says so in its own field and keeps the reference's `lm` false (compress.py:47-71: lm = payload coded
+    # with the model's LM pdfs); decoding it as plain packing, or a plain stream with a table, is refused instead of mis-decoded
+    meta_s, _ = BO.read_ecdc_header(blobs[0])
+    assert meta_s["lm"] is False and meta_s["ac"] == "static"
+    with pytest.raises(ValueError):
+        b.decompress_codes(blobs, 120)
+    with pytest.raises(ValueError):
+        b.decompress_codes(b.compress_codes(codes.cuda(), 38400), 120, static_cdf=cdf)
+    with pytest.raises(ValueError):
+        b.compress_codes(skew.cuda(), 38400, static_cdf=cdf[:5])   # one table per codebook
     hdr = len(blobs[0]) - len(blobs[0][BO.read_ecdc_header(blobs[0])[1]:])
     assert max(len(x) for x in blobs) - hdr < 900
     want = BO.ac_encode(BO.frame_code_order(skew[:, 9].numpy()).tolist(), cdf.cpu().numpy().astype(np.int64), np.tile(np.arange(6), 120))

@@ -367,3 +367,33 @@ def test_bench_workload_items_against_oracle(dtype):
         check(dtype, "chain_small", rel(got["latents"][i:i + 1].cpu().numpy(), ref["latents"].numpy()), i)
         check(dtype, "wav_small", rel(got["wav"][i:i + 1].cpu().numpy(), ref["wav"].numpy()), i)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------- pipelined conv-GEMM vs generic kernel
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_fast_every_tile_shape_against_generic_kernel(dtype):
+    """ldc_conv_compare: the same layer and pseudo-random operands through conv_fast.inc with every tile shape forced
+    (64x64, 128x64, 128x128, and the launcher's own choice incl. split-K) and through the generic kernel (conv_gemm.hip, which
+    the SConv1d vectors of the reference pin): outputs, fused GroupNorm statistics (unet.py:142-147), fused k column maxima
+    (unet.py:214) and the residual epilogue.  Shapes: the UNet's layer classes incl. two-input (concatenated) convs, k = 1/3/4/7,
+    stride 2, folded nearest upsampling, ragged row counts (B * L not a multiple of any tile)."""
+    import ctypes as C
+    e = engine("r84", dtype)
+    lib, ctx = e.lib, e._ctx
+    dt = L.LDC_F32 if dtype == "f32" else L.LDC_BF16
+    tol_out = 1e-5 if dtype == "f32" else 1.0 / 128          # one bf16 ulp of the largest output
+    shapes = [  # L, cin1, cin2, cout, k, stride, ups
+        (1200, 256, 0, 256, 3, 1, 0), (600, 512, 256, 512, 3, 1, 0), (150, 1024, 512, 1024, 3, 1, 0), (75, 1024, 1024, 1024, 3, 1, 0),
+        (75, 1024, 0, 1024, 3, 1, 0), (1200, 256, 0, 384, 1, 1, 0), (300, 512, 512, 512, 1, 1, 0), (1200, 128, 128, 256, 7, 1, 0),
+        (600, 256, 0, 512, 4, 2, 0), (75, 1024, 0, 1024, 3, 1, 1), (77, 256, 0, 128, 1, 1, 0), (53, 512, 0, 512, 3, 1, 0),
+    ]
+    for Lx, c1, c2, co, k, st, ups in shapes:
+        for cfg in (-1, 0, 1, 2):
+            for B in (3, 16):
+                if B == 16 and (cfg != -1 or Lx > 300):
+                    continue
+                d, m, r = C.c_double(), C.c_double(), C.c_double()
+                L.check(lib.ldc_conv_compare(ctx, dt, B, Lx, c1, c2, co, k, st, ups, cfg, 1 if k == 3 and st == 1 else 0, 1 if k == 1 else 0,
+                                             1 if cfg in (-1, 2) and st == 1 and not ups else 0, C.byref(d), C.byref(m), C.byref(r)))
+                assert m.value > 0.1 and d.value <= tol_out * m.value, (dtype, Lx, c1, c2, co, k, st, ups, cfg, B, d.value, m.value)
+                assert r.value < 1e-4, ("fused statistics", dtype, Lx, c1, c2, co, k, cfg, B, r.value)
