@@ -273,6 +273,8 @@ def main():
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
+    for e_k in engines:
+        e_k.host_stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -282,6 +284,7 @@ def main():
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
     assert bool(torch.isfinite(out).all()), "non-finite output"
     log(f"timed region: {elapsed:.3f} s for {args.steps} step(s)")
+    hs = [e_k.host_stats(reset=True) for e_k in engines]
 
     audio_s = world * B * (T / 16000.0) * args.steps
     result = {
@@ -295,6 +298,10 @@ def main():
                    "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                    "batches_in_flight": n_fl,
                    "parallelism": f"dp{world} (utterance-sharded, no data-path collective)"},
+        # host side of the timed region (rank 0): what one process spends inside hipGraphLaunch per bench step -- the ceiling of
+        # one process once the kernels get faster -- and how long it waited for its own look-ahead window (GPU-bound when > 0)
+        "host": {"graph_launch_ms_per_step": sum(h[0] for h in hs) / args.steps, "lookahead_wait_ms_per_step": sum(h[1] for h in hs) / args.steps,
+                 "graph_replays_per_step": sum(h[2] for h in hs) / args.steps},
     }
 
     if rank == 0 and not args.no_roofline:

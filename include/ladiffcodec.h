@@ -318,6 +318,10 @@ int ldc_unet_step_cost(ldc_ctx* ctx, int B, int L, double* flops, double* bytes)
 /* Timing of the dominant kernel class, measured with hipEvents on the launch stream when enabled.
  * ldc_profile_enable(ctx, 1) makes ldc_denoise bracket every conv-GEMM launch (eager, no graph). */
 int ldc_profile_enable(ldc_ctx* ctx, int on);
+/* Host-side cost of the step-graph replays since the last reset: milliseconds spent inside hipGraphLaunch, milliseconds spent
+ * waiting for the bounded look-ahead window (LDC_FLOW_DEPTH), number of replays. */
+int ldc_host_stats(ldc_ctx* ctx, int reset, double* graph_launch_ms, double* lookahead_wait_ms, int64_t* graph_launches);
+
 /* Device-side timeline of the timed (graph-replayed, multi-stream) mode: every step of every batch part stamps a 100 MHz
  * clock at its first and last kernel.  ldc_timeline_read: ticks[2j], ticks[2j+1] = begin / end of step j of `part`. */
 int ldc_timeline_enable(ldc_ctx* ctx, int on);

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <map>
 #include <memory>
@@ -239,6 +240,8 @@ struct ldc_ctx {
   hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int split_batch = 2;
+  double host_graph_ms = 0, host_wait_ms = 0;   // host time inside hipGraphLaunch / waiting for the look-ahead window (ldc_host_stats)
+  long long host_graph_launches = 0;
   hipStream_t side_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_side_fork[kMaxParts] = {nullptr, nullptr, nullptr, nullptr}, ev_side_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int side_streams = 0;
@@ -2095,14 +2098,27 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
     }
     sg->noise = noise; sg->x = x; sg->stream = s; sg->n = h.n * 100 + K;
   }
+  // host time inside hipGraphLaunch is accounted (ldc_host_stats): with ~1 500 kernel nodes per replay it is what caps one
+  // process once the kernels get faster
+  auto timed_launch = [&](hipGraphExec_t ge) -> hipError_t {
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipGraphLaunch(ge, s);
+    c->host_graph_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ++c->host_graph_launches;
+    return e;
+  };
   auto replay = [&](hipGraphExec_t ge) -> int {
     if (c->flow_depth > 0) {
-      if (c->flow_n >= (unsigned long long)c->flow_depth) HIPCHK(hipEventSynchronize(c->flow_ev[(c->flow_n - c->flow_depth) % ldc_ctx::kFlowRing]));
-      HIPCHK(hipGraphLaunch(ge, s));
+      if (c->flow_n >= (unsigned long long)c->flow_depth) {
+        const auto t0 = std::chrono::steady_clock::now();
+        HIPCHK(hipEventSynchronize(c->flow_ev[(c->flow_n - c->flow_depth) % ldc_ctx::kFlowRing]));
+        c->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      }
+      HIPCHK(timed_launch(ge));
       HIPCHK(hipEventRecord(c->flow_ev[c->flow_n % ldc_ctx::kFlowRing], s));
       ++c->flow_n;
     } else {
-      HIPCHK(hipGraphLaunch(ge, s));
+      HIPCHK(timed_launch(ge));
     }
     return LDC_OK;
   };
@@ -2769,6 +2785,15 @@ extern "C" int ldc_unet_step_cost(ldc_ctx* c, int B, int L, double* flops, doubl
 // 1.01 under the tracer against 1.5 untraced), so the evidence is taken on the device: the first and last kernel of every
 // step of every batch part stamp a constant-rate clock.  Toggling drops the captured graphs (the stamp pointer is a
 // kernel argument).
+extern "C" int ldc_host_stats(ldc_ctx* c, int reset, double* graph_launch_ms, double* lookahead_wait_ms, int64_t* graph_launches) {
+  if (!c) return fail(LDC_E_INVALID, "null context");
+  if (graph_launch_ms) *graph_launch_ms = c->host_graph_ms;
+  if (lookahead_wait_ms) *lookahead_wait_ms = c->host_wait_ms;
+  if (graph_launches) *graph_launches = c->host_graph_launches;
+  if (reset) { c->host_graph_ms = 0; c->host_wait_ms = 0; c->host_graph_launches = 0; }
+  return LDC_OK;
+}
+
 extern "C" int ldc_timeline_enable(ldc_ctx* c, int on) {
   if (!c) return fail(LDC_E_INVALID, "null ctx");
   HIPCHK(hipSetDevice(c->device));

@@ -74,6 +74,12 @@ class Engine:
         """ldc_set_option: 'split' (chains per batch), 'lstm_stream' (no cooperative LSTM), 'side_streams'."""
         L.check(self.lib.ldc_set_option(self._ctx, name.encode(), int(value)))
 
+    def host_stats(self, reset: bool = True):
+        """-> (ms inside hipGraphLaunch, ms waiting for the look-ahead window, graph replays) since the last reset"""
+        a, b, n = C.c_double(), C.c_double(), C.c_int64()
+        L.check(self.lib.ldc_host_stats(self._ctx, int(reset), C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     def reseed(self, seed: int) -> None:
         """torch.manual_seed counterpart for the device-drawn noise: sets the Philox seed and rewinds the call counter."""
         L.check(self.lib.ldc_reseed(self._ctx, int(seed)))

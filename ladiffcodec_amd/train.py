@@ -10,6 +10,20 @@ import ctypes as C
 from . import lib as L
 
 
+def grad_buffer(eng, param, shape=None):
+    """Where a layer's backward writes the gradient of `param`: the view of the trainer's flat gradient buffer registered for
+    this parameter (DiffusionTrainer binds every parameter's storage address, so the kernels write straight into the buffer
+    the gradient reduction and Adam read: no per-step concatenation of 135 M elements), else a fresh tensor."""
+    t = eng.torch
+    views = getattr(eng, "_grad_views", None)
+    if views is not None:
+        v = views.get(param.data_ptr())
+        if v is not None and v.numel() == param.numel():
+            eng._grad_written.add(param.data_ptr())
+            return v.view(*(shape if shape is not None else param.shape))
+    return t.empty(*(shape if shape is not None else param.shape), dtype=t.float32, device=eng.device)
+
+
 class Block:
     """unet.py:137-154.  forward(x, scale_shift) keeps what backward needs in a device workspace."""
 
@@ -47,7 +61,9 @@ class Block:
         Cout = self.weight.shape[0]
         dy = dy.to(self.eng.device, t.float32).contiguous()
         e = lambda *shape: t.empty(*shape, dtype=t.float32, device=self.eng.device)
-        dx, dw, db, dg, dbt = e(B, Cin, Lx), e(Cout, Cin, 3), e(Cout), e(Cout), e(Cout)
+        dx = e(B, Cin, Lx)
+        dw, db = grad_buffer(self.eng, self.weight), grad_buffer(self.eng, self.bias)
+        dg, dbt = grad_buffer(self.eng, self.gamma), grad_buffer(self.eng, self.beta)
         dss = e(B, 2 * Cout) if ss is not None else None
         s = self.eng._enter()
         L.check(self.lib.ldc_train_block_backward(self.eng._ctx, dy.data_ptr(), x.data_ptr(), self.gamma.data_ptr(), self.beta.data_ptr(),
@@ -114,7 +130,7 @@ class LayerNorm:
         x, stats = self._saved
         B, Cc, Lx = x.shape
         dy = dy.to(self.eng.device, t.float32).contiguous()
-        dx, dg = t.empty_like(x), t.empty(Cc, dtype=t.float32, device=self.eng.device)
+        dx, dg = t.empty_like(x), grad_buffer(self.eng, self.g)
         s = self.eng._enter()
         L.check(self.lib.ldc_train_layernorm_backward(self.eng._ctx, dy.data_ptr(), x.data_ptr(), self.g.data_ptr(), stats.data_ptr(), B, Cc, Lx,
                                                       dx.data_ptr(), dg.data_ptr(), s))
@@ -179,8 +195,8 @@ class Pointwise:
         Cout = self.weight.shape[0]
         dy = dy.to(self.eng.device, t.float32).contiguous().reshape(B, Cout, Lx)
         dx = t.empty_like(x3) if want_dx else None
-        dw = t.empty(Cout, Cin, dtype=t.float32, device=self.eng.device)
-        db = t.empty(Cout, dtype=t.float32, device=self.eng.device) if self.bias is not None else None
+        dw = grad_buffer(self.eng, self.weight)
+        db = grad_buffer(self.eng, self.bias) if self.bias is not None else None
         s = self.eng._enter()
         L.check(self.lib.ldc_train_pointwise_backward(self.eng._ctx, dy.data_ptr(), x3.data_ptr(), self.weight.data_ptr(), B, Cin, Cout, Lx,
                                                       int(self.pre_silu), dx.data_ptr() if dx is not None else None, dw.data_ptr(),
@@ -316,8 +332,8 @@ class Conv1d:
         Cout, _, K = self.weight.shape
         dy = dy.to(self.eng.device, t.float32).contiguous()
         dx = t.empty_like(x) if want_dx else None
-        dw = t.empty_like(self.weight)
-        db = t.empty(Cout, dtype=t.float32, device=self.eng.device) if self.bias is not None else None
+        dw = grad_buffer(self.eng, self.weight)
+        db = grad_buffer(self.eng, self.bias) if self.bias is not None else None
         s = self.eng._enter()
         L.check(self.lib.ldc_train_conv_backward(self.eng._ctx, dy.data_ptr(), x.data_ptr(), self.weight.data_ptr(), B, Cin, Cout, Lin, K, self.stride,
                                                  self.padding, dx.data_ptr() if dx is not None else None, dw.data_ptr(),
@@ -423,8 +439,8 @@ class ConvTranspose1d:
         B, Cin, Lx = x.shape
         Cout = self.weight.shape[1]
         dy = dy.to(self.eng.device, t.float32).contiguous()
-        dx, dw = t.empty_like(x), t.empty_like(self.weight)
-        db = t.empty(Cout, dtype=t.float32, device=self.eng.device) if self.bias is not None else None
+        dx, dw = t.empty_like(x), grad_buffer(self.eng, self.weight)
+        db = grad_buffer(self.eng, self.bias) if self.bias is not None else None
         s = self.eng._enter()
         L.check(self.lib.ldc_train_convtr_backward(self.eng._ctx, dy.data_ptr(), x.data_ptr(), self.weight.data_ptr(), B, Cin, Cout, Lx, self.ratio,
                                                    dx.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, s))
@@ -445,6 +461,22 @@ def maxscale(eng, x, dy=None):
     return out
 
 
+class _Sub:
+    """the entries of a state dict under a prefix, read on demand (so that the set of keys a network actually uses can be recorded)"""
+
+    def __init__(self, sd, prefix, alias=None):
+        self.sd, self.prefix, self.alias = sd, prefix, alias or {}
+
+    def _key(self, k):
+        return self.alias.get(k, self.prefix + k)
+
+    def __getitem__(self, k):
+        return self.sd[self._key(k)]
+
+    def __contains__(self, k):
+        return self._key(k) in self.sd
+
+
 class Unet1D:
     """Unet1D.forward (srcs/modules/unet.py:422-469) and its backward pass over the reference's own state dict
     (`other_cond` layout: x_cond is concatenated in front of x; process_cond's upsampler / scaling are applied by the caller).
@@ -457,8 +489,8 @@ class Unet1D:
         self.upsampling = [ConvTranspose1d(eng, sd[f"upsampling_layers.{i}.convtr.convtr.weight"], sd[f"upsampling_layers.{i}.convtr.convtr.bias"], r)
                            for i, r in enumerate(upsampling_ratios or ())]
         self.scale_cond = bool(unet_scale_cond)
-        sub = lambda prefix: {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
-        att = lambda prefix: {"norm.g": sd[prefix + "fn.norm.g"], **{k: v for k, v in sub(prefix + "fn.fn.").items()}}
+        sub = lambda prefix: _Sub(sd, prefix)
+        att = lambda prefix: _Sub(sd, prefix + "fn.fn.", {"norm.g": prefix + "fn.norm.g"})
         self.init_conv = Conv1d(eng, sd["init_conv.weight"], sd["init_conv.bias"], 1, 3)
         self.t1 = Pointwise(eng, sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
         self.t2 = Pointwise(eng, sd["time_mlp.3.weight"], sd["time_mlp.3.bias"])
@@ -603,48 +635,113 @@ class Unet1D:
         return grads, dx, dcond
 
 
+def predict_x_start(eng, x_t, eps, t):
+    """predicted_x_start of p_losses (ddpm_loss.py:416-420 -> predict_start_from_noise, :175-179; not clamped on this path)."""
+    tt = eng.torch
+    x_t, eps = eng._f32(x_t), eng._f32(eps)
+    t = t.to(eng.device, tt.int64).contiguous()
+    B, Cc, Lx = x_t.shape
+    out = tt.empty_like(x_t)
+    s = eng._enter()
+    L.check(eng.lib.ldc_train_predict_x_start(eng._ctx, x_t.data_ptr(), eps.data_ptr(), t.data_ptr(), B, Cc, Lx, out.data_ptr(), s))
+    eng._exit()
+    return out
+
+
+def neg_sdsdr(eng, est, tgt, clip_min: float = -30.0):
+    """sdr_loss of the reference (ClippedSDR, losses_fn.py:56-66, over asteroid's MultiSrcNegSDR('sdsdr')) per item; the
+    reference calls it as sdr_loss(x, x_hat) (model.py:194).  est, tgt: [B, 1, T]."""
+    tt = eng.torch
+    est, tgt = eng._f32(est), eng._f32(tgt)
+    B = est.shape[0]
+    out = tt.empty(B, dtype=tt.float32, device=eng.device)
+    s = eng._enter()
+    L.check(eng.lib.ldc_train_neg_sdsdr(eng._ctx, est.data_ptr(), tgt.data_ptr(), B, est.numel() // B, float(clip_min), out.data_ptr(), s))
+    eng._exit()
+    return out
+
+
 class DiffusionTrainer:
     """One optimisation step of the diffusion UNet as srcs/train.py:110-177 runs it for --run_diff (the codec is frozen, only
     model.diff_model's parameters are optimised, train.py:365): q_sample -> Unet1D forward -> p_losses objective -> Unet1D backward
     -> gradient averaging over ranks (one flat reduce-scatter + all-gather) -> Adam.  `x_start` is the scaled latent
     (model.py:165) produced by the inference kernels, `cond` the condition of model_for_cond.get_cond: with `upsampling_ratios` /
-    `unet_scale_cond` given, Unet1D.process_cond and the upsampler's own parameters are part of the step."""
+    `unet_scale_cond` given, Unet1D.process_cond and the upsampler's own parameters are part of the step.
+
+    The parameters live in ONE flat fp32 buffer, the network object is built once over views of it (Adam updates them in
+    place), and every layer's backward writes its parameter gradients straight into views of ONE flat gradient buffer -- the
+    buffers the gradient reduction and Adam work on (until round 3 the network was rebuilt and 135 M gradient elements were
+    concatenated every step)."""
 
     def __init__(self, eng, sd: dict, dim: int, dim_mults=(1, 2, 4, 8), lr: float = 1e-4, **kw):
         """kw: heads, dim_head, groups, upsampling_ratios, unet_scale_cond of Unet1D (with upsampling_ratios the raw condition is passed to step)."""
         t = eng.torch
         self.eng, self.torch = eng, t
-        self.names = sorted(sd)
+        self.dim, self.dim_mults, self.kw = dim, tuple(dim_mults), kw
+        # the trainable parameters are what Unet1D consumes for this configuration (not every key of the state dict: buffers,
+        # or the upsampling layers when upsampling_ratios is None, are not parameters of the step)
+        probe = _KeyRecorder(sd)
+        Unet1D(eng, probe, dim, self.dim_mults, **kw)
+        self.names = sorted(probe.used)
         self.shapes = {k: tuple(sd[k].shape) for k in self.names}
         self.flat = t.cat([sd[k].to(eng.device, t.float32).reshape(-1) for k in self.names]).contiguous()
-        self.dim, self.dim_mults, self.kw = dim, tuple(dim_mults), kw
+        self.flat_g = t.zeros_like(self.flat)
+        self.net = Unet1D(eng, self.state_dict(), dim, self.dim_mults, **kw)          # layers alias views of self.flat
+        self._grad_views = {p.data_ptr(): g for p, g in zip(self.state_dict().values(), self._views(self.flat_g).values())}
+        self.num_timesteps = int(eng.lib.ldc_train_num_timesteps(eng._ctx))
         self.opt = Adam(eng, self.flat, lr=lr)
 
-    def state_dict(self):
+    def _views(self, flat):
         out, off = {}, 0
         for k in self.names:
             n = 1
             for d in self.shapes[k]:
                 n *= d
-            out[k] = self.flat[off:off + n].reshape(self.shapes[k])
+            out[k] = flat[off:off + n].view(self.shapes[k])
             off += n
         return out
 
-    def step(self, x_start, cond, t, noise):
-        """-> loss (float tensor [1]) of this step, evaluated before the update"""
-        from . import parallel
-        tt = self.torch
-        net = Unet1D(self.eng, self.state_dict(), self.dim, self.dim_mults, **self.kw)
-        x_t = q_sample(self.eng, x_start, t, noise)
-        out = net.forward(x_t, t, cond)
-        loss, grad = p_losses_objective(self.eng, out, noise, t)
-        grads, _, _ = net.backward(grad)
-        flat_g = tt.cat([grads[k].reshape(-1) for k in self.names]).contiguous()
-        parallel.allreduce_gradients(flat_g)           # no-op without a process group
-        self.opt.step(flat_g)
-        return loss
+    def state_dict(self):
+        return self._views(self.flat)
 
-    def step_from_wav(self, wav, t=None, noise=None, latent_scale: float = 18.0, generator=None):
+    def gradients(self):
+        """views of the flat gradient buffer, keyed like the state dict (valid after `step`)"""
+        return self._views(self.flat_g)
+
+    def step(self, x_start, cond, t, noise, monitor: bool = False, wav=None, latent_scale: float = 18.0):
+        """-> loss (float tensor [1]) of this step, evaluated before the update.  monitor=True returns what DiffAudioRep.forward
+        reports besides (model.py:181-209): {'diff_loss', 'neg_loss', 'predicted_x_start', 'x_hat', 'x_t'} -- predicted_x_start
+        from the step's own forward pass (the reference runs the UNet a second time under no_grad for the same numbers,
+        ddpm_loss.py:416-420), x_hat = decoder(predicted_x_start * scale), neg_loss = mean clamp(-SD-SDR(wav, x_hat), -30):
+        the value srcs/train.py:401-408 selects the best checkpoint by."""
+        from . import lib as LL, parallel
+        eng = self.eng
+        eng._grad_views, eng._grad_written = self._grad_views, set()
+        try:
+            x_t = q_sample(eng, x_start, t, noise)
+            out = self.net.forward(x_t, t, cond)
+            loss, grad = p_losses_objective(eng, out, noise, t)
+            grads, _, _ = self.net.backward(grad)
+            missing = set(self._grad_views) - eng._grad_written
+            if missing or set(grads) != set(self.names):
+                raise RuntimeError(f"backward left {len(missing)} parameter gradient(s) unwritten; key mismatch: "
+                                   f"{sorted(set(self.names) ^ set(grads))[:5]}")
+        finally:
+            eng._grad_views = None
+        parallel.allreduce_gradients(self.flat_g)      # no-op without a process group
+        self.opt.step(self.flat_g)
+        if not monitor:
+            return loss
+        x0 = predict_x_start(eng, x_t, out, t)
+        rep = {"diff_loss": loss, "predicted_x_start": x0, "x_t": x_t}
+        if wav is not None:
+            x_hat = eng.decode_latents(LL.MODEL_MAIN, x0 * float(latent_scale))
+            rep["x_hat"] = x_hat
+            rep["neg_per_item"] = neg_sdsdr(eng, wav, x_hat)
+            rep["neg_loss"] = rep["neg_per_item"].mean()
+        return rep
+
+    def step_from_wav(self, wav, t=None, noise=None, latent_scale: float = 18.0, generator=None, monitor: bool = False):
         """The step as srcs/train.py:110-160 + DiffAudioRep.forward (model.py:146-182) drive it from audio: cond =
         model_for_cond.get_cond(x); x_rep = encoder(x) (frozen) / 18 (--scaling_global); t ~ U{0..T-1}, noise ~ N(0, I)
         (ddpm_loss.py:443-449) unless given; then `step`.  The engine's inference kernels run the two frozen encoders."""
@@ -655,7 +752,19 @@ class DiffusionTrainer:
         x_rep = self.eng.encode(LL.MODEL_MAIN, wav) / float(latent_scale)
         B = x_rep.shape[0]
         if t is None:
-            t = tt.randint(0, 1000, (B,), generator=generator)
+            t = tt.randint(0, self.num_timesteps, (B,), generator=generator)
         if noise is None:      # on the device unless a (CPU) generator asks for a reproducible host draw
             noise = tt.randn(x_rep.shape, generator=generator) if generator is not None else tt.randn(x_rep.shape, device=self.eng.device)
-        return self.step(x_rep, cond, t, noise)
+        return self.step(x_rep, cond, t, noise, monitor=monitor, wav=wav, latent_scale=latent_scale)
+
+
+class _KeyRecorder(dict):
+    """state dict that remembers which keys a Unet1D constructor read (all its reads go through __getitem__, see _Sub)"""
+
+    def __init__(self, sd):
+        super().__init__(sd)
+        self.used = set()
+
+    def __getitem__(self, k):
+        self.used.add(k)
+        return super().__getitem__(k)

@@ -110,3 +110,43 @@ def test_cli_two_batches_in_flight_against_oracle(tmp_path):
         y = wavfile.read(str(outd / name))[1]
         ref = O.decode_utterances(sdc, COND_CFG, sdm, mc, u, T(x).reshape(1, 1, n), 1, None)
         assert rel(y, ref["wav"].numpy().reshape(-1)) < 5e-3, name
+
+
+def test_cli_default_mode_bf16_50_steps_in_flight(tmp_path):
+    """The mode a user gets without flags of ours: --dtype bf16 (default), 50 reverse steps, graph replay, several batches
+    and --in_flight 2 (default) -- seven files at batch_size 2 = four batches dealt to two engines on two streams, each batch
+    one chain.  The noise of every file comes from a seeded tape (synthesis' test seam `noise_provider`; the device stream
+    cannot be reproduced on the CPU), the oracle decodes every file alone with the same tape.  bf16 tolerance: 2x the drift
+    measured on MI355X (tests/drift_tolerances.py, key wav_cli50)."""
+    from scipy.io import wavfile
+    from ladiffcodec_amd import sample as cli
+    from drift_tolerances import check
+    mc, u, _ = CASES["r84"]
+    synth.save_amlt(main_sd_np("r84"), str(tmp_path / "ladiff.amlt"))
+    synth.save_amlt(cond_sd_np(), str(tmp_path / "codec.amlt"))
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    n, steps = 5120, 50
+    names = [f"u{k}.wav" for k in range(7)]                       # sorted glob order = this order
+    xs = {}
+    for k, name in enumerate(names):
+        xs[name] = (synth.synthetic_wav(1, n, seed=300 + k)[0, 0] * 0.5).astype(np.float32)
+        wavfile.write(str(ind / name), 16000, xs[name])
+    Lz = n // mc.hop_length
+
+    def tape(i):
+        return torch.randn(steps, 1, 128, Lz, generator=torch.Generator().manual_seed(9000 + i))
+
+    args = cli.build_parser().parse_args([
+        "--model_for_cond", str(tmp_path / "codec.amlt"), "--model_path", str(tmp_path / "ladiff.amlt"), "--run_diff", "--scaling_global",
+        "--cond_bandwidth", "3", "--unet_scale_cond", "--enc_ratios", "8", "4", "--upsampling_ratios", "5", "2", "--diff_dims", "32",
+        "--input_dir", str(ind) + "/", "--output_dir", str(outd) + "/", "--midway_t", str(steps), "--batch_size", "2"])
+    assert args.dtype == "bf16" and args.in_flight == 2
+    args.noise_provider = lambda idxs, n_steps, L: torch.cat([tape(i) for i in idxs], dim=1)
+    written = cli.synthesis(args)
+    assert len(written) == 7
+    sdc, sdm = synth.to_torch(cond_sd_np()), synth.to_torch(main_sd_np("r84"))
+    for i, name in enumerate(names):
+        y = wavfile.read(str(outd / name))[1]
+        ref = O.decode_utterances(sdc, COND_CFG, sdm, mc, u, T(xs[name]).reshape(1, 1, n), steps, tape(i))
+        check("bf16", "wav_cli50", rel(y, ref["wav"].numpy().reshape(-1)), name)

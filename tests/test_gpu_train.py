@@ -266,3 +266,48 @@ def test_training_step_from_audio_matches_oracle():
     final = tr.state_dict()
     dev = torch.cat([(final[k[len("diff_model."):]].cpu() - v.detach()).abs().reshape(-1) for k, v in params.items()])
     assert float(dev.mean()) < 1e-5 and float((dev > 1e-4).float().mean()) < 2e-3, (float(dev.mean()), float(dev.max()))   # first step: every parameter moves by ~lr = 1e-3
+
+
+def test_full_width_training_step_reference_vectors():
+    """ONE optimisation step at the size BASELINE configs[3] names (diff_dims 256, seq_length 1200, enc_ratios 8 4; the grids
+    `bench.py --config c4` times) driven from audio, against the reference under torch autograd (tests/golden/train256.npz,
+    tools/gen_golden_train256.py: DiffAudioRep.forward of srcs/model.py:146-209): diff_loss, x_t, predicted_x_start, the decoder's
+    x_hat and the SD-SDR monitoring loss, sampled gradients of 28 parameters (k = 7 init conv, k = 4 stride-2 downsample, k = 3
+    convs incl. concatenated inputs, upsample conv, 1x1 / Linear layers, norms, both transposed-conv condition upsamplers: the
+    split-over-items dW path and every convmm grid class) and the sum of |g| of EVERY one of the 340 parameters."""
+    from ladiffcodec_amd import lib as L, synth
+    from ladiffcodec_amd.model import Engine
+    from ladiffcodec_amd.spec import CodecConfig, UnetConfig
+    from helpers import sub
+    g = load_golden("train256")
+    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    u = UnetConfig(dim=256, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0)
+    full = synth.ladiff_state_dict(mc, u, seed=1)
+    e = Engine(mc, u, cc, dtype="f32")
+    e.load_state_dict(L.MODEL_MAIN, {k: v for k, v in full.items() if not k.startswith("diffusion.model.")})
+    e.load_state_dict(L.MODEL_COND, synth.codec_state_dict(cc, seed=11))
+    e.finalize(strict=True)
+    sd = {k[len("diff_model."):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in full.items() if k.startswith("diff_model.")}
+    tr = TR.DiffusionTrainer(e, sd, dim=256, dim_mults=u.dim_mults, lr=1e-4, upsampling_ratios=u.upsampling_ratios, unet_scale_cond=True)
+    assert tr.num_timesteps == 1000 and set(tr.names) == set(str(n) for n in g["names"])
+    wav = torch.from_numpy(synth.synthetic_wav(2, 38400, seed=5))
+    noise = torch.randn(2, 128, 1200, generator=torch.Generator().manual_seed(6))
+    rep = tr.step_from_wav(wav, t=torch.from_numpy(g["t"]), noise=noise, monitor=True)
+    assert abs(float(rep["diff_loss"].cpu()[0]) - float(g["loss"][0])) < 2e-5 * max(1.0, abs(float(g["loss"][0])))
+    for key, tol in (("x_t", 1e-5), ("predicted_x_start", 1e-4), ("x_hat", 2e-4)):
+        got = rep[key].cpu().numpy()
+        assert rel(sub(got, g[key + ".stride"]), g[key]) < tol, key
+    assert np.abs(rep["neg_per_item"].cpu().numpy() - g["neg_per_item"]).max() < 2e-3          # dB
+    assert abs(float(rep["neg_loss"].cpu()) - float(g["neg_loss"][0])) < 2e-3
+    grads = tr.gradients()
+    worst = (0.0, "")
+    for k in [k for k in g if k.startswith("g.") and not k.endswith(".stride")]:
+        name = k[2:]
+        got = grads[name].cpu().numpy().reshape(-1)[::int(g[k + ".stride"])]
+        worst = max(worst, (rel(got, g[k]), name))
+    assert worst[0] < 5e-4, worst
+    sums = {str(n): float(v) for n, v in zip(g["names"], g["abs_sums"])}
+    off = max((abs(float(grads[n].double().abs().sum().cpu()) - sums[n]) / (sums[n] + 1e-12), n) for n in tr.names)
+    assert off[0] < 2e-3, off
+    e.close()

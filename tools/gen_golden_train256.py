@@ -36,9 +36,9 @@ from helpers import sub, sub_stride  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden", "train256.npz")
 SAMPLED = ["init_conv.weight", "init_conv.bias", "time_mlp.1.weight", "time_mlp.3.bias", "downs.0.0.block1.proj.weight", "downs.0.0.mlp.1.weight",
            "downs.0.0.block2.norm.weight", "downs.0.2.fn.norm.g", "downs.0.2.fn.fn.to_qkv.weight", "downs.0.2.fn.fn.to_out.0.weight",
-           "downs.0.2.fn.fn.to_out.1.g", "downs.0.3.weight", "downs.2.0.block1.proj.weight", "downs.2.0.res_conv.weight", "downs.4.3.weight",
+           "downs.0.2.fn.fn.to_out.1.g", "downs.0.3.weight", "downs.2.0.block1.proj.weight", "downs.4.3.weight",
            "mid_block1.block2.proj.weight", "mid_attn.fn.fn.to_qkv.weight", "mid_attn.fn.fn.to_out.weight", "ups.0.0.block1.proj.weight",
-           "ups.0.0.res_conv.weight", "ups.1.3.1.weight", "ups.4.1.block2.proj.bias", "final_res_block.block1.proj.weight", "final_conv.weight",
+           "ups.0.0.res_conv.weight", "ups.2.1.res_conv.weight", "ups.1.3.1.weight", "ups.4.1.block2.proj.bias", "final_res_block.block1.proj.weight", "final_conv.weight",
            "final_conv.bias", "upsampling_layers.0.convtr.convtr.weight", "upsampling_layers.1.convtr.convtr.weight",
            "upsampling_layers.1.convtr.convtr.bias"]
 
@@ -77,7 +77,7 @@ def main():
     tape = NoiseTape([noise])
     ref_ddpm.torch.randn_like, saved = tape, ref_ddpm.torch.randn_like
     try:
-        loss, predicted_x_start, x_t = model.diffusion(x_rep.detach(), cond, t=t)       # ddpm_loss.py:443-449 -> p_losses
+        loss, predicted_x_start, x_t, _t = model.diffusion(x_rep.detach(), cond, t=t)   # ddpm_loss.py:443-450 -> p_losses
     finally:
         ref_ddpm.torch.randn_like = saved
     assert tape.i == 1
