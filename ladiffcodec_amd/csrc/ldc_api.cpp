@@ -214,8 +214,16 @@ struct StepGraph {   // per batch part: hipGraph of {step_begin, unet step, p_sa
   float* x = nullptr;
   hipStream_t stream = nullptr;
   hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t pexec[kMaxParts][2] = {};   // per-part single-stream graphs ([part][0] = K steps, [1] = one step)
+  bool per_part = false;
   uint64_t last_use = 0;
   bool any() const { return exec[0] != nullptr; }
+  void destroy() {   // exec[0] aliases pexec[0][0] in per-part mode
+    if (per_part) exec[0] = nullptr;
+    for (auto& e : exec) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
+    for (auto& pe : pexec) for (auto& e : pe) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
+    per_part = false;
+  }
 };
 
 struct ldc_ctx {
@@ -240,6 +248,7 @@ struct ldc_ctx {
   hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int split_batch = 2;
+  int part_graphs = 0;          // LDC_PART_GRAPHS=1: one single-stream graph per batch part instead of one fork/join graph (host time 142 -> 76 ms per decode, decode 161 -> 163 ms: GPU-bound either way, so off)
   double host_graph_ms = 0, host_wait_ms = 0;   // host time inside hipGraphLaunch / waiting for the look-ahead window (ldc_host_stats)
   long long host_graph_launches = 0;
   hipStream_t side_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
@@ -957,6 +966,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->coop_resident[0] = lstm_coop_resident(256) ? 1 : 0;
   c->coop_resident[1] = lstm_coop_resident(512) ? 1 : 0;
   c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
+  c->part_graphs = env_int("LDC_PART_GRAPHS", 0);
   c->graph_steps = std::max(0, env_int("LDC_GRAPH_STEPS", 0));   // 0 = by chain count (denoise_loop)
   c->plan_bytes_cap = (size_t)std::max(1, env_int("LDC_PLAN_CACHE_GB", 48)) << 30;
   c->plan_count_cap = std::max(2 * kMaxParts, env_int("LDC_PLAN_CACHE_N", 24));
@@ -988,9 +998,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
 
 static void drop_plans(ldc_ctx* c) {
   (void)hipDeviceSynchronize();   // nothing captured or planned may still be running when it is destroyed
-  for (auto& g : c->graphs)
-    for (auto& e : g.exec)
-      if (e) (void)hipGraphExecDestroy(e);
+  for (auto& g : c->graphs) g.destroy();
   c->graphs.clear();
   for (auto& pl : c->plans) {
     for (hipEvent_t e : pl->marker_events) (void)hipEventDestroy(e);
@@ -1759,8 +1767,7 @@ static void evict_plan(ldc_ctx* c, size_t idx) {
   Plan* pl = c->plans[idx].get();
   for (size_t g = 0; g < c->graphs.size();) {
     if (c->graphs[g].L == pl->L && c->graphs[g].F == pl->F) {
-      for (auto& e : c->graphs[g].exec)
-        if (e) (void)hipGraphExecDestroy(e);
+      c->graphs[g].destroy();
       c->graphs.erase(c->graphs.begin() + g);
     } else {
       ++g;
@@ -2041,8 +2048,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
       for (size_t i = 1; i < c->graphs.size(); ++i)
         if (c->graphs[i].last_use < c->graphs[victim].last_use) victim = i;
       HIPCHK(hipDeviceSynchronize());
-      for (auto& e : c->graphs[victim].exec)
-        if (e) (void)hipGraphExecDestroy(e);
+      c->graphs[victim].destroy();
       c->graphs.erase(c->graphs.begin() + victim);
     }
     c->graphs.push_back(StepGraph());
@@ -2067,16 +2073,42 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   }
   const int K = std::min(k_want, std::max(1, n_steps - 1));
   int done = 0;
-  if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K) {
+  if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K + ((par && c->part_graphs) ? 100000 : 0)) {
     if (sg->any()) {
       // replays of the old executable graphs may still be in flight: drain before destroying (a re-capture is one of
       // the documented places where a call waits for the device)
       HIPCHK(hipDeviceSynchronize());
-      for (auto& e : sg->exec) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
+      sg->destroy();
     }
     // first step eagerly: loads code objects / sets function attributes outside of the capture
     LDCCHK(one_step(c, h, x, noise, stride, s));
     done = 1;
+    const bool per_part = par && c->part_graphs;
+    if (per_part) {
+      // ONE SINGLE-STREAM graph per batch part, captured and replayed on the part's own stream.  ROCm 7.2 replays a
+      // single-stream graph from AQL packets recorded at instantiation (~0.4 ms of host time for 1 500 kernel nodes); a graph
+      // that forks and joins streams inside takes the node-by-node path (~9 us per node: 140 ms of host time per 50-step decode
+      // of two parts, which is then what bounds the decode).  The parts fork once in front of the loop and join once behind it.
+      for (int k = 0; k < h.n; ++k) {
+        hipStream_t sk = k == 0 ? s : c->aux_stream[k];
+        for (int which = 0; which < 2; ++which) {
+          const int steps = which == 0 ? K : 1;
+          if (which == 1 && K == 1) break;
+          hipGraph_t g = nullptr;
+          HIPCHK(hipStreamBeginCapture(sk, hipStreamCaptureModeRelaxed));
+          int r = LDC_OK;
+          for (int i = 0; i < steps && r == LDC_OK; ++i) r = half_step(c, h, k, x, noise, stride, sk);
+          hipError_t e = hipStreamEndCapture(sk, &g);
+          if (r != LDC_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+          if (e != hipSuccess) return fail(LDC_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+          e = hipGraphInstantiate(&sg->pexec[k][which], g, nullptr, nullptr, 0);
+          (void)hipGraphDestroy(g);
+          if (e != hipSuccess) { sg->pexec[k][which] = nullptr; return fail(LDC_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+        }
+      }
+      sg->exec[0] = sg->pexec[0][0];   // marks the entry as built (any()); never launched through exec[] in this mode
+      sg->per_part = true;
+    } else {
     // exec[0]: K steps of every part; exec[1]: one step (remainder); the device-side step counters make every
     // replay continue where the last one stopped
     for (int which = 0; which < 2; ++which) {
@@ -2096,7 +2128,9 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
       (void)hipGraphDestroy(g);
       if (e != hipSuccess) { sg->exec[which] = nullptr; return fail(LDC_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
     }
-    sg->noise = noise; sg->x = x; sg->stream = s; sg->n = h.n * 100 + K;
+      sg->per_part = false;
+    }
+    sg->noise = noise; sg->x = x; sg->stream = s; sg->n = h.n * 100 + K + (per_part ? 100000 : 0);
   }
   // host time inside hipGraphLaunch is accounted (ldc_host_stats): with ~1 500 kernel nodes per replay it is what caps one
   // process once the kernels get faster
@@ -2123,6 +2157,24 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
     return LDC_OK;
   };
   int i = done;
+  if (sg->per_part) {
+    LDCCHK(fork_parts(c, h, s));
+    for (int k = 0; k < h.n; ++k) {
+      hipStream_t sk = k == 0 ? s : c->aux_stream[k];
+      int j = done;
+      auto launch_k = [&](hipGraphExec_t ge) -> hipError_t {
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = hipGraphLaunch(ge, sk);
+        c->host_graph_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ++c->host_graph_launches;
+        return e;
+      };
+      for (; j + K <= n_steps; j += K) HIPCHK(launch_k(sg->pexec[k][0]));
+      for (; j < n_steps; ++j) HIPCHK(launch_k(sg->pexec[k][K == 1 ? 0 : 1]));
+    }
+    LDCCHK(join_parts(c, h, s));
+    return LDC_OK;
+  }
   for (; i + K <= n_steps; i += K) LDCCHK(replay(sg->exec[0]));
   for (; i < n_steps; ++i) LDCCHK(replay(sg->exec[K == 1 ? 0 : 1]));
   return LDC_OK;
@@ -2798,9 +2850,7 @@ extern "C" int ldc_timeline_enable(ldc_ctx* c, int on) {
   if (!c) return fail(LDC_E_INVALID, "null ctx");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipDeviceSynchronize());
-  for (auto& g : c->graphs)
-    for (auto& e : g.exec)
-      if (e) (void)hipGraphExecDestroy(e);
+  for (auto& g : c->graphs) g.destroy();
   c->graphs.clear();
   if (on && !c->tl_buf) {
     void* p = nullptr;
