@@ -30,6 +30,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 2500.0}   # fp8 WEIGHTS are expanded to bf16 in registers: the MFMA is the bf16 one     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def fp8_label():
+    """what the MFMAs of the fp8 engine are (BASELINE configs[4]): the convs fed by a conv-only tensor (block2 of every ResnetBlock,
+    to_qkv, final_conv: 34 % of the step's flops) run fp8 x fp8 on the block-scaled fp8 MFMA, the others bf16 x fp8 weights"""
+    if os.environ.get("LDC_FP8_ACT", "1") != "0":
+        return ("fp8 e4m3 x fp8 e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4 for the convs whose input is produced for them alone (34 % of the "
+                "UNet's flops), bf16 activations x fp8 e4m3 weights (bf16 MFMA) for the others; fp32 accumulate")
+    return "bf16 activations x fp8 (e4m3) weights, bf16 MFMA"
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -291,7 +300,7 @@ def main():
         "metric": f"audio-sec decoded / wall-sec, 16kHz {kbps:g}kbps {N}-step DDPM",
         "value": audio_s / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 activations x fp8 (e4m3) weights" if args.dtype == "fp8" else args.dtype, "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio)",
+        "dtype": fp8_label() if args.dtype == "fp8" else args.dtype, "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio)",
         "config": {"workload": f"LaDiffCodec {kbps:g} kbps, diff_dims={args.diff_dims}, enc_ratios {' '.join(map(str, mc.enc_ratios))}, "
                                f"{N}-step DDPM, batch={B}x{T / 16000.0:.1f} s utterances per GPU", "name": args.config,
                    "global_batch": world * B, "latent_len": T // mc.hop_length, "denoise_steps": N,
@@ -327,11 +336,17 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/)
         traffic, traffic_src = None, None
-        for name in ("r02_conv_traffic.json", "r01_conv_traffic.json"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pmc_traffic import csrc_hash            # the figure is reported only while it was measured on THESE kernel sources
+        for name in ("r03_conv_traffic.json",):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and args.dtype == "bf16" and B == 32 and N == 50 and args.config == "c2":
-                traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                rec = json.load(open(tpath))
+                if rec.get("csrc_sha256_16") == csrc_hash():
+                    traffic = rec["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources)"
+                else:
+                    traffic_src = f"profiles/{name} was measured on other kernel sources (hash mismatch): not reported"
                 break
         convs_per_step = launches / max(1, N)
         result["roofline"] = {"bound": "mfma", "kernel": "conv_fast_kernel / conv_gemm_kernel (implicit-GEMM Conv1d on MFMA)",

@@ -337,6 +337,10 @@ int ldc_conv_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin
  * difference of the fused GroupNorm statistics / column maxima. */
 int ldc_conv_compare(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups, int tile_cfg,
                      int with_gn, int with_colmax, int with_residual, double* max_abs_diff, double* max_abs_ref, double* max_rel_stat);
+/* Self-check of the fp8 x fp8 conv-GEMM (block-scaled fp8 MFMA): operands drawn on the e4m3 grid through that kernel and through
+ * the bf16-activation x fp8-weight kernel, which then computes the same products exactly. */
+int ldc_conv_compare_fp8(ldc_ctx* ctx, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups, int with_gn, int with_colmax,
+                         double* max_abs_diff, double* max_abs_ref, double* max_rel_stat);
 int ldc_profile_read(ldc_ctx* ctx, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
 /* Per kernel class (LDC_CLASS_*) totals of the same profiling pass: event-timed milliseconds, launches, algorithmic
  * flops and algorithmic HBM bytes; arrays of n >= LDC_N_CLASSES entries (any may be NULL). */

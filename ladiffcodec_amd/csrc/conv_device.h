@@ -364,6 +364,7 @@ __device__ __forceinline__ void epilogue_rows_dispatch(const ConvKArgs& a, f32x1
 extern unsigned long long* g_conv_stamps;   // tuning aid, set by ldc_conv_microbench when LDC_CONV_STAMPS is on
 bool conv_fast_eligible(const ConvLayer& ly);
 hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, hipStream_t s, bool* launched);
+hipError_t launch_conv_fast_fp8(const ConvLayer& ly, const ConvKArgs& a_in, int M, int span_rows, hipStream_t s, bool* launched);
 hipError_t launch_conv_fast_bf16w8(const ConvLayer& ly, const ConvKArgs& a_in, int M, int span_rows, hipStream_t s, bool* launched);
 
 }  // namespace ldc

@@ -16,6 +16,7 @@ bool conv_fast_eligible(const ConvLayer& ly) {
 
 hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, hipStream_t s, bool* launched) {
   if (ly.dt == DT_F32) return launch_conv_fast_f32(ly, a, M, span_rows, s, launched);
+  if (ly.dt == DT_FP8) return launch_conv_fast_fp8(ly, a, M, span_rows, s, launched);
   return ly.w8 ? launch_conv_fast_bf16w8(ly, a, M, span_rows, s, launched) : launch_conv_fast_bf16(ly, a, M, span_rows, s, launched);
 }
 

@@ -335,6 +335,26 @@ void pack_conv_weights_fp8(const ConvLayer& ly, const float* w, void* dst, float
   }
 }
 
+// fp8 x fp8 path (ly.dt == DT_FP8): [chunk of 64 channels][tap][n_pad][64 B] e4m3 with one scale per output channel; the 16-byte
+// slots of a row are stored in order (the swizzle is applied by the LDS-DMA source address, as for bf16 rows)
+void pack_conv_weights_fp8act(const ConvLayer& ly, const float* w, void* dst, float* scales) {
+  const int cin = ly.cin1 + ly.cin2, k = ly.taps, bke = 64;
+  const int nchunks = cin / bke;
+  uint8_t* out = reinterpret_cast<uint8_t*>(dst);
+  memset(out, 0, conv_packed_weight_bytes(ly));
+  for (int n = 0; n < ly.n; ++n) {
+    float amax = 0.f;
+    for (int i = 0; i < cin * k; ++i) amax = std::max(amax, fabsf(w[(size_t)n * cin * k + i]));
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    scales[n] = sc;
+    for (int c = 0; c < nchunks; ++c)
+      for (int t = 0; t < k; ++t) {
+        uint8_t* row = out + (((size_t)c * k + t) * ly.n_pad + n) * 64;
+        for (int kk = 0; kk < bke; ++kk) row[kk] = host_f32_to_e4m3(w[((size_t)n * cin + c * bke + kk) * k + t] / sc);
+      }
+  }
+}
+
 void pack_convtr_weights(const ConvLayer& ly, const float* w, int cin, int cout, int stride, void* dst) {
   // w [Cin][Cout][2*stride]; GEMM column n = phase*Cout + co; tap 0 reads row q-1 (kernel index phase+stride),
   // tap 1 reads row q (kernel index phase).
@@ -378,7 +398,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   if (ly.tr_stride) a.colmax = nullptr;
   a.ksplit = 1; a.sk_part = c.sk_part; a.sk_count = c.sk_count; a.sk_part_cap = c.sk_part_cap; a.sk_count_cap = c.sk_count_cap;
   a.tune = c.tune; a.sk_need = c.sk_need;
-  a.wscale = ly.w8 ? ly.wscale : nullptr; a.w8 = ly.w8;
+  a.wscale = (ly.w8 || ly.dt == DT_FP8) ? ly.wscale : nullptr; a.w8 = ly.w8;
   if (c.sk_need) *c.sk_need = 0;
   if (c.gn_sum && c.gn_groups > 0 && !ly.tr_stride) {
     const int cpg = ly.n / c.gn_groups;
@@ -412,6 +432,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     if (e != hipSuccess || launched) return e;
   }
   if (c.sk_need) return hipSuccess;   // dry run: the generic kernel never splits K
+  if (ly.dt == DT_FP8) return hipErrorInvalidValue;   // fp8 inputs exist only on the pipelined kernel (the planner checks eligibility)
   a.win_rows = std::min(span, c.B * c.L_in) + 1;
   int bn = ly.bn;
   // few-tile GEMMs with a long K (the SEANet encoder's last strided / k=7 convs: 3 840 rows x 3 584..4 096 deep, 30

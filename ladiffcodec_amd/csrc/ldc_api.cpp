@@ -137,6 +137,7 @@ struct Codec {
 
 struct ResnetW {
   ConvLayer c1, c2, res;
+  ConvLayer c2_f8;              // fp8-weight contexts: block2's conv with fp8 INPUTS too (w == null: not eligible)
   bool has_res = false;
   float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   int cin1 = 0, cin2 = 0, cout = 0;
@@ -145,6 +146,7 @@ struct ResnetW {
 struct LinAttnW {
   float* norm_g = nullptr;
   ConvLayer qkv, out;
+  ConvLayer qkv_f8;             // to_qkv with fp8 inputs (see ResnetW::c2_f8)
   float* out_g = nullptr;       // null for the bottleneck Attention
   int dim = 0;
 };
@@ -159,6 +161,7 @@ struct UnetW {
   int dim = 0, time_dim = 0, groups = 8, heads = 4, dim_head = 32, channels = 128, cond_channels = 128;
   std::vector<int> dims;
   ConvLayer init, final_conv;
+  ConvLayer final_conv_f8;      // final_conv with fp8 inputs
   std::vector<LevelW> downs, ups;
   ResnetW mid1, mid2, fin;
   LinAttnW mid_attn;
@@ -248,6 +251,8 @@ struct ldc_ctx {
   hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int split_batch = 2;
+  int fp8_act = 1;              // LDC_FP8_ACT: in an fp8-weight context, tensors whose only consumer is a conv are produced in fp8 and
+                                // that conv runs fp8 x fp8 on the block-scaled MFMA (0: bf16 activations x fp8 weights everywhere)
   int part_graphs = 0;          // LDC_PART_GRAPHS=1: one single-stream graph per batch part instead of one fork/join graph (host time 142 -> 76 ms per decode, decode 161 -> 163 ms: GPU-bound either way, so off)
   double host_graph_ms = 0, host_wait_ms = 0;   // host time inside hipGraphLaunch / waiting for the look-ahead window (ldc_host_stats)
   long long host_graph_launches = 0;
@@ -394,7 +399,11 @@ struct ConvSpec {
   int cin1 = 0, cin2 = 0, cout = 0, k = 1, stride = 1, dil = 1, pad_left = 0, ups = 0, pad_mode = PAD_ZERO;
   int pre_act = ACT_NONE, post_act = ACT_NONE;
   int no_w8 = 0;               // keep this layer's weights in bf16 even in an fp8-weight context
+  int act8 = 0;                // fp8 inputs as well (dt is then DT_FP8): the fp8 x fp8 MFMA path
 };
+
+// the column form of gn_apply (norm_act.hip) is the one that can write fp8
+static bool gn_apply_fp8_ok(int C) { return C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 && C <= 2048; }
 
 static int make_conv(ldc_ctx* c, const ConvSpec& sp, const float* w_oik, const float* bias, ConvLayer* out) {
   ConvLayer ly;
@@ -411,7 +420,11 @@ static int make_conv(ldc_ctx* c, const ConvSpec& sp, const float* w_oik, const f
   ly.flops_per_row = 2.0 * (sp.cin1 + sp.cin2) * sp.k * sp.cout;
   ly.w8 = (c->w8 && sp.dt == DT_BF16 && !sp.no_w8) ? 1 : 0;
   std::vector<char> packed(conv_packed_weight_bytes(ly));
-  if (ly.w8) {
+  if (sp.dt == DT_FP8) {
+    std::vector<float> scales((size_t)sp.cout);
+    pack_conv_weights_fp8act(ly, w_oik, packed.data(), scales.data());
+    LDCCHK(c->wmem.upload(&ly.wscale, scales));
+  } else if (ly.w8) {
     std::vector<float> scales((size_t)sp.cout);
     pack_conv_weights_fp8(ly, w_oik, packed.data(), scales.data());
     LDCCHK(c->wmem.upload(&ly.wscale, scales));
@@ -691,6 +704,10 @@ static int build_resnet(ldc_ctx* c, WeightReader& wr, const std::string& p, int 
     ConvSpec s2 = sp;
     s2.cin1 = cout; s2.cin2 = 0;
     LDCCHK(make_conv(c, s2, w.data(), b2->data.data(), &r->c2));
+    if (c->w8 && c->fp8_act && c->dt == DT_BF16 && cout % 64 == 0 && gn_apply_fp8_ok(cout)) {
+      s2.dt = DT_FP8; s2.act8 = 1;
+      LDCCHK(make_conv(c, s2, w.data(), b2->data.data(), &r->c2_f8));
+    }
   }
   if (r->has_res) {
     ConvSpec s3 = sp;
@@ -717,6 +734,11 @@ static int build_attn(ldc_ctx* c, WeightReader& wr, const std::string& p, int di
   ConvSpec sq;
   sq.dt = c->dt; sq.cin1 = dim; sq.cout = 3 * hidden; sq.k = 1;
   LDCCHK(make_conv(c, sq, wq->data.data(), nullptr, &a->qkv));
+  if (c->w8 && c->fp8_act && c->dt == DT_BF16 && dim % 64 == 0 && dim <= 1024) {
+    sq.dt = DT_FP8; sq.act8 = 1;
+    LDCCHK(make_conv(c, sq, wq->data.data(), nullptr, &a->qkv_f8));
+    sq.dt = c->dt; sq.act8 = 0;
+  }
   ConvSpec so;
   so.dt = c->dt; so.cin1 = hidden; so.cout = dim; so.k = 1;
   LDCCHK(make_conv(c, so, wo->data.data(), bo->data.data(), &a->out));
@@ -787,6 +809,15 @@ static int build_unet(ldc_ctx* c, std::string* missing) {
   }
   LDCCHK(build_resnet(c, wr, P + ".final_res_block", u.dim, u.dim, u.dim, &u.fin)); take_ss(u.fin);
   LDCCHK(build_plain_conv(c, wr, P + ".final_conv", u.dim, 0, u.channels, 1, 1, 0, 0, &u.final_conv));
+  if (c->w8 && c->fp8_act && c->dt == DT_BF16 && u.dim % 64 == 0) {
+    HostTensor* w = wr.get(P + ".final_conv.weight", {u.channels, u.dim, 1});
+    HostTensor* b = wr.get(P + ".final_conv.bias", {u.channels});
+    if (w && b) {
+      ConvSpec sp;
+      sp.dt = DT_FP8; sp.act8 = 1; sp.cin1 = u.dim; sp.cout = u.channels; sp.k = 1;
+      LDCCHK(make_conv(c, sp, w->data.data(), b->data.data(), &u.final_conv_f8));
+    }
+  }
   u.ss_stride = ss_off;
   // cond upsampler: non-causal SConvTranspose1d(k=2r, s=r), no weight-norm (unet.py:372-377, conv.py:270-273)
   for (int i = 0; i < c->cfg.n_upsampling_ratios; ++i) {
@@ -967,6 +998,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->coop_resident[1] = lstm_coop_resident(512) ? 1 : 0;
   c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
   c->part_graphs = env_int("LDC_PART_GRAPHS", 0);
+  c->fp8_act = env_int("LDC_FP8_ACT", 1);
   c->graph_steps = std::max(0, env_int("LDC_GRAPH_STEPS", 0));   // 0 = by chain count (denoise_loop)
   c->plan_bytes_cap = (size_t)std::max(1, env_int("LDC_PLAN_CACHE_GB", 48)) << 30;
   c->plan_count_cap = std::max(2 * kMaxParts, env_int("LDC_PLAN_CACHE_N", 24));
@@ -1065,12 +1097,17 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     return LDC_OK;
   }
   if (n == "lstm_stream") { c->lstm_stream_only = value ? 1 : 0; return LDC_OK; }
+  if (n == "fp8_act") {   // fp8-weight contexts: fp8 x fp8 MFMA where a tensor's only consumer is a conv (decided when the weights are packed)
+    if (c->finalized) return fail(LDC_E_STATE, "fp8_act must be set before ldc_finalize_weights");
+    c->fp8_act = value ? 1 : 0;
+    return LDC_OK;
+  }
   if (n == "side_streams") {
     if (value && c->split_batch != 1) return fail(LDC_E_INVALID, "side streams need a single chain (split 1)");
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fp8_act)", name);
 }
 
 extern "C" int ldc_reseed(ldc_ctx* c, uint64_t seed) {
@@ -1533,12 +1570,15 @@ struct PlanBuilder {
   // ResnetBlock.forward (unet.py:176-192)
   // ln_g != null: the block's last kernel also writes LayerNorm(out) * ln_g to *xn_out (the PreNorm of the attention
   // block that consumes `out`)
-  void* resnet(const ResnetW& r, const void* x1, const void* x2, int L, const float* ln_g = nullptr, void** xn_out = nullptr) {
+  void* resnet(const ResnetW& r, const void* x1, const void* x2, int L, const float* ln_g = nullptr, void** xn_out = nullptr,
+               bool xn_fp8 = false) {
     const int rows = B * L, dt = c->dt, g = c->unet.groups, Bn = B;
     const UnetW* u = &c->unet;
     const float* cur_ss = pl->cur_ss;
+    // fp8-weight context: block1's output feeds block2's conv alone, so it is produced in fp8 and that conv runs fp8 x fp8
+    const bool f8 = c->w8 && c->fp8_act && r.c2_f8.w != nullptr;
     void* a = act(rows, r.cout);
-    void* b = act(rows, r.cout);
+    void* b = f8 ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
     void* d = act(rows, r.cout);
     void* out = act(rows, r.cout);
     float* st1 = next_stats();
@@ -1560,26 +1600,30 @@ struct PlanBuilder {
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
     add([=](hipStream_t s) {
       return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, cur_ss + rp->ss_off,
-                             0, nullptr, ACT_SILU, s);
-    }, false, 0, LDC_CLASS_GN_APPLY, 2.0 * Bn * L * rp->cout * es);
-    conv(r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
+                             0, nullptr, ACT_SILU, s, nullptr, nullptr, f8 ? 1 : 0);
+    }, false, 0, LDC_CLASS_GN_APPLY, (f8 ? 1.5 : 2.0) * Bn * L * rp->cout * es);
+    conv(f8 ? r.c2_f8 : r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
     if (r.has_res) mark(3);
     void* xn = nullptr;
     if (ln_g && xn_out && c->fuse_ln && gn_apply_ln_fusable(r.cout)) {
-      xn = act(rows, r.cout);
+      xn = xn_fp8 ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
       *xn_out = xn;
     }
+    const int out8_ln = (xn && xn_fp8) ? 2 : 0;
     add([=](hipStream_t s) {
-      return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s, xn, ln_g);
+      return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s, xn, ln_g, out8_ln);
     }, false, 0, LDC_CLASS_GN_APPLY, (xn ? 4.0 : 3.0) * Bn * L * rp->cout * es);
     return out;
   }
+  bool qkv_fp8(const LinAttnW& a) const { return c->w8 && c->fp8_act && a.qkv_f8.w != nullptr; }
   // Residual(PreNorm(LinearAttention)) (unet.py:208-222) / Residual(PreNorm(Attention)) (:234-246)
   void* attention(const LinAttnW& a, const void* x, int L, bool linear, void* xn_pre = nullptr) {
     const int rows = B * L, dt = c->dt, Bn = B;
     const int H = c->unet.heads, Dh = c->unet.dim_head, hid = H * Dh;
-    void* xn = xn_pre ? xn_pre : act(rows, a.dim);
+    const bool f8 = qkv_fp8(a);
+    void* xn = xn_pre ? xn_pre : (f8 ? ar->alloc((size_t)rows * a.dim) : act(rows, a.dim));
+    const ConvLayer& qkv_ly = f8 ? a.qkv_f8 : a.qkv;
     void* qkv = act(rows, 3 * hid);
     void* o = act(rows, hid);
     void* out = act(rows, a.dim);
@@ -1588,13 +1632,13 @@ struct PlanBuilder {
     // step's single memset (they sit behind the GroupNorm statistics)
     float* ws = (linear && c->fuse_kmax) ? linattn_ws + (size_t)(linattn_used++) * B * linattn_ws_floats_per_item(H, Dh) : linattn_ws;
     if (!xn_pre)
-      add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s); }, false, 0, LDC_CLASS_LAYERNORM,
+      add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s, f8 ? 1 : 0); }, false, 0, LDC_CLASS_LAYERNORM,
           2.0 * rows * a.dim * es);
     if (linear) {
       const size_t wss = linattn_ws_floats_per_item(H, Dh);
       if (c->fuse_kmax && c->fuse_attn_tail && !a.out.w8 && linattn_tail_supported(dt, H, Dh, a.dim)) {
         // three launches: qkv conv (+ k column max) -> context -> tail (out, to_out conv, LayerNorm, + x)
-        conv(a.qkv, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
+        conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
         add([=](hipStream_t s) { return launch_linattn_ctx(dt, qkv, ws, Bn, L, H, Dh, s); }, false, 0, LDC_CLASS_LINATTN, 2.0 * rows * hid * es);
         const int dim = a.dim;
         info = "tail_c" + std::to_string(dim) + "_L" + std::to_string(L) + "_B" + std::to_string(B);
@@ -1604,11 +1648,11 @@ struct PlanBuilder {
         return out;
       }
       if (c->fuse_kmax) {
-        conv(a.qkv, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
+        conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
         add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, true, s); }, false, 0, LDC_CLASS_LINATTN,
             4.0 * rows * hid * es);
       } else {
-        conv(a.qkv, xn, nullptr, qkv, nullptr, L, L);
+        conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L);
         add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, false, s); }, false, 0, LDC_CLASS_LINATTN,
             5.0 * rows * hid * es);
       }
@@ -1617,7 +1661,7 @@ struct PlanBuilder {
       add([=](hipStream_t s) { return launch_ln_rows(dt, t, out, x, ap->out_g, rows, ap->dim, s); }, false, 0, LDC_CLASS_LAYERNORM,
           3.0 * rows * a.dim * es);
     } else {
-      conv(a.qkv, xn, nullptr, qkv, nullptr, L, L);
+      conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L);
       add([=](hipStream_t s) { return launch_attn_full(dt, qkv, o, Bn, L, H, Dh, s); }, false, 0, LDC_CLASS_ATTN_FULL, 4.0 * rows * hid * es);
       conv(a.out, o, nullptr, out, x, L, L);   // + x in the epilogue
     }
@@ -1720,7 +1764,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     const LevelW& lv = u.downs[i];
     x = pb.resnet(lv.b1, x, nullptr, Lc); hs.push_back({x, Lc});
     void* xn = nullptr;
-    x = pb.resnet(lv.b2, x, nullptr, Lc, lv.attn.norm_g, &xn);
+    x = pb.resnet(lv.b2, x, nullptr, Lc, lv.attn.norm_g, &xn, pb.qkv_fp8(lv.attn));
     x = pb.attention(lv.attn, x, Lc, true, xn); hs.push_back({x, Lc});
     int Ln = Lc;
     if (lv.kind == 0) Ln = (Lc + 2 - 4) / 2 + 1;
@@ -1731,7 +1775,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   }
   {
     void* xn = nullptr;
-    x = pb.resnet(u.mid1, x, nullptr, Lc, u.mid_attn.norm_g, &xn);
+    x = pb.resnet(u.mid1, x, nullptr, Lc, u.mid_attn.norm_g, &xn, pb.qkv_fp8(u.mid_attn));
     x = pb.attention(u.mid_attn, x, Lc, false, xn);
   }
   x = pb.resnet(u.mid2, x, nullptr, Lc);
@@ -1741,7 +1785,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     if (hs.back().second != Lc) return fail(LDC_E_INVALID, "latent length %d is not divisible by 2^%zu", L, u.downs.size() - 1);
     x = pb.resnet(lv.b1, x, hs.back().first, Lc); hs.pop_back();
     void* xn = nullptr;
-    x = pb.resnet(lv.b2, x, hs.back().first, Lc, lv.attn.norm_g, &xn); hs.pop_back();
+    x = pb.resnet(lv.b2, x, hs.back().first, Lc, lv.attn.norm_g, &xn, pb.qkv_fp8(lv.attn)); hs.pop_back();
     x = pb.attention(lv.attn, x, Lc, true, xn);
     const int Ln = lv.kind == 1 ? 2 * Lc : Lc;
     void* y = pb.act(B * Ln, lv.cout);
@@ -1752,11 +1796,12 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   if (Lc != L) return fail(LDC_E_INVALID, "latent length %d does not survive the down/up path (got %d)", L, Lc);
   x = pb.resnet(u.fin, x, x0, L);
   {
-    void* th = pb.act(B * L, u.dim);
+    const bool f8 = c->w8 && c->fp8_act && u.final_conv_f8.w != nullptr;
+    void* th = f8 ? ar.alloc((size_t)B * L * u.dim) : pb.act(B * L, u.dim);
     const void* xin = x;
     const int64_t n = (int64_t)B * L * u.dim;
-    pb.add([=](hipStream_t s) { return launch_act(dt, xin, th, n, ACT_TANH, s); }, false, 0, LDC_CLASS_ELEMENTWISE, 2.0 * n * es);
-    pb.conv(u.final_conv, th, nullptr, pl->eps_cl, nullptr, L, L);
+    pb.add([=](hipStream_t s) { return launch_act(dt, xin, th, n, ACT_TANH, s, f8 ? 1 : 0); }, false, 0, LDC_CLASS_ELEMENTWISE, (f8 ? 1.5 : 2.0) * n * es);
+    pb.conv(f8 ? u.final_conv_f8 : u.final_conv, th, nullptr, pl->eps_cl, nullptr, L, L);
   }
   return LDC_OK;
 }
@@ -3113,6 +3158,115 @@ extern "C" int ldc_conv_compare(ldc_ctx* c, int dtype, int B, int L, int cin1, i
   double d = 0, m = 0;
   for (size_t i = 0; i < n_out; ++i) {
     const double a = val(h0, i), b = val(h1, i);
+    if (!(b == b)) { d = 1e30; break; }
+    d = std::max(d, fabs(a - b));
+    m = std::max(m, fabs(a));
+  }
+  *max_abs_diff = d;
+  *max_abs_ref = m;
+  double rs = 0;
+  if (with_gn) {
+    std::vector<float> s0(stat_n), s1(stat_n);
+    HIPCHK(hipMemcpy(s0.data(), st[0], stat_n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s1.data(), st[1], stat_n * 4, hipMemcpyDeviceToHost));
+    double smax = 0;
+    for (size_t i = 0; i < stat_n; ++i) smax = std::max(smax, (double)fabsf(s0[i]));
+    for (size_t i = 0; i < stat_n; ++i) rs = std::max(rs, fabs((double)s0[i] - s1[i]) / (smax + 1e-30));
+  }
+  if (with_colmax) {
+    std::vector<unsigned> c0(cm_n), c1(cm_n);
+    HIPCHK(hipMemcpy(c0.data(), cm[0], cm_n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c1.data(), cm[1], cm_n * 4, hipMemcpyDeviceToHost));
+    auto unkey = [](unsigned kx) { const unsigned b = (kx & 0x80000000u) ? (kx & 0x7fffffffu) : ~kx; float f; memcpy(&f, &b, 4); return (double)f; };
+    for (size_t i = 0; i < cm_n; ++i) rs = std::max(rs, fabs(unkey(c0[i]) - unkey(c1[i])) / (m + 1e-30));
+  }
+  *max_rel_stat = rs;
+  return LDC_OK;
+}
+
+// Self-check of the fp8 x fp8 conv (conv_fast_fp8.hip): operands drawn ON the e4m3 grid, so the bf16-activation x fp8-weight
+// kernel (same quantised weights, expanded to bf16 in registers, bf16 MFMA) computes exactly the same products; the two results
+// may differ by the fp32 summation order only (one bf16 ulp of the output at most).  Reports max |diff| and max |output|.
+extern "C" int ldc_conv_compare_fp8(ldc_ctx* c, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups, int with_gn,
+                                    int with_colmax, double* max_abs_diff, double* max_abs_ref, double* max_rel_stat) {
+  if (!c || !max_abs_diff || !max_abs_ref || !max_rel_stat) return fail(LDC_E_INVALID, "bad arguments");
+  if ((cin1 % 64) || (cin2 % 64)) return fail(LDC_E_INVALID, "fp8 inputs need channel counts that are multiples of 64");
+  HIPCHK(hipSetDevice(c->device));
+  const int cin = cin1 + cin2;
+  std::vector<float> w((size_t)cout * cin * k), bias(cout);
+  unsigned seed = 777u;
+  for (auto& v : w) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.2f; }
+  for (auto& v : bias) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f); }
+  DevMem keep;
+  const bool saved_w8 = c->w8;
+  c->w8 = true;
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  ConvLayer ly[2];
+  ConvSpec sp;
+  sp.cin1 = cin1; sp.cin2 = cin2; sp.cout = cout; sp.k = k; sp.stride = stride; sp.ups = ups;
+  sp.pad_left = (k == 4 && stride == 2) ? 1 : (k - 1) / 2;
+  sp.dt = DT_BF16;
+  int rc = make_conv(c, sp, w.data(), bias.data(), &ly[0]);            // bf16 activations x fp8 weights
+  sp.dt = DT_FP8; sp.act8 = 1;
+  if (rc == LDC_OK) rc = make_conv(c, sp, w.data(), bias.data(), &ly[1]);   // fp8 x fp8
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  c->w8 = saved_w8;
+  LDCCHK(rc);
+  const int L_out = ups ? 2 * L : (stride == 2 ? (L + 2 * sp.pad_left - k) / 2 + 1 : L);
+  const int groups = 8;
+  const size_t n_out = (size_t)B * L_out * cout, stat_n = (size_t)B * groups * kGnPad, cm_n = (size_t)B * cout;
+  // inputs: e4m3 codes with |value| <= 3.5 (exponent field <= 8), never the NaN code; the same values as bf16
+  auto make_input = [&](size_t n, unsigned sd, void** d8, void** d16) -> int {
+    std::vector<uint8_t> h8(n);
+    std::vector<uint16_t> h16(n);
+    for (size_t i = 0; i < n; ++i) {
+      sd = sd * 1664525u + 1013904223u;
+      uint8_t code = (uint8_t)(sd >> 13);
+      if (((code >> 3) & 0xf) > 8) code = (uint8_t)((code & 0x87) | (8 << 3));
+      h8[i] = code;
+      const float f = host_e4m3_to_f32(code);
+      uint32_t u;
+      memcpy(&u, &f, 4);
+      h16[i] = (uint16_t)(u >> 16);                       // every e4m3 value is exact in bf16
+    }
+    LDCCHK(keep.alloc(d8, n));
+    LDCCHK(keep.alloc(d16, n * 2));
+    HIPCHK(hipMemcpy(*d8, h8.data(), n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*d16, h16.data(), n * 2, hipMemcpyHostToDevice));
+    return LDC_OK;
+  };
+  void *x1[2] = {nullptr, nullptr}, *x2[2] = {nullptr, nullptr};
+  LDCCHK(make_input((size_t)B * L * cin1, 31u, &x1[1], &x1[0]));
+  if (cin2) LDCCHK(make_input((size_t)B * L * cin2, 32u, &x2[1], &x2[0]));
+  void *part = nullptr, *cnt = nullptr;
+  LDCCHK(keep.alloc(&part, (size_t)(8 << 20) * 4));
+  LDCCHK(keep.alloc(&cnt, 1024 * 4));
+  HIPCHK(hipMemset(cnt, 0, 1024 * 4));
+  hipStream_t s = c->own_stream;
+  void *y[2], *st[2], *cm[2];
+  for (int v = 0; v < 2; ++v) {
+    LDCCHK(keep.alloc(&y[v], n_out * 2));
+    LDCCHK(keep.alloc(&st[v], stat_n * 4));
+    LDCCHK(keep.alloc(&cm[v], cm_n * 4));
+    HIPCHK(hipMemset(y[v], 0, n_out * 2));
+    HIPCHK(hipMemset(st[v], 0, stat_n * 4));
+    HIPCHK(hipMemset(cm[v], 0, cm_n * 4));
+    ConvCall cc;
+    cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1[v]; cc.x2 = x2[v]; cc.y = y[v]; cc.y_ld = cout;
+    if (with_gn) { cc.gn_sum = (float*)st[v]; cc.gn_groups = groups; }
+    if (with_colmax) { cc.colmax = (unsigned*)cm[v]; cc.colmax_lo = 0; cc.colmax_hi = cout; cc.colmax_stride = cout; }
+    cc.sk_part = (float*)part; cc.sk_part_cap = (long long)8 << 20; cc.sk_count = (unsigned*)cnt; cc.sk_count_cap = 1024;
+    cc.tune = &c->tune;
+    HIPCHK(launch_conv(ly[v], cc, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<uint16_t> h0(n_out), h1(n_out);
+  HIPCHK(hipMemcpy(h0.data(), y[0], n_out * 2, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(h1.data(), y[1], n_out * 2, hipMemcpyDeviceToHost));
+  auto val = [](uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return (double)f; };
+  double d = 0, m = 0;
+  for (size_t i = 0; i < n_out; ++i) {
+    const double a = val(h0[i]), b = val(h1[i]);
     if (!(b == b)) { d = 1e30; break; }
     d = std::max(d, fabs(a - b));
     m = std::max(m, fabs(a));

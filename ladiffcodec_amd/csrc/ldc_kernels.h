@@ -11,7 +11,7 @@
 
 namespace ldc {
 
-enum { DT_F32 = 0, DT_BF16 = 1 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_FP8 = 2 };   // DT_FP8: OCP e4m3 conv INPUTS of the fp8 x fp8 MFMA path (conv_fast_fp8.hip); outputs stay bf16
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_ELU = 2, ACT_TANH = 3, ACT_GELU = 4, ACT_SIGMOID = 5, ACT_RELU = 6 };
 enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
 // GroupNorm statistics accumulators: every (item, group) pair owns a 64-byte line ([0] = sum, [1] = sum of squares).  Packed
@@ -19,7 +19,7 @@ enum { PAD_ZERO = 0, PAD_REFLECT = 1 };
 // (~10 ns each: +7.7 us per launch, measured on the same conv with and without fused statistics).
 static constexpr int kGnPad = 16;
 
-inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : (dt == DT_FP8 ? 1 : 2); }
 
 // ------------------------------------------------------------------------------------------------
 // conv_gemm.hip : implicit-GEMM Conv1d / ConvTranspose1d on MFMA
@@ -85,6 +85,8 @@ size_t conv_packed_weight_bytes(const ConvLayer& ly);
 void pack_conv_weights(const ConvLayer& ly, const float* w_oik, void* dst_host);
 // w8: also fills scales[n] (max |w| of the output channel / 448)
 void pack_conv_weights_fp8(const ConvLayer& ly, const float* w_oik, void* dst_host, float* scales);
+// ly.dt == DT_FP8 (fp8 inputs): [chunk of 64][tap][n_pad][64 B], fills scales[n]
+void pack_conv_weights_fp8act(const ConvLayer& ly, const float* w_oik, void* dst_host, float* scales);
 // OCP e4m3fn, round to nearest even, saturating at +-448 (host)
 uint8_t host_f32_to_e4m3(float f);
 float host_e4m3_to_f32(uint8_t v);
@@ -99,16 +101,18 @@ int conv_pick_bn(int n);
 hipError_t launch_gn_stats(int dt, const void* x, int B, int L, int C, int groups, float* stats, hipStream_t s);
 // y = act( GN(x)*(scale+1)+shift ) (+ residual).  scale_shift: fp32 [2*C] (scale then shift) selected
 // by *t_ptr from a table with row stride ss_stride, or null.  eps 1e-5.
+// out8 bit 0: y is written as OCP fp8 e4m3 ([rows][C] bytes, saturating) instead of dt; bit 1: the same for y_ln.  (The fp8 x fp8
+// conv path: a tensor whose only consumer is a conv is produced in the conv's input type.)
 hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual, int B, int L, int C, int groups,
                            const float* stats, const float* gamma, const float* beta, const float* ss_table,
-                           int ss_stride, const int* t_ptr, int act, hipStream_t s, void* y_ln = nullptr, const float* ln_g = nullptr);
+                           int ss_stride, const int* t_ptr, int act, hipStream_t s, void* y_ln = nullptr, const float* ln_g = nullptr, int out8 = 0);
 // y_ln != null: also write channel-LayerNorm(y) * ln_g (needs gn_apply_ln_fusable(C) and ACT_SILU)
 bool gn_apply_ln_fusable(int C);
 // channel LayerNorm (gain only, biased var, eps 1e-5) per row; y = LN(x)*g (+ residual)
 hipError_t launch_ln_rows(int dt, const void* x, void* y, const void* residual, const float* g, int rows, int C,
-                          hipStream_t s);
+                          hipStream_t s, int out8 = 0);
 // elementwise tanh in place / out of place
-hipError_t launch_act(int dt, const void* x, void* y, int64_t n, int act, hipStream_t s);
+hipError_t launch_act(int dt, const void* x, void* y, int64_t n, int act, hipStream_t s, int out8 = 0);
 
 // ------------------------------------------------------------------------------------------------
 // attention.hip   (heads x dim_head = 4 x 32 fixed by the reference, unet.py:195,225)

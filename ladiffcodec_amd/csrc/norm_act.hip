@@ -78,6 +78,19 @@ __device__ __forceinline__ float act_f(float v, int act) {
 // GroupNorm statistics.  grid (chunks, B); a block walks rows [r0, r1) of one item, thread -> fixed
 // 8-channel slice (so a fixed group), then LDS-reduces per group and issues one atomic pair per group.
 // ---------------------------------------------------------------------------------------------
+// 8 values -> 8 OCP e4m3 bytes at byte offset `off` (saturating at +-448: v_cvt_pk_fp8_f32 rounds to nearest even)
+__device__ __forceinline__ void store8_fp8(void* y, size_t off, const float* o) {
+  float c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c[i] = fminf(fmaxf(o[i], -448.0f), 448.0f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  *reinterpret_cast<int2*>(reinterpret_cast<char*>(y) + off) = make_int2(lo, hi);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const void* x, int L, int C, int groups, int rows_per_block,
                                                        float* stats) {
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
                                                             int groups, int rows_per_block, const float* stats,
                                                             const float* gamma, const float* beta, const float* ss_table,
                                                             int ss_stride, const int* t_ptr, int act, int dbg,
-                                                            void* y_ln, const float* ln_g) {
+                                                            void* y_ln, const float* ln_g, int out8) {
   __shared__ __attribute__((aligned(16))) float s_a[2048];
   __shared__ __attribute__((aligned(16))) float s_b[2048];
   __shared__ float s_red[LN ? 2 * 4 * 8 : 1];   // [sum | sumsq][wave][q]
@@ -255,7 +268,8 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] += rr[q][i];
       }
-      if (dbg & 8) Vec8<T>::store_nt(y, ((size_t)b * L + r) * C + v * 8, o);
+      if (out8 & 1) store8_fp8(y, ((size_t)b * L + r) * C + v * 8, o);
+      else if (dbg & 8) Vec8<T>::store_nt(y, ((size_t)b * L + r) * C + v * 8, o);
       else if (!(dbg & 4)) Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
       else if (o[0] == 12345.678f) Vec8<T>::store(y, 0, o);
       if (LN) {
@@ -319,7 +333,8 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (f[q][i] - mean[q]) * rstd * g8[i];
-        Vec8<T>::store(y_ln, ((size_t)b * L + r) * C + v * 8, o);
+        if (out8 & 2) store8_fp8(y_ln, ((size_t)b * L + r) * C + v * 8, o);
+        else Vec8<T>::store(y_ln, ((size_t)b * L + r) * C + v * 8, o);
       }
     }
   }
@@ -341,17 +356,17 @@ static int gn_pick_u(int B, int L, int vpr) {
 template <typename T, int ACT, bool LN, int VPR>
 static void gn_launch_u(int U, dim3 grid, hipStream_t s, const void* x, void* y, const void* residual, int L, int C, int groups, int rpb,
                         const float* stats, const float* gamma, const float* beta, const float* ss_table, int ss_stride,
-                        const int* t_ptr, int act, int dbg, void* y_ln, const float* ln_g) {
+                        const int* t_ptr, int act, int dbg, void* y_ln, const float* ln_g, int out8) {
 #define LDC_GN_GO(UU)                                                                                                     \
   hipLaunchKernelGGL((gn_apply_cols_kernel<T, ACT, LN, VPR, UU>), grid, dim3(256), 0, s, x, y, residual, L, C, groups, rpb, \
-                     stats, gamma, beta, ss_table, ss_stride, t_ptr, act, dbg, y_ln, ln_g)
+                     stats, gamma, beta, ss_table, ss_stride, t_ptr, act, dbg, y_ln, ln_g, out8)
   if (U == 8) LDC_GN_GO(8); else if (U == 4) LDC_GN_GO(4); else if (U == 2) LDC_GN_GO(2); else LDC_GN_GO(1);
 #undef LDC_GN_GO
 }
 
 hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual, int B, int L, int C, int groups,
                            const float* stats, const float* gamma, const float* beta, const float* ss_table,
-                           int ss_stride, const int* t_ptr, int act, hipStream_t s, void* y_ln, const float* ln_g) {
+                           int ss_stride, const int* t_ptr, int act, hipStream_t s, void* y_ln, const float* ln_g, int out8) {
   const int vpr = C / 8;
   if (y_ln && (!gn_apply_ln_fusable(C) || act != ACT_SILU)) return hipErrorInvalidValue;
   if (C % 8 == 0 && vpr <= 256 && 256 % vpr == 0 && C <= 2048) {
@@ -359,7 +374,7 @@ hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual,
     const int rpb = (256 / vpr) * U;   // one U-row trip per thread
     const int dbg = 0;
     dim3 grid((L + rpb - 1) / rpb, B);
-#define LDC_GN_ARGS grid, s, x, y, residual, L, C, groups, rpb, stats, gamma, beta, ss_table, ss_stride, t_ptr, act, dbg, y_ln, ln_g
+#define LDC_GN_ARGS grid, s, x, y, residual, L, C, groups, rpb, stats, gamma, beta, ss_table, ss_stride, t_ptr, act, dbg, y_ln, ln_g, out8
     if (y_ln) {
       if (dt == DT_F32) {
         if (vpr == 32) gn_launch_u<float, ACT_SILU, true, 32>(U, LDC_GN_ARGS);
@@ -377,6 +392,7 @@ hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual,
 #undef LDC_GN_ARGS
     return hipGetLastError();
   }
+  if (out8) return hipErrorInvalidValue;   // the generic form has no fp8 output (the planner asks for it only where the column form applies)
   const size_t total = (size_t)B * L * (C / 8);
   int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 8);
   if (blocks < 1) blocks = 1;
@@ -441,7 +457,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const void* x, void* y, co
 // Row held in registers (C <= 512 * NV): one global read, two-pass statistics on the registers, one write.
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_rows_reg_kernel(const void* x, void* y, const void* residual, const float* g,
-                                                          int rows, int C) {
+                                                          int rows, int C, int out8) {
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (row >= rows) return;
@@ -483,22 +499,23 @@ __global__ __launch_bounds__(256) void ln_rows_reg_kernel(const void* x, void* y
 #pragma unroll
         for (int i = 0; i < 8; ++i) o8[i] += r[k][i];
       }
-      Vec8<T>::store(y, (size_t)row * C + v * 8, o8);
+      if (out8) store8_fp8(y, (size_t)row * C + v * 8, o8);
+      else Vec8<T>::store(y, (size_t)row * C + v * 8, o8);
     }
   }
 }
 
 hipError_t launch_ln_rows(int dt, const void* x, void* y, const void* residual, const float* g, int rows, int C,
-                          hipStream_t s) {
-  if (C % 8) return hipErrorInvalidValue;
+                          hipStream_t s, int out8) {
+  if (C % 8 || (out8 && C > 1024)) return hipErrorInvalidValue;
   if (C <= 1024) {
     const int nb = (rows + 3) / 4;
     if (dt == DT_F32) {
-      if (C <= 512) hipLaunchKernelGGL((ln_rows_reg_kernel<float, 1>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C);
-      else hipLaunchKernelGGL((ln_rows_reg_kernel<float, 2>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C);
+      if (C <= 512) hipLaunchKernelGGL((ln_rows_reg_kernel<float, 1>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C, out8);
+      else hipLaunchKernelGGL((ln_rows_reg_kernel<float, 2>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C, out8);
     } else {
-      if (C <= 512) hipLaunchKernelGGL((ln_rows_reg_kernel<__bf16, 1>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C);
-      else hipLaunchKernelGGL((ln_rows_reg_kernel<__bf16, 2>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C);
+      if (C <= 512) hipLaunchKernelGGL((ln_rows_reg_kernel<__bf16, 1>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C, out8);
+      else hipLaunchKernelGGL((ln_rows_reg_kernel<__bf16, 2>), dim3(nb), dim3(256), 0, s, x, y, residual, g, rows, C, out8);
     }
     return hipGetLastError();
   }
@@ -513,25 +530,26 @@ hipError_t launch_ln_rows(int dt, const void* x, void* y, const void* residual, 
 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void act_kernel(const void* x, void* y, size_t nvec, int act) {
+__global__ __launch_bounds__(256) void act_kernel(const void* x, void* y, size_t nvec, int act, int out8) {
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
     float f[8];
     Vec8<T>::load(x, idx * 8, f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] = act_f(f[i], act);
-    Vec8<T>::store(y, idx * 8, f);
+    if (out8) store8_fp8(y, idx * 8, f);
+    else Vec8<T>::store(y, idx * 8, f);
   }
 }
 
-hipError_t launch_act(int dt, const void* x, void* y, int64_t n, int act, hipStream_t s) {
+hipError_t launch_act(int dt, const void* x, void* y, int64_t n, int act, hipStream_t s, int out8) {
   if (n % 8) return hipErrorInvalidValue;
   const size_t nvec = (size_t)n / 8;
   int blocks = (int)std::min<size_t>((nvec + 255) / 256, 256 * 8);
   if (blocks < 1) blocks = 1;
   if (dt == DT_F32)
-    hipLaunchKernelGGL(act_kernel<float>, dim3(blocks), dim3(256), 0, s, x, y, nvec, act);
+    hipLaunchKernelGGL(act_kernel<float>, dim3(blocks), dim3(256), 0, s, x, y, nvec, act, out8);
   else
-    hipLaunchKernelGGL(act_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, x, y, nvec, act);
+    hipLaunchKernelGGL(act_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, x, y, nvec, act, out8);
   return hipGetLastError();
 }
 

@@ -125,6 +125,50 @@ def read_wav_16k(path: str, eng=None) -> np.ndarray:
     return x
 
 
+def wav_header(path: str) -> Tuple[int, int, int]:
+    """(channels, samples at 16 kHz, sample rate) from the file header alone (memory-mapped read: no sample is touched); the length
+    after resampling is torchaudio's ceil(16000 * T / sr) (functional.resample)."""
+    from scipy.io import wavfile
+    sr, x = wavfile.read(path, mmap=True)
+    n = int(x.shape[0])
+    ch = 1 if x.ndim == 1 else int(x.shape[1])
+    del x
+    n16 = n if sr == 16000 else -(-16000 * n // int(sr))
+    return ch, n16, int(sr)
+
+
+class LazyWavs:
+    """The run's recordings at 16 kHz, loaded (and resampled on the GPU) on first use: a rank touches only the files of its own
+    shard (through round 2 every rank read and resampled the whole corpus before sharding it: world-times redundant I/O and
+    O(corpus) host memory per rank).  `shapes[i]` = (channels, samples) from the header."""
+
+    def __init__(self, files: List[str], eng):
+        self.files, self.eng = files, eng
+        self.shapes = [wav_header(f)[:2] for f in files]
+        self._cache: Dict[int, np.ndarray] = {}
+
+    def subset(self, idx: List[int]) -> "LazyWavs":
+        out = LazyWavs.__new__(LazyWavs)
+        out.files, out.eng = [self.files[i] for i in idx], self.eng
+        out.shapes = [self.shapes[i] for i in idx]
+        out._cache = {}
+        return out
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i: int) -> np.ndarray:
+        if i not in self._cache:
+            w = read_wav_16k(self.files[i], self.eng if hasattr(self.eng, "resample") else None)
+            if w.shape[-1] != self.shapes[i][1]:               # a resampler that rounds differently: trust the data
+                self.shapes[i] = (w.shape[0], w.shape[-1])
+            self._cache[i] = w
+        return self._cache[i]
+
+    def drop(self, i: int) -> None:
+        self._cache.pop(i, None)
+
+
 def output_path(wav_file: str, input_dir: str, output_dir: str) -> str:
     """sample.py:75-81,136: save_path = output_dir + wav_file[len(input_dir):][:-4]; file = save_path + '.wav'."""
     local_path = wav_file[len(input_dir):][:-4]
@@ -208,16 +252,26 @@ def plan_batches(lengths: List[int], channels: List[int], rank: int, world: int,
     return work
 
 
-_CHUNK_QUANTUM = 1280     # samples: a chunk holds whole condition frames (320) and a latent length divisible by 8 (hop 32 x 8)
+_CHUNK_QUANTUM = 2560     # default quantum (enc_ratios 8 4): see chunk_quantum
 
 
-def plan_chunks(n_samples: int, chunk: int) -> List[Tuple[int, int]]:
+def chunk_quantum(enc_ratios, unet_levels: int = 5) -> int:
+    """Samples a chunk must be a multiple of: whole condition frames (320 samples, cond codec hop 8*5*4*2) AND a latent length that
+    survives the UNet's unet_levels - 1 halvings (unet.py:336-349): lcm(320, hop * 2^(levels-1)) -- 2560 for enc_ratios 8 4 (hop
+    32), 640 for enc_ratios 8.  (Through round 2 this was a fixed 1280, which let a 1.2 s tail -- the tail of a 30 s recording cut
+    into 2.4 s chunks -- reach the UNet with L = 600.)"""
+    import math
+    hop = int(np.prod(list(enc_ratios)))
+    return math.lcm(320, hop * (1 << (unet_levels - 1)))
+
+
+def plan_chunks(n_samples: int, chunk: int, quantum: int = _CHUNK_QUANTUM) -> List[Tuple[int, int]]:
     """[(start, length)] of a recording cut into `chunk`-sample pieces; the tail keeps whole quanta (a shorter last chunk),
-    what is left of it (< 1280 samples = 80 ms) is dropped as the reference drops the sub-frame tail (sample.py:87-88)."""
+    what is left of it (less than one quantum) is dropped as the reference drops the sub-frame tail (sample.py:87-88)."""
     out, pos = [], 0
     while n_samples - pos >= chunk:
         out.append((pos, chunk)); pos += chunk
-    tail = (n_samples - pos) // _CHUNK_QUANTUM * _CHUNK_QUANTUM
+    tail = (n_samples - pos) // quantum * quantum
     if tail > 0:
         out.append((pos, tail))
     return out
@@ -230,12 +284,13 @@ def decode_long_files(eng, files: List[str], wavs, inp_args, rank: int, world: i
     import torch
     from scipy.io import wavfile
     from . import lib as L, parallel
-    chunk = max(_CHUNK_QUANTUM, int(round(inp_args.chunk_sec * 16000)) // _CHUNK_QUANTUM * _CHUNK_QUANTUM)
-    mine = parallel.shard_utterances([w.shape[-1] for w in wavs], rank, world)
+    quantum = chunk_quantum(getattr(inp_args, "enc_ratios", [8, 4]))
+    chunk = max(quantum, int(round(inp_args.chunk_sec * 16000)) // quantum * quantum)
+    mine = parallel.shard_utterances([sh[1] for sh in wavs.shapes], rank, world)
     pieces: Dict[int, List[Tuple[int, int, int]]] = {}            # chunk length -> [(file, order, start)]
     nchunks = {}
     for i in mine:
-        plan = plan_chunks(wavs[i].shape[-1], chunk)
+        plan = plan_chunks(wavs.shapes[i][1], chunk, quantum)
         nchunks[i] = len(plan)
         for k, (st, ln) in enumerate(plan):
             pieces.setdefault(ln, []).append((i, k, st))
@@ -245,7 +300,11 @@ def decode_long_files(eng, files: List[str], wavs, inp_args, rank: int, world: i
         for s in range(0, len(items), inp_args.batch_size):
             part = items[s:s + inp_args.batch_size]
             batch = torch.from_numpy(np.stack([wavs[i][0, st:st + ln] for i, _, st in part])[:, None, :])
-            stages = eng.decode(batch.to(dev), inp_args.midway_t, noise=None, per_item=True, want_stages=True)
+            # test seam (see decode_files): keys are (file index, chunk number)
+            provider = getattr(inp_args, "noise_provider", None)
+            hop = int(np.prod(getattr(inp_args, "enc_ratios", [8])))
+            noise = provider([(i, k) for i, k, _ in part], inp_args.midway_t, ln // hop).to(dev) if provider is not None else None
+            stages = eng.decode(batch.to(dev), inp_args.midway_t, noise=noise, per_item=True, want_stages=True)
             wav_raw = eng.decode_latents(L.MODEL_MAIN, stages["latents"])          # un-normalised decoder output
             for j, (i, k, _) in enumerate(part):
                 raw[i][k] = wav_raw[j:j + 1]
@@ -269,22 +328,22 @@ def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_r
     from scipy.io import wavfile
     engines = list(eng) if isinstance(eng, (list, tuple)) else [eng]
     eng = engines[0]
-    wavs = [read_wav_16k(f, eng if hasattr(eng, "resample") else None) for f in files]
-    keep = [i for i, w in enumerate(wavs) if w.shape[-1] // 640 * 640 > 0]                   # sample.py:87-88
-    files, wavs = [files[i] for i in keep], [wavs[i] for i in keep]
+    wavs = LazyWavs(files, eng)                     # headers only: (channels, samples at 16 kHz); data is loaded per shard
+    keep = [i for i, sh in enumerate(wavs.shapes) if sh[1] // 640 * 640 > 0]                  # sample.py:87-88
+    files, wavs = [files[i] for i in keep], wavs.subset(keep)
     chunk_sec = float(getattr(inp_args, "chunk_sec", 0.0) or 0.0)
     if chunk_sec > 0:
         # recordings longer than a chunk (mono) take the long-form path, everything else the reference's whole-file path
-        is_long = [w.shape[0] == 1 and w.shape[-1] > int(round(chunk_sec * 16000)) for w in wavs]
-        long_f = [f for f, m in zip(files, is_long) if m]
-        long_w = [w for w, m in zip(wavs, is_long) if m]
-        files = [f for f, m in zip(files, is_long) if not m]
-        wavs = [w for w, m in zip(wavs, is_long) if not m]
+        is_long = [sh[0] == 1 and sh[1] > int(round(chunk_sec * 16000)) for sh in wavs.shapes]
+        long_i = [i for i, m in enumerate(is_long) if m]
+        short_i = [i for i, m in enumerate(is_long) if not m]
+        long_f, long_w = [files[i] for i in long_i], wavs.subset(long_i)
+        files, wavs = [files[i] for i in short_i], wavs.subset(short_i)
         written_long = decode_long_files(eng, long_f, long_w, inp_args, rank, world, local_rank) if long_f else []
     else:
         written_long = []
-    lengths = [w.shape[-1] for w in wavs]
-    channels = [w.shape[0] for w in wavs]
+    lengths = [sh[1] for sh in wavs.shapes]
+    channels = [sh[0] for sh in wavs.shapes]
     written = []
     dev = torch.device("cuda", local_rank)
     streams = [torch.cuda.Stream(device=dev) for _ in engines] if len(engines) > 1 else [None]

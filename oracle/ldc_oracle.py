@@ -226,6 +226,16 @@ def get_cond(sd: SD, c: CodecConfig, wav: torch.Tensor, bandwidth: Optional[floa
 # ----------------------------------------------------------------------------------------------
 
 WS_PREFOLDED = False    # tests of the fp8-weight engine hand the oracle weights that are already standardised (and quantised)
+ACT_FP8 = False         # tests of the fp8 x fp8 engine: the tensors that engine produces in fp8 (block1's output, the PreNorm output
+                        # in front of to_qkv, tanh(x) in front of final_conv; channel counts that are multiples of 64) are rounded to
+                        # OCP e4m3 here too (saturating at +-448), so that the comparison isolates the kernels from the format
+
+
+def _q8(x: torch.Tensor) -> torch.Tensor:
+    """what an fp8-producing kernel stores (norm_act.hip store8_fp8), for tensors the fp8 x fp8 path quantises"""
+    if not ACT_FP8 or x.shape[1] % 64 != 0:
+        return x
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
 
 
 def ws_fold(w: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -269,7 +279,7 @@ def resnet_block(sd: SD, r: spec.ResnetSpec, x: torch.Tensor, temb: torch.Tensor
     p = r.prefix
     h = F.conv1d(x, ws_fold(sd[p + ".block1.proj.weight"]), sd[p + ".block1.proj.bias"], padding=1)
     h = F.group_norm(h, groups, sd[p + ".block1.norm.weight"], sd[p + ".block1.norm.bias"])
-    h = F.silu(h * (scale + 1) + shift)
+    h = _q8(F.silu(h * (scale + 1) + shift))
     h = F.conv1d(h, ws_fold(sd[p + ".block2.proj.weight"]), sd[p + ".block2.proj.bias"], padding=1)
     h = F.group_norm(h, groups, sd[p + ".block2.norm.weight"], sd[p + ".block2.norm.bias"])
     h = F.silu(h)
@@ -280,7 +290,7 @@ def resnet_block(sd: SD, r: spec.ResnetSpec, x: torch.Tensor, temb: torch.Tensor
 def linear_attention(sd: SD, p: str, x: torch.Tensor, heads: int, dim_head: int) -> torch.Tensor:
     """Residual(PreNorm(LinearAttention)), unet.py:50-56, 93-101, 208-222."""
     b, c, n = x.shape
-    xn = channel_layernorm(x, sd[p + ".fn.norm.g"])
+    xn = _q8(channel_layernorm(x, sd[p + ".fn.norm.g"])) if c <= 1024 else channel_layernorm(x, sd[p + ".fn.norm.g"])
     qkv = F.conv1d(xn, sd[p + ".fn.fn.to_qkv.weight"]).chunk(3, dim=1)
     q, k, v = (t.reshape(b, heads, dim_head, n) for t in qkv)
     q = q.softmax(dim=-2) * dim_head ** -0.5
@@ -295,7 +305,7 @@ def linear_attention(sd: SD, p: str, x: torch.Tensor, heads: int, dim_head: int)
 def full_attention(sd: SD, p: str, x: torch.Tensor, heads: int, dim_head: int) -> torch.Tensor:
     """Residual(PreNorm(Attention)), unet.py:234-246."""
     b, c, n = x.shape
-    xn = channel_layernorm(x, sd[p + ".fn.norm.g"])
+    xn = _q8(channel_layernorm(x, sd[p + ".fn.norm.g"])) if c <= 1024 else channel_layernorm(x, sd[p + ".fn.norm.g"])
     qkv = F.conv1d(xn, sd[p + ".fn.fn.to_qkv.weight"]).chunk(3, dim=1)
     q, k, v = (t.reshape(b, heads, dim_head, n) for t in qkv)
     q = q * dim_head ** -0.5
@@ -369,7 +379,7 @@ def unet_forward(sd: SD, u: UnetConfig, x: torch.Tensor, t: torch.Tensor, cond: 
         if taps is not None:
             taps[f"up{i}"] = x
     x = resnet_block(sd, g.final, torch.cat((x, r), dim=1), temb, u.groups)
-    x = torch.tanh(x)
+    x = _q8(torch.tanh(x))
     return F.conv1d(x, sd[prefix + ".final_conv.weight"], sd[prefix + ".final_conv.bias"])
 
 

@@ -16,7 +16,14 @@ MEASURED = {   # worst value seen over items / timesteps / layouts on MI355X, ro
              "wav_200": 8.8e-4, "eps_small": 2.12e-2, "chain_small": 3.2e-4, "wav_small": 1.6e-4, "repeat": 1.8e-4,
              "wav_cli50": 3.2e-4},     # round 3: the CLI's default mode (50 steps, dim 32, two engines in flight)
     # fp8 (e4m3) UNet weights with per-channel scales against the UNQUANTISED fp32 oracle: the price of config 5's weights
-    "fp8": {"eps_vs_unquantised": 0.125},     # measured: 0.125 on the synthetic (Gaussian) checkpoints at dim 256
+    "fp8": {"eps_vs_unquantised": 0.125,     # measured: 0.125 on the synthetic (Gaussian) checkpoints at dim 256
+            # round 3 (recorded on MI355X): the fp8 x fp8 path (act8: tensors whose only consumer is a conv are produced in fp8) against
+            # the oracle on the same quantised weights + activations (a bf16-level difference upstream flips an activation to the
+            # neighbouring e4m3 code, a 6-12 % step of that element: the kernel itself is pinned exactly by
+            # test_conv_fp8_x_fp8_mfma_against_bf16_path_on_the_e4m3_grid), against the unquantised model, and both fp8 forms after
+            # the timed 50-step decode against the reference's fp32 decode
+            "eps_bench_act8": 5.7e-2, "eps_small_act8": 2.8e-2, "eps_vs_unquantised_act8": 0.124,
+            "lat_50": 1.74e-2, "wav_50": 4.2e-3, "lat_50_act8": 1.76e-2, "wav_50_act8": 4.4e-3, "wav_c5": 3.5e-2},
 }
 # f32: 2x a 1e-6-class number would trip on a different reduction order; the floor keeps the f32 bar at 1e-5
 _FLOOR = {"f32": 1e-5, "bf16": 0.0, "fp8": 0.0}

@@ -164,9 +164,12 @@ def test_long_form_chunk_plan_and_reassembly(tmp_path, monkeypatch):
     import torch
     from scipy.io import wavfile
     from ladiffcodec_amd import sample
-    assert sample.plan_chunks(480000, 38400) == [(k * 38400, 38400) for k in range(12)] + [(460800, 19200)]
-    assert sample.plan_chunks(38400 + 1279, 38400) == [(0, 38400)]                       # < 80 ms of tail: dropped
-    assert sample.plan_chunks(2560 + 1280, 2560) == [(0, 2560), (2560, 1280)]
+    # enc_ratios 8 4: a chunk is whole condition frames (320 samples) AND a latent length that survives the UNet's four halvings
+    # (hop 32 x 16): quanta of 2560 samples -- the 1.2 s tail of a 30 s recording keeps 1.12 s
+    assert sample.chunk_quantum([8, 4]) == 2560 and sample.chunk_quantum([8]) == 640
+    assert sample.plan_chunks(480000, 38400) == [(k * 38400, 38400) for k in range(12)] + [(460800, 17920)]
+    assert sample.plan_chunks(38400 + 2559, 38400) == [(0, 38400)]                       # less than a quantum of tail: dropped
+    assert sample.plan_chunks(2560 + 1280, 2560, 640) == [(0, 2560), (2560, 1280)]
     ind, outd = tmp_path / "in", tmp_path / "out"
     ind.mkdir(); outd.mkdir()
     rng = np.random.default_rng(1)
@@ -190,6 +193,7 @@ def test_long_form_chunk_plan_and_reassembly(tmp_path, monkeypatch):
     class A:
         pass
     a = A(); a.batch_size = 4; a.midway_t = 3; a.input_dir = str(ind) + "/"; a.output_dir = str(outd) + "/"; a.chunk_sec = 2560 / 16000.0
+    a.enc_ratios = [8]                                                                      # quantum 640: long1's 1280-sample tail survives
     monkeypatch.setattr(torch.Tensor, "to", lambda self, *x, **k: self)                     # no GPU here
     eng = Stub()
     files = sorted(str(ind / n) for n in spec_files)

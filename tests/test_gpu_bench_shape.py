@@ -308,10 +308,15 @@ def fake_quantise_unet(sd_np, u):
     return out
 
 
+@pytest.mark.parametrize("act8", [0, 1])
 @pytest.mark.parametrize("layout", ["small", "bench"])
-def test_fp8_weight_engine(layout):
-    """dtype 'fp8': the kernels must reproduce the oracle run on the SAME quantised weights to the bf16 tolerance (kernel
-    correctness), and stay close to the unquantised model (what the quantisation costs, recorded in DESIGN.md)."""
+def test_fp8_weight_engine(layout, act8):
+    """dtype 'fp8' in its two forms -- act8 = 0: bf16 activations x fp8 (e4m3) weights expanded to bf16 in registers (bf16 MFMA);
+    act8 = 1 (default): additionally every tensor whose only consumer is a conv (block1's output, the PreNorm output in front of
+    to_qkv, tanh(x) in front of final_conv) is PRODUCED in fp8 and that conv runs fp8 x fp8 on v_mfma_scale_f32_32x32x64_f8f6f4.
+    The kernels must reproduce the oracle run on the SAME quantised weights (and, act8, the same quantised activations) to a
+    bf16-class tolerance (kernel correctness), and their distance to the unquantised model is recorded (what the format costs,
+    DESIGN.md section 2)."""
     if layout == "small":
         mc, u, _ = CASES["r84"]
         sd_np = main_sd_np("r84")
@@ -322,6 +327,7 @@ def test_fp8_weight_engine(layout):
         sd_np = synth.ladiff_state_dict(mc, u, seed=1)
         B, Lz, F = 32, 1200, 120
     e = Engine(mc, u, COND_CFG, dtype="fp8")
+    e.set_option("fp8_act", act8)
     e.load_state_dict(L.MODEL_MAIN, {k: v for k, v in sd_np.items() if not k.startswith("diffusion.model.")})
     e.load_state_dict(L.MODEL_COND, cond_sd_np())
     e.finalize(strict=True)
@@ -333,16 +339,48 @@ def test_fp8_weight_engine(layout):
     items = (0, B - 1)
     sd_q = fake_quantise_unet(sd_np, u)
     sd_f = synth.to_torch(sd_np)
+    tag = "_act8" if act8 else ""
     for i in items:
-        O.WS_PREFOLDED = True
+        O.WS_PREFOLDED, O.ACT_FP8 = True, bool(act8)
         try:
             ref_q = O.unet_forward(sd_q, u, x[i:i + 1], torch.full((1,), t, dtype=torch.long), cond[i:i + 1])
         finally:
-            O.WS_PREFOLDED = False
+            O.WS_PREFOLDED, O.ACT_FP8 = False, False
         ref_f = O.unet_forward(sd_f, u, x[i:i + 1], torch.full((1,), t, dtype=torch.long), cond[i:i + 1])
-        check("bf16", "eps_bench" if layout == "bench" else "eps_small", rel(got[i:i + 1].numpy(), ref_q.numpy()), ("fp8 vs quantised oracle", layout, i))
-        check("fp8", "eps_vs_unquantised", rel(got[i:i + 1].numpy(), ref_f.numpy()), (layout, i))
+        key = ("eps_bench" if layout == "bench" else "eps_small") + tag
+        check("fp8" if act8 else "bf16", key, rel(got[i:i + 1].numpy(), ref_q.numpy()), ("fp8 vs quantised oracle", layout, i))
+        check("fp8", "eps_vs_unquantised" + tag, rel(got[i:i + 1].numpy(), ref_f.numpy()), (layout, i))
     # the sampler runs (graph capture included) and stays finite
     out = e.denoise(torch.tanh(x).cuda(), cond.cuda(), 5)
     assert torch.isfinite(out).all()
+    e.close()
+
+
+@pytest.mark.parametrize("act8", [0, 1])
+def test_fp8_engine_50_step_decode_drift_vs_reference(act8):
+    """What config 5's formats cost at the END of the path: the timed workload (32 x 2.4 s, 50 steps, recorded noise) on the fp8
+    engine against the reference's fp32 decode of two of its utterances (tests/golden/bench256.npz): RVQ codes stay bit-exact
+    (the codec is exact fp32 in every engine), the drift of the latents and of the waveform is recorded / bounded."""
+    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    u = UnetConfig(dim=256, upsampling_ratios=(5, 2), unet_scale_cond=True)
+    cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0)
+    sd = synth.ladiff_state_dict(mc, u, seed=1)
+    e = Engine(mc, u, cc, dtype="fp8")
+    e.set_option("fp8_act", act8)
+    e.load_state_dict(L.MODEL_MAIN, {k: v for k, v in sd.items() if not k.startswith("diffusion.model.")})
+    e.load_state_dict(L.MODEL_COND, synth.codec_state_dict(cc, seed=11))
+    e.finalize(strict=True)
+    B, Tn, n = 32, 38400, 50
+    Lz = Tn // mc.hop_length
+    wav = torch.from_numpy(synth.synthetic_wav(B, Tn, seed=1234))
+    noise = torch.randn(n, B, 128, Lz, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    for i in (5, 22):
+        noise[:, i:i + 1] = torch.randn(n, 1, 128, Lz, generator=torch.Generator().manual_seed(100 + i)).cuda()
+    got = e.decode(wav.cuda(), n, noise, per_item=True, want_stages=True)
+    bg = bench_golden()
+    tag = "_act8" if act8 else ""
+    for i in (5, 22):
+        assert np.array_equal(got["codes"][:, i:i + 1].cpu().numpy(), bg.g[f"dec50.{i}.codes"])
+        check("fp8", "lat_50" + tag, bg.compare(f"dec50.{i}.latents", got["latents"][i:i + 1].cpu().numpy()), i)
+        check("fp8", "wav_50" + tag, bg.compare(f"dec50.{i}.wav", got["wav"][i:i + 1].cpu().numpy()), i)
     e.close()

@@ -150,3 +150,53 @@ def test_cli_default_mode_bf16_50_steps_in_flight(tmp_path):
         y = wavfile.read(str(outd / name))[1]
         ref = O.decode_utterances(sdc, COND_CFG, sdm, mc, u, T(xs[name]).reshape(1, 1, n), steps, tape(i))
         check("bf16", "wav_cli50", rel(y, ref["wav"].numpy().reshape(-1)), name)
+
+
+def test_cli_config5_long_form_fp8_50_steps(tmp_path):
+    """BASELINE configs[4] through synthesis(): ONE 30 s recording = 13 chunks of 2.4 s (12 full + a 1.2 s tail) decoded as batch
+    items, --dtype fp8 (e4m3 UNet weights; fp8 x fp8 MFMA where a tensor's only consumer is a conv), 50 reverse steps, graph
+    replay -- against the oracle run chunk by chunk on the SAME quantised weights and activations with the same noise tape, the
+    chunks' raw decoder outputs joined and normalised over the whole recording (sample.py:133-134)."""
+    from scipy.io import wavfile
+    from ladiffcodec_amd import sample as cli
+    from drift_tolerances import check
+    from test_gpu_bench_shape import fake_quantise_unet
+    mc, u, _ = CASES["r84"]
+    synth.save_amlt(main_sd_np("r84"), str(tmp_path / "ladiff.amlt"))
+    synth.save_amlt(cond_sd_np(), str(tmp_path / "codec.amlt"))
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    chunk, steps = 38400, 50
+    n = 12 * chunk + chunk // 2 + 100                              # 30 s (and a few samples more)
+    tail = (n - 12 * chunk) // 2560 * 2560                          # 1.12 s: whole 2560-sample quanta (cond frames x UNet halvings)
+    x = (synth.synthetic_wav(1, n, seed=515)[0, 0] * 0.5).astype(np.float32)
+    wavfile.write(str(ind / "long.wav"), 16000, x)
+    plan = [(k * chunk, chunk) for k in range(12)] + [(12 * chunk, tail)]
+
+    def tape(k, Lz):
+        return torch.randn(steps, 1, 128, Lz, generator=torch.Generator().manual_seed(7000 + k))
+
+    args = cli.build_parser().parse_args([
+        "--model_for_cond", str(tmp_path / "codec.amlt"), "--model_path", str(tmp_path / "ladiff.amlt"), "--run_diff", "--scaling_global",
+        "--cond_bandwidth", "3", "--unet_scale_cond", "--enc_ratios", "8", "4", "--upsampling_ratios", "5", "2", "--diff_dims", "32",
+        "--input_dir", str(ind) + "/", "--output_dir", str(outd) + "/", "--midway_t", str(steps), "--dtype", "fp8", "--chunk_sec", "2.4"])
+    args.noise_provider = lambda keys, n_steps, Lz: torch.cat([tape(k, Lz) for _, k in keys], dim=1)
+    written = cli.synthesis(args)
+    assert len(written) == 1
+    sr_out, y = wavfile.read(str(outd / "long.wav"))
+    assert sr_out == 16000 and y.shape == (12 * chunk + tail,)
+    sdc = synth.to_torch(cond_sd_np())
+    sd_q = fake_quantise_unet(main_sd_np("r84"), u)
+    O.WS_PREFOLDED, O.ACT_FP8 = True, True
+    try:
+        # the twelve full chunks as one oracle batch (utterances do not interact), the tail alone
+        xb = torch.stack([T(x[st:st + chunk]) for st, _ in plan[:12]]).reshape(12, 1, chunk)
+        nb = torch.cat([tape(k, chunk // mc.hop_length) for k in range(12)], dim=1)
+        full = O.decode_utterances(sdc, COND_CFG, sd_q, mc, u, xb, steps, nb, per_item=True)["wav_raw"]
+        st, ln = plan[12]
+        last = O.decode_utterances(sdc, COND_CFG, sd_q, mc, u, T(x[st:st + ln]).reshape(1, 1, ln), steps, tape(12, ln // mc.hop_length), per_item=True)["wav_raw"]
+    finally:
+        O.WS_PREFOLDED, O.ACT_FP8 = False, False
+    raws = [full[k:k + 1] for k in range(12)] + [last]
+    whole = O.output_normalise(torch.cat(raws, dim=-1))
+    check("fp8", "wav_c5", rel(y, whole.numpy().reshape(-1)))

@@ -397,3 +397,26 @@ def test_conv_fast_every_tile_shape_against_generic_kernel(dtype):
                                              1 if cfg in (-1, 2) and st == 1 and not ups else 0, C.byref(d), C.byref(m), C.byref(r)))
                 assert m.value > 0.1 and d.value <= tol_out * m.value, (dtype, Lx, c1, c2, co, k, st, ups, cfg, B, d.value, m.value)
                 assert r.value < 1e-4, ("fused statistics", dtype, Lx, c1, c2, co, k, cfg, B, r.value)
+
+
+def test_conv_fp8_x_fp8_mfma_against_bf16_path_on_the_e4m3_grid():
+    """ldc_conv_compare_fp8: the fp8 x fp8 conv-GEMM (v_mfma_scale_f32_32x32x64_f8f6f4, 64 channels per LDS row) against the
+    bf16-activation x fp8-weight kernel on operands drawn ON the e4m3 grid -- both compute the same products exactly and may
+    differ by the fp32 summation order only: at most one bf16 ulp of the largest output, fused statistics to 1e-4."""
+    import ctypes as C
+    e = engine("r84", "bf16")
+    lib, ctx = e.lib, e._ctx
+    shapes = [  # L, cin1, cin2, cout, k, stride, ups
+        (1200, 256, 0, 256, 3, 1, 0), (300, 512, 0, 512, 3, 1, 0), (75, 1024, 0, 1024, 3, 1, 0), (1200, 256, 0, 384, 1, 1, 0),
+        (75, 1024, 0, 384, 1, 1, 0), (1200, 256, 0, 128, 1, 1, 0), (160, 64, 0, 64, 3, 1, 0), (53, 128, 64, 128, 3, 1, 0),
+    ]
+    for Lx, c1, c2, co, k, st, ups in shapes:
+        for B in (3, 16):
+            if B == 16 and Lx > 300:
+                continue
+            d, m, r = C.c_double(), C.c_double(), C.c_double()
+            L.check(lib.ldc_conv_compare_fp8(ctx, B, Lx, c1, c2, co, k, st, ups, 1 if k == 3 else 0, 1 if k == 1 else 0,
+                                             C.byref(d), C.byref(m), C.byref(r)))
+            assert m.value > 0.1 and d.value <= m.value / 128, (Lx, c1, c2, co, k, B, d.value, m.value)
+            # GroupNorm sums agree to 1e-4; a column MAXIMUM is one of the (bf16-rounded) outputs and may differ by their one ulp
+            assert r.value < (1.0 / 128 if k == 1 else 1e-4), ("fused statistics", Lx, c1, c2, co, k, B, r.value)

@@ -4,8 +4,22 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts wide coa
 their bytes -> doubled; both counters are in KB."""
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+
+def csrc_hash():
+    """sha256 over the kernel sources: bench.py reports a committed traffic figure only while the kernels it was measured on
+    are the kernels it runs (round-2 review: the figure went stale silently)"""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ladiffcodec_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def mean_counter(d, name):
@@ -17,10 +31,11 @@ def mean_counter(d, name):
     return (sum(vals) / len(vals), len(vals)) if vals else (0.0, 0)
 
 
-fetch, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
-write, nw = mean_counter(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": "conv_fast_kernel", "launches_sampled": [nf, nw], "fetch_kb_mean_raw": fetch, "write_kb_mean": write,
-       "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
-       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 0; FETCH_SIZE doubled (gfx950)"}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(out)
+if __name__ == "__main__":
+    fetch, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
+    write, nw = mean_counter(sys.argv[2], "WRITE_SIZE")
+    out = {"kernel": "conv_fast_kernel", "launches_sampled": [nf, nw], "fetch_kb_mean_raw": fetch, "write_kb_mean": write,
+           "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "csrc_sha256_16": csrc_hash(),
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 0; FETCH_SIZE doubled (gfx950)"}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(out)
