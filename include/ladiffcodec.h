@@ -318,6 +318,10 @@ int ldc_unet_step_cost(ldc_ctx* ctx, int B, int L, double* flops, double* bytes)
 /* Timing of the dominant kernel class, measured with hipEvents on the launch stream when enabled.
  * ldc_profile_enable(ctx, 1) makes ldc_denoise bracket every conv-GEMM launch (eager, no graph). */
 int ldc_profile_enable(ldc_ctx* ctx, int on);
+/* Tuning aid: histogram of the XCC (die) ids `wgs` workgroups land on when launched on a stream created with the given CU mask
+ * (n_words 32-bit words; NULL: unmasked). */
+int ldc_xcc_census(ldc_ctx* ctx, const uint32_t* mask, int n_words, int wgs, int* hist16);
+
 /* Host-side cost of the step-graph replays since the last reset: milliseconds spent inside hipGraphLaunch, milliseconds spent
  * waiting for the bounded look-ahead window (LDC_FLOW_DEPTH), number of replays. */
 int ldc_host_stats(ldc_ctx* ctx, int reset, double* graph_launch_ms, double* lookahead_wait_ms, int64_t* graph_launches);

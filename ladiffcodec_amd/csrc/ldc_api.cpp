@@ -181,6 +181,8 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
   long long sk_need_max = 0;
   void* arena_base = nullptr;
   size_t arena_bytes = 0;
+  void* zero_ptr = nullptr;     // the step's accumulators (GroupNorm sums, split-K counters, k-max keys, scale_x maxima): cleared by
+  size_t zero_bytes = 0;        // launch_step_begin
   void* x_cl = nullptr;         // [B*L][channels]
   void* cond_in_cl = nullptr;   // [B*F][cond_channels]   (raw cond, channels-last)
   void* cond_cl = nullptr;      // [B*L][cond_channels]   (processed)
@@ -1570,8 +1572,9 @@ struct PlanBuilder {
   // ResnetBlock.forward (unet.py:176-192)
   // ln_g != null: the block's last kernel also writes LayerNorm(out) * ln_g to *xn_out (the PreNorm of the attention
   // block that consumes `out`)
+  // out_mode (final ResnetBlock only): bit 2 = write tanh(out) (unet.py:467), bit 0 = in fp8 (its only consumer is final_conv)
   void* resnet(const ResnetW& r, const void* x1, const void* x2, int L, const float* ln_g = nullptr, void** xn_out = nullptr,
-               bool xn_fp8 = false) {
+               bool xn_fp8 = false, int out_mode = 0) {
     const int rows = B * L, dt = c->dt, g = c->unet.groups, Bn = B;
     const UnetW* u = &c->unet;
     const float* cur_ss = pl->cur_ss;
@@ -1580,7 +1583,7 @@ struct PlanBuilder {
     void* a = act(rows, r.cout);
     void* b = f8 ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
     void* d = act(rows, r.cout);
-    void* out = act(rows, r.cout);
+    void* out = (out_mode & 1) ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
     float* st1 = next_stats();
     float* st2 = next_stats();
     const int cpg = r.cout / g;
@@ -1610,7 +1613,7 @@ struct PlanBuilder {
       xn = xn_fp8 ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
       *xn_out = xn;
     }
-    const int out8_ln = (xn && xn_fp8) ? 2 : 0;
+    const int out8_ln = ((xn && xn_fp8) ? 2 : 0) | (gn_apply_fp8_ok(r.cout) ? out_mode : 0);
     add([=](hipStream_t s) {
       return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s, xn, ln_g, out8_ln);
     }, false, 0, LDC_CLASS_GN_APPLY, (xn ? 4.0 : 3.0) * Bn * L * rp->cout * es);
@@ -1734,10 +1737,8 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   }
   pl->taps["cond_proc"] = {pl->cond_cl, Cc, L};
   // ---- Unet1D.forward (unet.py:430-469) ----
-  {
-    float* sp = pb.stats_pool;
-    pb.add([=](hipStream_t s) { return hipMemsetAsync(sp, 0, stats_bytes, s); });
-  }
+  pl->zero_ptr = pb.stats_pool;            // cleared by the step's first kernel (launch_step_begin): no memset node of its own
+  pl->zero_bytes = stats_bytes;
   const void* in_cond = pl->cond_cl;
   const void* in_x = pl->x_cl;
   if (c->cfg.unet_scale_x) {
@@ -1794,13 +1795,22 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     pl->taps["up" + std::to_string(i)] = {y, lv.cout, Lc};
   }
   if (Lc != L) return fail(LDC_E_INVALID, "latent length %d does not survive the down/up path (got %d)", L, Lc);
-  x = pb.resnet(u.fin, x, x0, L);
   {
+    // final ResnetBlock -> tanh -> final_conv (unet.py:465-469): the tanh is applied by the block's last kernel (one launch and
+    // two passes over the tensor less), in fp8 when final_conv runs fp8 x fp8
     const bool f8 = c->w8 && c->fp8_act && u.final_conv_f8.w != nullptr;
-    void* th = f8 ? ar.alloc((size_t)B * L * u.dim) : pb.act(B * L, u.dim);
-    const void* xin = x;
-    const int64_t n = (int64_t)B * L * u.dim;
-    pb.add([=](hipStream_t s) { return launch_act(dt, xin, th, n, ACT_TANH, s, f8 ? 1 : 0); }, false, 0, LDC_CLASS_ELEMENTWISE, (f8 ? 1.5 : 2.0) * n * es);
+    const bool fuse_tanh = gn_apply_fp8_ok(u.dim);
+    const void* th = nullptr;
+    if (fuse_tanh) {
+      th = pb.resnet(u.fin, x, x0, L, nullptr, nullptr, false, 4 | (f8 ? 1 : 0));
+    } else {
+      x = pb.resnet(u.fin, x, x0, L);
+      void* tb = f8 ? ar.alloc((size_t)B * L * u.dim) : pb.act(B * L, u.dim);
+      const void* xin = x;
+      const int64_t n = (int64_t)B * L * u.dim;
+      pb.add([=](hipStream_t s) { return launch_act(dt, xin, tb, n, ACT_TANH, s, f8 ? 1 : 0); }, false, 0, LDC_CLASS_ELEMENTWISE, (f8 ? 1.5 : 2.0) * n * es);
+      th = tb;
+    }
     pb.conv(f8 ? u.final_conv_f8 : u.final_conv, th, nullptr, pl->eps_cl, nullptr, L, L);
   }
   return LDC_OK;
@@ -1982,7 +1992,7 @@ extern "C" int ldc_unet_forward(ldc_ctx* c, const float* x, int t, const float* 
   for (int k = 0; k < h.n; ++k) {
     Plan* pl = h.p[k];
     HIPCHK(launch_step_set(pl->step_state, t, 0, c->cur_key, s));
-    HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, nullptr, s));
+    HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, nullptr, s, pl->zero_ptr, pl->zero_bytes));
     LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
     HIPCHK(launch_from_cl(c->dt, pl->eps_cl, eps_out + (size_t)h.b0[k] * c->unet.channels * L, pl->B, c->unet.channels, L, nullptr,
                           0, 0.f, s));
@@ -2016,7 +2026,7 @@ static int half_step(ldc_ctx* c, const Halves& h, int k, float* x, const float* 
   Plan* pl = h.p[k];
   const size_t off = (size_t)h.b0[k] * c->unet.channels * pl->L;
   unsigned long long* tl = c->timeline ? c->tl_buf + (size_t)k * 2048 * 2 : nullptr;
-  HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, tl, s));
+  HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, tl, s, pl->zero_ptr, pl->zero_bytes));
   LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
   HIPCHK(launch_p_sample_update(c->dt, x + off, pl->eps_cl, noise ? noise + off : nullptr, noise_stride, pl->x_cl, pl->B,
                                 c->unet.channels, pl->L, c->sched, pl->step_state, (uint64_t)off, s));
@@ -2882,6 +2892,33 @@ extern "C" int ldc_unet_step_cost(ldc_ctx* c, int B, int L, double* flops, doubl
 // 1.01 under the tracer against 1.5 untraced), so the evidence is taken on the device: the first and last kernel of every
 // step of every batch part stamp a constant-rate clock.  Toggling drops the captured graphs (the stamp pointer is a
 // kernel argument).
+// Tuning aid: which XCCs (dies) the workgroups of a launch land on when its stream is created with a CU mask
+// (hipExtStreamCreateWithCUMask): `wgs` workgroups each record HW_REG_XCC_ID; hist[x] = workgroups seen on XCC x.  mask == NULL: no mask.
+__global__ void xcc_census_kernel(int* out, int spin) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 0xf);
+  for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(8);   // keep workgroups resident so that the launch spreads
+}
+extern "C" int ldc_xcc_census(ldc_ctx* c, const uint32_t* mask, int n_words, int wgs, int* hist16) {
+  if (!c || !hist16 || wgs < 1 || wgs > (1 << 16)) return fail(LDC_E_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = nullptr;
+  if (mask && n_words > 0) HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask));
+  else HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  int* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (size_t)wgs * sizeof(int)));
+  HIPCHK(hipMemsetAsync(d, 0xff, (size_t)wgs * sizeof(int), st));
+  hipLaunchKernelGGL(xcc_census_kernel, dim3(wgs), dim3(64), 0, st, d, 64);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<int> h((size_t)wgs);
+  HIPCHK(hipMemcpy(h.data(), d, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; ++i) hist16[i] = 0;
+  for (int v : h) if (v >= 0 && v < 16) ++hist16[v];
+  (void)hipFree(d);
+  (void)hipStreamDestroy(st);
+  return LDC_OK;
+}
+
 extern "C" int ldc_host_stats(ldc_ctx* c, int reset, double* graph_launch_ms, double* lookahead_wait_ms, int64_t* graph_launches) {
   if (!c) return fail(LDC_E_INVALID, "null context");
   if (graph_launch_ms) *graph_launch_ms = c->host_graph_ms;
@@ -3066,12 +3103,26 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     HIPCHK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
     double pro = 0, loop = 0, epi = 0, tab = 0, dma = 0; int n = 0;
     unsigned long long t_first = ~0ull, t_last = 0;
+    int xcc_match = 0, xcc_hist[16] = {0}, xcc_of_class[8][16] = {};
     for (int b = 0; b < nblk; ++b) {
       if (!h[8 * b + 3]) continue;
+      xcc_match += ((int)h[8 * b + 6] == (b & 7));
+      ++xcc_hist[h[8 * b + 6] & 15];
+      ++xcc_of_class[b & 7][h[8 * b + 6] & 15];
       t_first = std::min(t_first, h[8 * b]); t_last = std::max(t_last, h[8 * b + 3]);
       pro += (double)(h[8 * b + 1] - h[8 * b]); loop += (double)(h[8 * b + 2] - h[8 * b + 1]); epi += (double)(h[8 * b + 3] - h[8 * b + 2]);
       tab += (double)(h[8 * b + 4] - h[8 * b]); dma += (double)(h[8 * b + 5] - h[8 * b + 4]);
       ++n;
+    }
+    if (n) fprintf(stderr, "  XCC id == workgroup %% 8 for %d of %d workgroups; per-XCC counts %d %d %d %d %d %d %d %d\n", xcc_match, n, xcc_hist[0], xcc_hist[1],
+                   xcc_hist[2], xcc_hist[3], xcc_hist[4], xcc_hist[5], xcc_hist[6], xcc_hist[7]);
+    if (n) {
+      fprintf(stderr, "  workgroup %% 8 -> XCC ids seen (count):");
+      for (int cl = 0; cl < 8; ++cl) {
+        fprintf(stderr, "  %d:", cl);
+        for (int x = 0; x < 16; ++x) if (xcc_of_class[cl][x]) fprintf(stderr, " %d(%d)", x, xcc_of_class[cl][x]);
+      }
+      fprintf(stderr, "\n");
     }
     if (n) fprintf(stderr, "  stamps (s_memtime ticks per workgroup): blocks=%d prologue=%.1f (tile+copy tables %.1f, first copies issued %.1f, fragment tables %.1f) loop=%.1f epilogue=%.1f | first start -> last end %.0f\n",
                    n, pro / n, tab / n, dma / n, (pro - tab - dma) / n, loop / n, epi / n, (double)(t_last - t_first));

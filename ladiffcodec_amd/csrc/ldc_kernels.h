@@ -101,7 +101,8 @@ int conv_pick_bn(int n);
 hipError_t launch_gn_stats(int dt, const void* x, int B, int L, int C, int groups, float* stats, hipStream_t s);
 // y = act( GN(x)*(scale+1)+shift ) (+ residual).  scale_shift: fp32 [2*C] (scale then shift) selected
 // by *t_ptr from a table with row stride ss_stride, or null.  eps 1e-5.
-// out8 bit 0: y is written as OCP fp8 e4m3 ([rows][C] bytes, saturating) instead of dt; bit 1: the same for y_ln.  (The fp8 x fp8
+// out8 bit 0: y is written as OCP fp8 e4m3 ([rows][C] bytes, saturating) instead of dt; bit 1: the same for y_ln; bit 2: y = tanh(y)
+// after the residual add (the final ResnetBlock, whose output feeds torch.tanh alone).  (The fp8 x fp8
 // conv path: a tensor whose only consumer is a conv is produced in the conv's input type.)
 hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual, int B, int L, int C, int groups,
                            const float* stats, const float* gamma, const float* beta, const float* ss_table,
@@ -169,7 +170,9 @@ hipError_t launch_scale_copy(int dt, const void* x, void* y, int B, int64_t n_pe
 hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s);      // t -= 1, j += 1 (tl: timeline slot or null)
 // cur[0..stride) = table[st[0]][0..stride): the current timestep's scale/shift row, so that consumers need no
 // dependent load through the step counter
-hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, unsigned long long* tl, hipStream_t s);
+// also zeroes [zero, zero + zero_bytes) (rounded up to 16 bytes: the caller pads the region): the step's accumulators
+hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, unsigned long long* tl, hipStream_t s,
+                             void* zero = nullptr, size_t zero_bytes = 0);
 hipError_t launch_step_set(int* st, int t, int j, uint64_t noise_key, hipStream_t s);
 // output normalisation (sample.py:133-134); ws: double [B][2] + float [B] zeroed by the launcher
 hipError_t launch_output_normalise(float* x, int B, int64_t n_per_item, int per_item, void* ws, hipStream_t s);

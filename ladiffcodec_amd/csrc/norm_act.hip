@@ -268,6 +268,10 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(const void* x, void*
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] += rr[q][i];
       }
+      if (out8 & 4) {   // tanh of the block's output (unet.py:467: the final ResnetBlock feeds torch.tanh alone)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = act_f(o[i], ACT_TANH);
+      }
       if (out8 & 1) store8_fp8(y, ((size_t)b * L + r) * C + v * 8, o);
       else if (dbg & 8) Vec8<T>::store_nt(y, ((size_t)b * L + r) * C + v * 8, o);
       else if (!(dbg & 4)) Vec8<T>::store(y, ((size_t)b * L + r) * C + v * 8, o);
@@ -392,7 +396,7 @@ hipError_t launch_gn_apply(int dt, const void* x, void* y, const void* residual,
 #undef LDC_GN_ARGS
     return hipGetLastError();
   }
-  if (out8) return hipErrorInvalidValue;   // the generic form has no fp8 output (the planner asks for it only where the column form applies)
+  if (out8) return hipErrorInvalidValue;   // the generic form has no fp8 / tanh output (the planner asks for it only where the column form applies)
   const size_t total = (size_t)B * L * (C / 8);
   int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 8);
   if (blocks < 1) blocks = 1;
