@@ -19,6 +19,8 @@
 // reference's autograd / torch.optim.Adam (tests/golden/train_block.npz, train_unet.npz).  The GEMM-shaped pieces (conv / pointwise
 // forward, dX, dW) run on the exact-fp32 MFMA (convmm_kernel below); their first VALU forms stay as the reference (LDC_TRAIN_VALU=1)
 // and for sequences shorter than 16.  bench.py --config c4 times the step; a bf16 path on conv_fast is the next slice.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "ldc_kernels.h"
@@ -219,22 +221,29 @@ int g_train_valu = 0;   // set by ldc_create from LDC_TRAIN_VALU (process-wide t
 
 typedef float tf32x16 __attribute__((ext_vector_type(16)));
 
-template <int MODE>
+// TI x TJ 32 x 32 blocks per wave (2 x 2 waves): 64 x 64 output tiles (TI = TJ = 1, the round-2 form: four loads and eight MFMAs per
+// thread and reduction chunk) or 128 x 128 (TI = TJ = 2: eight loads per operand and 32 MFMAs per chunk -- the load / LDS / barrier
+// work per MFMA halves; round 3, opt-in: see convmm_big).
+template <int MODE, int TI, int TJ>
 __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float* src, const float* bias, float* out, int B, int Cin, int Cout,
                                                      int Lin, int Lout, int K, int S, int P, int nsplit) {
-  constexpr int PITCH = 64 + 4;
-  __shared__ float As[16][PITCH];
-  __shared__ float Bs[16][PITCH];
+  constexpr int BM = 64 * TI, BN = 64 * TJ;
+  __shared__ float As[16][BM + 4];
+  __shared__ float Bs[16][BN + 4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, i32 = lane & 31, g = lane >> 5;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   // MODE 2: grid z = tap * nsplit + part; every part reduces its own items and adds its tile to the (pre-zeroed) gradient
   const int z = MODE == 2 ? (int)blockIdx.z / nsplit : (int)blockIdx.z, part = MODE == 2 ? (int)blockIdx.z % nsplit : 0;
   // M, N of this mode
   const int M = MODE == 1 ? Cin : Cout;
   const int N = MODE == 0 ? Lout : (MODE == 1 ? Lin : Cin);
-  tf32x16 acc;
+  tf32x16 acc[TI][TJ];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < TJ; ++b2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.f;
   // outer / inner reduction ranges: (tap, channel chunks) for MODE 0 / 1, (item, position chunks) for MODE 2
   const int outer_n = MODE == 2 ? B : K;
   const int inner_n = MODE == 0 ? Cin : (MODE == 1 ? Cout : Lout);
@@ -243,10 +252,10 @@ __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float
   const int nchunk = (inner_n + 15) / 16;
   const int n_it = (outer_hi - outer_lo) * nchunk;
   // the tiles of reduction step `it` -> registers (the global loads of step it + 1 are in flight under the MFMAs of step it)
-  auto fetch = [&](int it, float (&ra)[4], float (&rb)[4]) {
+  auto fetch = [&](int it, float (&ra)[4 * TI], float (&rb)[4 * TJ]) {
     const int outer = outer_lo + it / nchunk, k0 = (it % nchunk) * 16;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 4 * TI; ++p) {
       float v = 0.f;
       const int k = tid & 15, m = (tid >> 4) + 16 * p;
       if (MODE == 2) {   // A(o, l) = dy[b][o][l]: consecutive threads walk l
@@ -259,69 +268,121 @@ __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float
       }
       ra[p] = v;
     }
+    if (MODE == 2) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      float v = 0.f;
-      if (MODE == 0) {          // B(i, l) = x[b][i][l*S + t - P]
-        const int n = tid & 63, k = (tid >> 6) + 4 * p, i = k0 + k, l = n0 + n, pos = l * S + outer - P;
-        if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = src[((size_t)z * Cin + i) * Lin + pos];
-      } else if (MODE == 1) {   // B(o, m) = dy[b][o][(m + P - t) / S]
-        const int n = tid & 63, k = (tid >> 6) + 4 * p, o = k0 + k, mpos = n0 + n, u = mpos + P - outer;
-        if (o < Cout && mpos < Lin && u >= 0 && (S == 1 || u % S == 0)) {
-          const int l = S == 1 ? u : u / S;
-          if (l < Lout) v = src[((size_t)z * Cout + o) * Lout + l];
-        }
-      } else {                  // B(l, i) = x[b][i][l*S + t - P]: consecutive threads walk l   (w carries x in MODE 2)
+      for (int p = 0; p < 4 * TJ; ++p) {   // B(l, i) = x[b][i][l*S + t - P]: consecutive threads walk l   (w carries x in MODE 2)
+        float v = 0.f;
         const int k = tid & 15, n = (tid >> 4) + 16 * p, l = k0 + k, i = n0 + n, pos = l * S + z - P;
         if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = w[((size_t)outer * Cin + i) * Lin + pos];
+        rb[p] = v;
       }
-      rb[p] = v;
+    } else {
+#pragma unroll
+      for (int q = 0; q < TJ; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          float v = 0.f;
+          const int n = (tid & 63) + 64 * q, k = (tid >> 6) + 4 * p;
+          if (MODE == 0) {          // B(i, l) = x[b][i][l*S + t - P]
+            const int i = k0 + k, l = n0 + n, pos = l * S + outer - P;
+            if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = src[((size_t)z * Cin + i) * Lin + pos];
+          } else {                  // B(o, m) = dy[b][o][(m + P - t) / S]
+            const int o = k0 + k, mpos = n0 + n, u = mpos + P - outer;
+            if (o < Cout && mpos < Lin && u >= 0 && (S == 1 || u % S == 0)) {
+              const int l = S == 1 ? u : u / S;
+              if (l < Lout) v = src[((size_t)z * Cout + o) * Lout + l];
+            }
+          }
+          rb[q * 4 + p] = v;
+        }
     }
   };
-  float ra[4], rb[4];
+  float ra[4 * TI], rb[4 * TJ];
   if (n_it > 0) fetch(0, ra, rb);
   for (int it = 0; it < n_it; ++it) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      As[tid & 15][(tid >> 4) + 16 * p] = ra[p];
-      if (MODE == 2) Bs[tid & 15][(tid >> 4) + 16 * p] = rb[p];
-      else Bs[(tid >> 6) + 4 * p][tid & 63] = rb[p];
+    for (int p = 0; p < 4 * TI; ++p) As[tid & 15][(tid >> 4) + 16 * p] = ra[p];
+    if (MODE == 2) {
+#pragma unroll
+      for (int p = 0; p < 4 * TJ; ++p) Bs[tid & 15][(tid >> 4) + 16 * p] = rb[p];
+    } else {
+#pragma unroll
+      for (int q = 0; q < TJ; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) Bs[(tid >> 6) + 4 * p][(tid & 63) + 64 * q] = rb[q * 4 + p];
     }
     __syncthreads();
     if (it + 1 < n_it) fetch(it + 1, ra, rb);
 #pragma unroll
-    for (int sx = 0; sx < 8; ++sx)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * sx + g][32 * wm + i32], Bs[2 * sx + g][32 * wn + i32], acc, 0, 0, 0);
+    for (int sx = 0; sx < 8; ++sx) {
+      float fa[TI], fb[TJ];
+#pragma unroll
+      for (int a = 0; a < TI; ++a) fa[a] = As[2 * sx + g][32 * (wm * TI + a) + i32];
+#pragma unroll
+      for (int b2 = 0; b2 < TJ; ++b2) fb[b2] = Bs[2 * sx + g][32 * (wn * TJ + b2) + i32];
+#pragma unroll
+      for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < TJ; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b2], acc[a][b2], 0, 0, 0);
+    }
     __syncthreads();
   }
   // C/D layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const int n = n0 + 32 * wn + i32;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * g;
-    if (m >= M || n >= N) continue;
-    if (MODE == 0) out[((size_t)z * Cout + m) * Lout + n] = acc[r] + (bias ? bias[m] : 0.f);
-    else if (MODE == 1) out[((size_t)z * Cin + m) * Lin + n] = acc[r];
-    else if (nsplit == 1) out[((size_t)m * Cin + n) * K + z] = acc[r];
-    else atomicAdd(&out[((size_t)m * Cin + n) * K + z], acc[r]);
-  }
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < TJ; ++b2) {
+      const int n = n0 + 32 * (wn * TJ + b2) + i32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * (wm * TI + a) + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (m >= M || n >= N) continue;
+        const float v = acc[a][b2][r];
+        if (MODE == 0) out[((size_t)z * Cout + m) * Lout + n] = v + (bias ? bias[m] : 0.f);
+        else if (MODE == 1) out[((size_t)z * Cin + m) * Lin + n] = v;
+        else if (nsplit == 1) out[((size_t)m * Cin + n) * K + z] = v;
+        else atomicAdd(&out[((size_t)m * Cin + n) * K + z], v);
+      }
+    }
 }
 static bool convmm_ok(int Lin, int Lout) { return !g_train_valu && Lin >= 16 && Lout >= 16; }
+// 128 x 128 tiles (opt-in, LDC_TRAIN_BIG_TILES=1) when both output dimensions fill them reasonably and the grid still covers the
+// chip.  Measured on the full-width step (32 x 2.4 s): 125.1 ms against 122.5 ms with 64 x 64 tiles everywhere -- the kernel is not
+// bound by its loads per MFMA (the fp32 MFMA is 64 cycles; eight resident workgroups per CU cover the rest), so the default stays.
+static bool convmm_big(int M, int N, long tiles_other) {
+  static const bool on = getenv("LDC_TRAIN_BIG_TILES") != nullptr;
+  if (!on) return false;
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * tiles_other;
+  const double fill = (double)M * N / ((double)((M + 127) / 128 * 128) * ((N + 127) / 128 * 128));
+  return M >= 128 && N >= 96 && fill >= 0.7 && t128 >= 192;
+}
 static void convmm_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
                            float* y, hipStream_t s) {
-  hipLaunchKernelGGL(convmm_kernel<0>, dim3((Lout + 63) / 64, (Cout + 63) / 64, B), dim3(256), 0, s, w, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, 1);
+  if (convmm_big(Cout, Lout, B))
+    hipLaunchKernelGGL((convmm_kernel<0, 2, 2>), dim3((Lout + 127) / 128, (Cout + 127) / 128, B), dim3(256), 0, s, w, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, 1);
+  else
+    hipLaunchKernelGGL((convmm_kernel<0, 1, 1>), dim3((Lout + 63) / 64, (Cout + 63) / 64, B), dim3(256), 0, s, w, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, 1);
 }
 static void convmm_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s) {
-  hipLaunchKernelGGL(convmm_kernel<1>, dim3((Lin + 63) / 64, (Cin + 63) / 64, B), dim3(256), 0, s, w, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, 1);
+  if (convmm_big(Cin, Lin, B))
+    hipLaunchKernelGGL((convmm_kernel<1, 2, 2>), dim3((Lin + 127) / 128, (Cin + 127) / 128, B), dim3(256), 0, s, w, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, 1);
+  else
+    hipLaunchKernelGGL((convmm_kernel<1, 1, 1>), dim3((Lin + 63) / 64, (Cin + 63) / 64, B), dim3(256), 0, s, w, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, 1);
 }
 static void convmm_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s) {
   // few output tiles, a long reduction over the items: split the items over workgroups (fp32 atomics into the zeroed gradient:
   // the sum order varies from run to run at the 1e-7 level) until the grid fills the chip
-  const int tiles = ((Cin + 63) / 64) * ((Cout + 63) / 64) * K;
+  const bool big = convmm_big(Cout, Cin, (long)K * B);
+  const int T = big ? 128 : 64;
+  const int tiles = ((Cin + T - 1) / T) * ((Cout + T - 1) / T) * K;
   const int nsplit = std::max(1, std::min(B, (768 + tiles - 1) / tiles));
   if (nsplit > 1) (void)hipMemsetAsync(dw, 0, (size_t)Cout * Cin * K * sizeof(float), s);
-  hipLaunchKernelGGL(convmm_kernel<2>, dim3((Cin + 63) / 64, (Cout + 63) / 64, K * nsplit), dim3(256), 0, s, x, dy, nullptr, dw, B, Cin, Cout, Lin, Lout, K, S,
-                     P, nsplit);
+  if (big)
+    hipLaunchKernelGGL((convmm_kernel<2, 2, 2>), dim3((Cin + 127) / 128, (Cout + 127) / 128, K * nsplit), dim3(256), 0, s, x, dy, nullptr, dw, B, Cin, Cout, Lin, Lout,
+                       K, S, P, nsplit);
+  else
+    hipLaunchKernelGGL((convmm_kernel<2, 1, 1>), dim3((Cin + 63) / 64, (Cout + 63) / 64, K * nsplit), dim3(256), 0, s, x, dy, nullptr, dw, B, Cin, Cout, Lin, Lout, K,
+                       S, P, nsplit);
 }
 
 // ---------------------------------------------------------------------------------------------
