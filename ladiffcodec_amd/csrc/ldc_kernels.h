@@ -245,6 +245,12 @@ hipError_t launch_train_convtr_forward(const float* x, const float* w, const flo
 hipError_t launch_train_convtr_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int r, float* dx,
                                         float* dw, float* db, hipStream_t s);
 hipError_t launch_train_maxscale(const float* x, const float* dy, int B, int64_t n_per_item, float* out, hipStream_t s);
+extern int g_train_fp32_mfma;   // LDC_TRAIN_FP32_MFMA: the round-2 exact-fp32 MFMA GEMMs (convmm_kernel) instead of the split-bf16 ones (train_mm3.hip)
+// split-bf16 (3 x bf16 MFMA, fp32-class accuracy) GEMM shapes of a Conv1d under training: train_mm3.hip
+hipError_t launch_mm3_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
+                              float* y, hipStream_t s);
+hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s);
+hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s);
 extern int g_train_valu;   // LDC_TRAIN_VALU: the training path's GEMM shapes on the VALU reference kernels instead of the fp32 MFMA ones
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, hipStream_t s);
 hipError_t launch_train_ln_forward(const float* x, const float* g, int B, int C, int L, float* y, float* stats, hipStream_t s);

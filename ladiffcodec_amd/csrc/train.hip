@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void ws_backward_kernel(const float* dwn, cons
 // 64 x 64 output tile per workgroup (2 x 2 waves of 32 x 32), reduction in chunks of 16 through LDS (k-major, so the 32 lanes
 // of a fragment read consecutive words).  The VALU forms above stay as the reference (LDC_TRAIN_VALU=1) and for L < 16.
 // ---------------------------------------------------------------------------------------------
+int g_train_fp32_mfma = 0;   // set by ldc_create from LDC_TRAIN_FP32_MFMA
 int g_train_valu = 0;   // set by ldc_create from LDC_TRAIN_VALU (process-wide tuning aid, like g_conv_stamps)
 
 typedef float tf32x16 __attribute__((ext_vector_type(16)));
@@ -251,54 +252,94 @@ __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float
   const int outer_hi = MODE == 2 ? (int)((long long)B * (part + 1) / nsplit) : outer_n;
   const int nchunk = (inner_n + 15) / 16;
   const int n_it = (outer_hi - outer_lo) * nchunk;
-  // the tiles of reduction step `it` -> registers (the global loads of step it + 1 are in flight under the MFMAs of step it)
-  auto fetch = [&](int it, float (&ra)[4 * TI], float (&rb)[4 * TJ]) {
-    const int outer = outer_lo + it / nchunk, k0 = (it % nchunk) * 16;
+  // The tiles of reduction step (outer, chunk) -> registers; the global loads of the next step are in flight under the MFMAs of
+  // the current one.  Addressing is incremental (round 3): everything that depends on the thread and on `outer` (tap / item) is
+  // computed once per `outer` -- the base pointers and the padding / stride predicates -- and a chunk step adds a wave-uniform
+  // stride.  The first form recomputed every 64-bit index and bounds check per load: ~240 VALU instructions per 8 MFMAs, which,
+  // not the loads, is what held these kernels at a third of the fp32 MFMA rate (eight resident waves per SIMD share its VALU).
+  const int kq = tid & 15;                          // reduction index inside a chunk for the k-fastest operands
+  const float* pa[4 * TI];
+  const float* pb[4 * TJ];
+  bool va[4 * TI], vb[4 * TJ];
+  int pos2 = 0;                                     // MODE 2: input position of reduction index kq at chunk 0
+  const long sA = MODE == 0 ? 16L * K : (MODE == 1 ? 16L * Cin * K : 16L);
+  const long sB = MODE == 0 ? 16L * Lin : (MODE == 1 ? 16L * Lout : 16L * S);
+  auto setup_outer = [&](int outer) {
 #pragma unroll
     for (int p = 0; p < 4 * TI; ++p) {
-      float v = 0.f;
-      const int k = tid & 15, m = (tid >> 4) + 16 * p;
-      if (MODE == 2) {   // A(o, l) = dy[b][o][l]: consecutive threads walk l
-        const int o = m0 + m, l = k0 + k;
-        if (o < Cout && l < Lout) v = src[((size_t)outer * Cout + o) * Lout + l];
-      } else {           // A(m, c) = w[o][i][t]: consecutive threads walk the reduction channel
-        const int c = k0 + k;
-        const int o = MODE == 0 ? m0 + m : c, i = MODE == 0 ? c : m0 + m;
-        if (o < Cout && i < Cin) v = w[((size_t)o * Cin + i) * K + outer];
-      }
-      ra[p] = v;
+      const int m = (tid >> 4) + 16 * p;
+      if (MODE == 0) { const int o = m0 + m; va[p] = o < Cout; pa[p] = w + ((size_t)(va[p] ? o : 0) * Cin + kq) * K + outer; }
+      else if (MODE == 1) { const int i = m0 + m; va[p] = i < Cin; pa[p] = w + ((size_t)kq * Cin + (va[p] ? i : 0)) * K + outer; }
+      else { const int o = m0 + m; va[p] = o < Cout; pa[p] = src + ((size_t)outer * Cout + (va[p] ? o : 0)) * Lout + kq; }
     }
     if (MODE == 2) {
+      pos2 = kq * S + z - P;
 #pragma unroll
-      for (int p = 0; p < 4 * TJ; ++p) {   // B(l, i) = x[b][i][l*S + t - P]: consecutive threads walk l   (w carries x in MODE 2)
-        float v = 0.f;
-        const int k = tid & 15, n = (tid >> 4) + 16 * p, l = k0 + k, i = n0 + n, pos = l * S + z - P;
-        if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = w[((size_t)outer * Cin + i) * Lin + pos];
-        rb[p] = v;
+      for (int p = 0; p < 4 * TJ; ++p) {
+        const int i = n0 + (tid >> 4) + 16 * p;
+        vb[p] = i < Cin;
+        pb[p] = w + ((size_t)outer * Cin + (vb[p] ? i : 0)) * Lin + pos2;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < TJ; ++q) {
+        const int n = (tid & 63) + 64 * q;
+        bool ok;
+        long off;
+        if (MODE == 0) {          // B(i, l) = x[b][i][l*S + t - P]
+          const int l = n0 + n, pos = l * S + outer - P;
+          ok = l < Lout && pos >= 0 && pos < Lin;
+          off = ok ? pos : 0;
+        } else {                  // B(o, m) = dy[b][o][(m + P - t) / S]
+          const int mpos = n0 + n, u = mpos + P - outer;
+          ok = mpos < Lin && u >= 0 && (S == 1 || u % S == 0);
+          const int l = ok ? (S == 1 ? u : u / S) : 0;
+          ok = ok && l < Lout;
+          off = ok ? l : 0;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int kk = (tid >> 6) + 4 * p;
+          vb[q * 4 + p] = ok;
+          pb[q * 4 + p] = src + ((size_t)z * (MODE == 0 ? Cin : Cout) + kk) * (MODE == 0 ? Lin : Lout) + off;
+        }
+      }
+    }
+  };
+  int f_outer = outer_lo, f_chunk = 0;              // fetch cursor
+  auto fetch = [&](float (&ra)[4 * TI], float (&rb)[4 * TJ]) {
+    const int k0 = f_chunk * 16;
+    const bool ka = k0 + kq < inner_n;
+#pragma unroll
+    for (int p = 0; p < 4 * TI; ++p) {
+      ra[p] = (va[p] && ka) ? *pa[p] : 0.f;
+      pa[p] += sA;
+    }
+    if (MODE == 2) {
+      const int pos = pos2 + k0 * S;
+      const bool kb = ka && pos >= 0 && pos < Lin;
+#pragma unroll
+      for (int p = 0; p < 4 * TJ; ++p) {
+        rb[p] = (vb[p] && kb) ? *pb[p] : 0.f;
+        pb[p] += sB;
       }
     } else {
 #pragma unroll
       for (int q = 0; q < TJ; ++q)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          float v = 0.f;
-          const int n = (tid & 63) + 64 * q, k = (tid >> 6) + 4 * p;
-          if (MODE == 0) {          // B(i, l) = x[b][i][l*S + t - P]
-            const int i = k0 + k, l = n0 + n, pos = l * S + outer - P;
-            if (i < Cin && l < Lout && pos >= 0 && pos < Lin) v = src[((size_t)z * Cin + i) * Lin + pos];
-          } else {                  // B(o, m) = dy[b][o][(m + P - t) / S]
-            const int o = k0 + k, mpos = n0 + n, u = mpos + P - outer;
-            if (o < Cout && mpos < Lin && u >= 0 && (S == 1 || u % S == 0)) {
-              const int l = S == 1 ? u : u / S;
-              if (l < Lout) v = src[((size_t)z * Cout + o) * Lout + l];
-            }
-          }
-          rb[q * 4 + p] = v;
+          const bool kb = k0 + (tid >> 6) + 4 * p < inner_n;
+          rb[q * 4 + p] = (vb[q * 4 + p] && kb) ? *pb[q * 4 + p] : 0.f;
+          pb[q * 4 + p] += sB;
         }
+    }
+    if (++f_chunk == nchunk) {
+      f_chunk = 0;
+      if (++f_outer < outer_hi) setup_outer(f_outer);
     }
   };
   float ra[4 * TI], rb[4 * TJ];
-  if (n_it > 0) fetch(0, ra, rb);
+  if (n_it > 0) { setup_outer(f_outer); fetch(ra, rb); }
   for (int it = 0; it < n_it; ++it) {
 #pragma unroll
     for (int p = 0; p < 4 * TI; ++p) As[tid & 15][(tid >> 4) + 16 * p] = ra[p];
@@ -312,7 +353,7 @@ __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float
         for (int p = 0; p < 4; ++p) Bs[(tid >> 6) + 4 * p][(tid & 63) + 64 * q] = rb[q * 4 + p];
     }
     __syncthreads();
-    if (it + 1 < n_it) fetch(it + 1, ra, rb);
+    if (it + 1 < n_it) fetch(ra, rb);
 #pragma unroll
     for (int sx = 0; sx < 8; ++sx) {
       float fa[TI], fb[TJ];
@@ -358,18 +399,21 @@ static bool convmm_big(int M, int N, long tiles_other) {
 }
 static void convmm_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
                            float* y, hipStream_t s) {
+  if (!g_train_fp32_mfma) { (void)launch_mm3_forward(x, w, bias, B, Cin, Cout, Lin, Lout, K, S, P, y, s); return; }
   if (convmm_big(Cout, Lout, B))
     hipLaunchKernelGGL((convmm_kernel<0, 2, 2>), dim3((Lout + 127) / 128, (Cout + 127) / 128, B), dim3(256), 0, s, w, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, 1);
   else
     hipLaunchKernelGGL((convmm_kernel<0, 1, 1>), dim3((Lout + 63) / 64, (Cout + 63) / 64, B), dim3(256), 0, s, w, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, 1);
 }
 static void convmm_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s) {
+  if (!g_train_fp32_mfma) { (void)launch_mm3_dx(dy, w, B, Cin, Cout, Lin, Lout, K, S, P, dx, s); return; }
   if (convmm_big(Cin, Lin, B))
     hipLaunchKernelGGL((convmm_kernel<1, 2, 2>), dim3((Lin + 127) / 128, (Cin + 127) / 128, B), dim3(256), 0, s, w, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, 1);
   else
     hipLaunchKernelGGL((convmm_kernel<1, 1, 1>), dim3((Lin + 63) / 64, (Cin + 63) / 64, B), dim3(256), 0, s, w, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, 1);
 }
 static void convmm_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s) {
+  if (!g_train_fp32_mfma) { (void)launch_mm3_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s); return; }
   // few output tiles, a long reduction over the items: split the items over workgroups (fp32 atomics into the zeroed gradient:
   // the sum order varies from run to run at the 1e-7 level) until the grid fills the chip
   const bool big = convmm_big(Cout, Cin, (long)K * B);

@@ -1,0 +1,489 @@
+// LaDiffCodec on MI355X -- training GEMMs of the diffusion UNet on the bf16 MFMA with fp32-class accuracy (round 3).
+//
+// What this replaces: the three GEMM shapes of every Conv1d of Unet1D under `loss.backward()` (reference: srcs/modules/unet.py:422-469
+// through torch autograd; srcs/train.py:170-205 is the step).  Round 2 ran them on v_mfma_f32_32x32x2_f32 (convmm_kernel in train.hip,
+// kept as LDC_TRAIN_FP32_MFMA=1): exact fp32, but that instruction is 1/16 of the bf16 rate and the kernel reached a third of it.
+//
+// Here every fp32 operand a is split into two bf16 numbers, a = hi + lo + O(2^-17 |a|) with hi = bf16(a), lo = bf16(a - hi), and a
+// product is three bf16 MFMAs accumulated in fp32:   a b ~= hi_a hi_b + hi_a lo_b + lo_a hi_b   (the dropped lo_a lo_b and the two
+// residuals are 2^-16 |a b| each, random in sign: the sums agree with an fp32 fmaf chain to ~1e-6 relative in the tests, well inside
+// the tolerance the training parity tests already carry against the reference's own autograd).  Three v_mfma_f32_32x32x16_bf16 cost
+// 96 cycles for 16 reduction steps where the fp32 MFMA takes 512: the bound moves from the matrix pipe to staging, so the kernel is
+// built around that:
+//   * 128 x 128 output tile per workgroup (2 x 2 waves of 64 x 64 = 2 x 2 MFMA blocks), reduction chunks of 32, LDS double-buffered
+//     (4 planes -- A hi / A lo / B hi / B lo -- of 128 rows x 64 B, 16-byte slots XOR-swizzled by (row >> 2) & 3: fragment reads and
+//     staging writes are conflict-free ds_read/write_b128), one barrier per chunk, the global loads of chunk i + 1 in flight under
+//     the MFMAs of chunk i;
+//   * the batch is folded into the GEMM's N (columns = (item, position)), so the L = 75 / 150 levels fill their tiles;
+//   * weights are split once per use by a pack kernel into [tap][row][k/8][hi x 8 | lo x 8] (rows and k zero-padded to the tile), so
+//     the A operand of forward / dX is four 16-byte loads per thread and chunk and needs no arithmetic;
+//   * activations ([B, C, L] fp32, the training layout) are gathered with the positions along the lanes (coalesced), 16 channels per
+//     thread, split in registers and written as whole 16-byte k-vectors.
+//   MODE 0 forward  y  [Cout x (B Lout)] = sum_t  W_t   [Cout x Cin]  . x  shifted by t    (+ bias)
+//   MODE 1 dX       dx [Cin  x (B Lin)]  = sum_t  W_t^T [Cin x Cout]  . dy shifted by -t
+//   MODE 2 dW       dW_t [Cout x Cin]    = sum_b  dy[b] [Cout x Lout] . x[b]^T shifted by t     (grid z = tap * nsplit + part)
+// Roofline: MFMA-bound in the limit (3 x the bf16 flops: 2.5 PFLOP/s / 3 = 833 TFLOP/s of fp32-equivalent work); measured numbers in
+// DESIGN.md (training row) and profiles/.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+
+#include "ldc_kernels.h"
+
+namespace ldc {
+namespace mm3 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (not HIP's u32x4: a struct of unions, which kept register arrays of it in scratch / LDS)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned: the hardware takes unaligned dwordx4 loads
+union V8 {
+  u32x4 u;
+  bf16x8 v;
+  __bf16 e[8];
+};
+union V4 {
+  u32x2 u;
+  __bf16 e[4];
+};
+
+// values are passed one by one: an array parameter makes the compiler promote the caller's staging registers to LDS
+#define LDC_SPLIT1(f, H, L, j) { const __bf16 a_ = (__bf16)(f); (H).e[j] = a_; (L).e[j] = (__bf16)((f) - (float)a_); }
+__device__ __forceinline__ void split8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7, u32x4& hi, u32x4& lo) {
+  V8 h, l;
+  LDC_SPLIT1(f0, h, l, 0) LDC_SPLIT1(f1, h, l, 1) LDC_SPLIT1(f2, h, l, 2) LDC_SPLIT1(f3, h, l, 3)
+  LDC_SPLIT1(f4, h, l, 4) LDC_SPLIT1(f5, h, l, 5) LDC_SPLIT1(f6, h, l, 6) LDC_SPLIT1(f7, h, l, 7)
+  hi = h.u;
+  lo = l.u;
+}
+__device__ __forceinline__ void split4(float f0, float f1, float f2, float f3, u32x2& hi, u32x2& lo) {
+  V4 h, l;
+  LDC_SPLIT1(f0, h, l, 0) LDC_SPLIT1(f1, h, l, 1) LDC_SPLIT1(f2, h, l, 2) LDC_SPLIT1(f3, h, l, 3)
+  hi = h.u;
+  lo = l.u;
+}
+
+// w [Cout][Cin][K] fp32 -> pw [K][MP][RP / 8][hi x 8 | lo x 8] bf16.  TR = 0: rows = Cout, k = Cin (forward); TR = 1: rows = Cin, k = Cout (dX).
+template <int TR>
+__global__ __launch_bounds__(256) void mm3_pack_kernel(const float* w, int Cin, int Cout, int K, int MP, int RP, u32x4* pw) {
+  const int M = TR ? Cin : Cout, R = TR ? Cout : Cin, oct = RP / 8;
+  const long total = (long)K * MP * oct;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    // TR = 0: the octet index runs fastest (consecutive threads read consecutive channels of one output row);
+    // TR = 1: the row (= input channel) runs fastest within a tap, for the same reason
+    int t, row, q;
+    if (TR == 0) { q = (int)(idx % oct); row = (int)((idx / oct) % MP); t = (int)(idx / ((long)oct * MP)); }
+    else { row = (int)(idx % MP); q = (int)((idx / MP) % oct); t = (int)(idx / ((long)oct * MP)); }
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = q * 8 + j;
+      const bool ok = row < M && k < R;
+      const int o = TR ? k : row, i = TR ? row : k;
+      f[j] = ok ? w[((size_t)o * Cin + i) * K + t] : 0.f;
+    }
+    u32x4 hi, lo;
+    split8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], hi, lo);
+    u32x4* dst = pw + (((size_t)t * MP + row) * oct + q) * 2;
+    dst[0] = hi;
+    dst[1] = lo;
+  }
+}
+
+// TAIL (MODE 0 / 1): the reduction extent is not a multiple of 32 (never in the UNet itself): the last chunk's loads are clamped and masked;
+// TAIL (MODE 2): Lout is not a multiple of 4 (the L = 150 / 75 levels): dy is read as dwords instead of dwordx4
+template <int MODE, bool TAIL>
+__global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ Asrc, const float* __restrict__ Bsrc, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
+                                                     int nsplit, int MP, int RP) {
+  __shared__ u32x4 lds[2][4][512];   // [stage][A hi, A lo, B hi, B lo][row * 4 + (slot ^ swizzle)]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, i32 = lane & 31, g = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int z = MODE == 2 ? (int)blockIdx.z / nsplit : 0, part = MODE == 2 ? (int)blockIdx.z % nsplit : 0;
+  const int M = MODE == 1 ? Cin : Cout;
+  const int Lcol = MODE == 0 ? Lout : Lin;                       // MODE 0 / 1: positions per item along N
+  const int N = MODE == 2 ? Cin : B * Lcol;
+  const int red = MODE == 0 ? Cin : (MODE == 1 ? Cout : Lout);    // inner reduction extent
+  const int Lsrc = MODE == 0 ? Lin : Lout;                        // MODE 0 / 1: row length of the gathered activation
+  // reduction steps of this workgroup, flattened as (outer, chunk): MODE 2 takes the items of its part (grid z = tap * nsplit + part),
+  // MODE 0 / 1 an even share of the (tap, channel chunk) steps when the output tiles alone do not fill the chip (grid z = part;
+  // parts add into the zeroed output)
+  const int nchunk = (red + 31) / 32;
+  const int outer_lo = MODE == 2 ? (int)((long long)B * part / nsplit) : 0;
+  const int outer_hi = MODE == 2 ? (int)((long long)B * (part + 1) / nsplit) : K;
+  const int kpart = MODE == 2 ? 0 : (int)blockIdx.z;
+  const int it_all = (outer_hi - outer_lo) * nchunk;
+  const int it_begin = MODE == 2 ? 0 : (int)((long long)it_all * kpart / nsplit);
+  const int n_it = (MODE == 2 ? it_all : (int)((long long)it_all * (kpart + 1) / nsplit)) - it_begin;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.f;
+
+  // ---- staging ----
+  // MODE 0 / 1: thread -> (row / column r = tid & 127, k half h = tid >> 7: 16 reduction indices = LDS slots 2h, 2h + 1)
+  // MODE 2:     thread -> (row 32 p + (tid >> 3), four consecutive positions 4 (tid & 7) .. + 3 = half of slot (tid & 7) >> 1), p = 0..3
+  // Two register sets: a chunk is loaded two iterations before it is written to LDS (one chunk of MFMAs, 0.3 us, does not cover an
+  // HBM / far-L2 round trip with two workgroups per CU).
+  struct Stage {
+    u32x4 a0, a1, a2, a3;   // MODE 0 / 1: packed weights (hi, lo of two k-octets)
+    float a[16];            // MODE 2: dy
+    float b[16];            // activations
+    int nv;                 // TAIL: valid reduction indices of this thread's 16
+    bool ok;                // MODE 0 / 1: this thread's column is inside the item for the chunk's tap (applied when the set is
+                            // written to LDS: a select right after the load would wait for it inside fetch)
+  };
+  const int r128 = tid & 127, h = tid >> 7;
+  int cb = 0, cl = 0;       // MODE 0 / 1: (item, position) of this thread's column
+  bool cvalid = false;
+  if (MODE != 2) {
+    const int n = n0 + r128;
+    cvalid = n < N;
+    cb = cvalid ? n / Lcol : 0;
+    cl = cvalid ? n - cb * Lcol : 0;
+  }
+  const u32x4* pA = nullptr;
+  const float* pB = nullptr;
+  bool bok = false;
+  // MODE 2: per-pass row pointers (advanced by a chunk of positions), row predicates
+  // (32-bit element offsets from the item's wave-uniform base: eight 64-bit pointers spilled)
+  int qa[4] = {0, 0, 0, 0}, qb[4] = {0, 0, 0, 0};
+  int a_last = 0;
+  const float* baseA = nullptr;
+  const float* baseB = nullptr;
+  bool oka[4] = {false, false, false, false}, okb[4] = {false, false, false, false};
+  int f_outer = outer_lo + it_begin / nchunk, f_chunk = it_begin % nchunk;
+
+  auto setup_outer = [&](int outer) {
+    if (MODE != 2) {
+      pA = (const u32x4*)Asrc + (((size_t)outer * MP + m0 + r128) * (RP / 8) + 2 * h) * 2;
+      int pos;
+      if (MODE == 0) {
+        pos = cl * S + outer - P;
+        bok = cvalid && pos >= 0 && pos < Lin;
+      } else {
+        const int u = cl + P - outer;
+        bok = cvalid && u >= 0 && (S == 1 || u % S == 0);
+        pos = bok ? (S == 1 ? u : u / S) : 0;
+        bok = bok && pos < Lout;
+      }
+      pB = Bsrc + ((size_t)cb * red + 16 * h) * Lsrc + (bok ? pos : 0);
+      pA += 8 * f_chunk;                       // (non-zero only for the first step of a split reduction)
+      pB += (size_t)32 * f_chunk * Lsrc;
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = 32 * p + (tid >> 3);
+        const int o = m0 + row, i = n0 + row;
+        oka[p] = o < Cout;
+        okb[p] = i < Cin;
+        qa[p] = (oka[p] ? o : 0) * Lout + 4 * (tid & 7);
+        qb[p] = (okb[p] ? i : 0) * Lin;
+      }
+      baseA = (const float*)Asrc + (size_t)outer * Cout * Lout;
+      a_last = Cout * Lout - 4;
+      baseB = Bsrc + (size_t)outer * Cin * Lin;
+    }
+  };
+  // Loads are unconditional wherever the address is known to be inside the tensor (the value is then selected against the padding /
+  // tail predicate): a predicated load costs an exec-mask branch each, and sixteen of them per chunk showed in the issue slots.
+  auto fetch = [&](Stage& r) {
+    const int k0 = f_chunk * 32;
+    if (MODE != 2) {
+      r.a0 = pA[0]; r.a1 = pA[1]; r.a2 = pA[2]; r.a3 = pA[3];
+      pA += 8;
+      // straight-line on purpose: with a branch in here the compiler's s_waitcnt bookkeeping falls back to "everything older", which
+      // drains the set that was loaded one iteration ago together with the one just issued
+      r.ok = bok;
+      r.nv = red - (k0 + 16 * h);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float* q = pB + (size_t)j * Lsrc;
+        if (TAIL) q = j < r.nv ? q : Bsrc;
+        r.b[j] = *q;
+      }
+      pB += (size_t)32 * Lsrc;
+    } else {
+      // dW, branch-free as well: dy as one dwordx4 per pass when the rows keep it dword-x4-safe to clamp (TAIL == false: Lout % 4 == 0,
+      // so a thread's four positions are all inside or all outside the row, and the clamp to the end of the tensor only ever moves
+      // fully masked ones), else four dwords clamped into the row; x always as dwords clamped into the row (the tap shift makes the
+      // first / last thread of a row straddle the padding).  Masks are applied in store() from the chunk origin kept with the set.
+      const int lq = k0 + 4 * (tid & 7);
+      r.nv = lq;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (!TAIL) {
+          const f32x4u v = *(const f32x4u*)(baseA + min(qa[p] + k0, a_last));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r.a[4 * p + e] = v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r.a[4 * p + e] = baseA[qa[p] - 4 * (tid & 7) + min(lq + e, Lout - 1)];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r.b[4 * p + e] = baseB[qb[p] + min(max((lq + e) * S + z - P, 0), Lin - 1)];
+      }
+    }
+    if (++f_chunk == nchunk) {
+      f_chunk = 0;
+      if (++f_outer < outer_hi) setup_outer(f_outer);
+    }
+  };
+  auto store = [&](const Stage& r, int st) {
+    if (MODE != 2) {
+      const int sw = (r128 >> 2) & 3;
+      lds[st][0][r128 * 4 + ((2 * h) ^ sw)] = r.a0;
+      lds[st][1][r128 * 4 + ((2 * h) ^ sw)] = r.a1;
+      lds[st][0][r128 * 4 + ((2 * h + 1) ^ sw)] = r.a2;
+      lds[st][1][r128 * 4 + ((2 * h + 1) ^ sw)] = r.a3;
+      u32x4 hi, lo;
+      float b[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) b[j] = (r.ok && (!TAIL || j < r.nv)) ? r.b[j] : 0.f;
+      split8(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], hi, lo);
+      lds[st][2][r128 * 4 + ((2 * h) ^ sw)] = hi;
+      lds[st][3][r128 * 4 + ((2 * h) ^ sw)] = lo;
+      split8(b[8], b[9], b[10], b[11], b[12], b[13], b[14], b[15], hi, lo);
+      lds[st][2][r128 * 4 + ((2 * h + 1) ^ sw)] = hi;
+      lds[st][3][r128 * 4 + ((2 * h + 1) ^ sw)] = lo;
+    } else {
+      const int slot = (tid & 7) >> 1, half = tid & 1;
+      const int lq = r.nv, pos0 = lq * S + z - P;
+      // (uniform per chunk up to the halo) interior: every position of the chunk is inside both rows
+      const bool edge = lq + 4 > Lout || pos0 < 0 || pos0 + 3 * S >= Lin;
+      float ma[4], mb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ma[e] = lq + e < Lout ? 1.f : 0.f;
+        const int pos = pos0 + e * S;
+        mb[e] = (pos >= 0 && pos < Lin) ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = 32 * p + (tid >> 3), sw = (row >> 2) & 3;
+        const int at = (row * 4 + (slot ^ sw)) * 2 + half;     // in 8-byte units
+        u32x2 hi, lo;
+        // (rows past M / N are clamped reads of row 0: they only reach output rows / columns that are never stored; the clamped
+        // loads are of real tensor data, so the 0 / 1 multiply is a safe mask)
+        if (edge) split4(r.a[4 * p] * ma[0], r.a[4 * p + 1] * ma[1], r.a[4 * p + 2] * ma[2], r.a[4 * p + 3] * ma[3], hi, lo);
+        else split4(r.a[4 * p], r.a[4 * p + 1], r.a[4 * p + 2], r.a[4 * p + 3], hi, lo);
+        ((u32x2*)lds[st][0])[at] = hi;
+        ((u32x2*)lds[st][1])[at] = lo;
+        if (edge) split4(r.b[4 * p] * mb[0], r.b[4 * p + 1] * mb[1], r.b[4 * p + 2] * mb[2], r.b[4 * p + 3] * mb[3], hi, lo);
+        else split4(r.b[4 * p], r.b[4 * p + 1], r.b[4 * p + 2], r.b[4 * p + 3], hi, lo);
+        ((u32x2*)lds[st][2])[at] = hi;
+        ((u32x2*)lds[st][3])[at] = lo;
+      }
+    }
+  };
+  const int swl = (i32 >> 2) & 3;
+  auto compute = [&](int st) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int slot = ((2 * ks + g) ^ swl);
+      V8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int row = 64 * wm + 32 * a + i32;
+        ah[a].u = lds[st][0][row * 4 + slot];
+        al[a].u = lds[st][1][row * 4 + slot];
+      }
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int row = 64 * wn + 32 * b2 + i32;
+        bh[b2].u = lds[st][2][row * 4 + slot];
+        bl[b2].u = lds[st][3][row * 4 + slot];
+      }
+      // term-major: four independent accumulators between two MFMAs into the same one
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a].v, bh[b2].v, acc[a][b2], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bl[b2].v, acc[a][b2], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bh[b2].v, acc[a][b2], 0, 0, 0);
+    }
+  };
+
+  if (true) {
+    Stage X, Y;
+    // iteration `it`: LDS[it & 1] holds chunk it, X / Y hold chunks it + 1 and it + 2 (X the odd ones)
+    int it = 0;
+    if (n_it >= 5) {
+      // steady state, its prologue AND its loop inside one branch, without conditions: every path on which a fetch may not have been
+      // issued makes the compiler's s_waitcnt bookkeeping assume it was not, i.e. drain the set that was issued an iteration ago
+      // TOGETHER with the one just issued (seen in the ISA as vmcnt(15..0) where vmcnt(35..20) is what the data flow needs)
+      setup_outer(f_outer);
+      fetch(X);
+      store(X, 0);
+      fetch(X);
+      fetch(Y);
+      __syncthreads();
+      for (; it + 4 < n_it; it += 2) {
+        compute(0);
+        store(X, 1);
+        fetch(X);
+        __syncthreads();
+        compute(1);
+        store(Y, 0);
+        fetch(Y);
+        __syncthreads();
+      }
+    } else {
+      if (n_it > 0) {
+        setup_outer(f_outer);
+        fetch(X);
+        store(X, 0);
+        if (n_it > 1) fetch(X);
+        if (n_it > 2) fetch(Y);
+      }
+      __syncthreads();
+    }
+    for (; it < n_it; it += 2) {
+      compute(0);
+      if (it + 1 < n_it) store(X, 1);
+      if (it + 3 < n_it) fetch(X);
+      __syncthreads();
+      if (it + 1 >= n_it) break;
+      compute(1);
+      if (it + 2 < n_it) store(Y, 0);
+      if (it + 4 < n_it) fetch(Y);
+      __syncthreads();
+    }
+  } else {
+    // dW: one register set (two do not fit 256 registers next to the row offsets): the loads of chunk it + 1 fly under chunk it
+    Stage X;
+    if (n_it > 0) {
+      setup_outer(f_outer);
+      fetch(X);
+      store(X, 0);
+    }
+    __syncthreads();
+    for (int it = 0; it < n_it; ++it) {
+      if (it + 1 < n_it) fetch(X);
+      compute(it & 1);
+      if (it + 1 < n_it) store(X, (it & 1) ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // C/D layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int b2 = 0; b2 < 2; ++b2) {
+    const int n = n0 + 64 * wn + 32 * b2 + i32;
+    if (n >= N) continue;
+    float* colp;
+    size_t rstride;
+    if (MODE == 2) {
+      colp = out + (size_t)n * K + z;
+      rstride = (size_t)Cin * K;
+    } else {
+      const int bb = n / Lcol, l = n - bb * Lcol;
+      colp = out + (size_t)bb * M * Lcol + l;
+      rstride = (size_t)Lcol;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 64 * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (m >= M) continue;
+        const float v = acc[a][b2][r];
+        const float add = (MODE == 0 && bias && kpart == 0) ? bias[m] : 0.f;
+        if (nsplit == 1) colp[(size_t)m * rstride] = v + add;
+        else atomicAdd(&colp[(size_t)m * rstride], v + add);
+      }
+  }
+}
+
+}  // namespace mm3
+using namespace mm3;
+namespace {
+// packed-weight workspace (one training context per process; grows on demand, never inside a capture)
+void* g_pw = nullptr;
+size_t g_pw_bytes = 0;
+u32x4* pack_workspace(size_t bytes, hipStream_t s) {
+  if (bytes > g_pw_bytes) {
+    (void)hipStreamSynchronize(s);
+    if (g_pw) (void)hipFree(g_pw);
+    g_pw = nullptr;
+    g_pw_bytes = 0;
+    const size_t want = std::max(bytes + bytes / 2, (size_t)32 << 20);
+    if (hipMalloc(&g_pw, want) != hipSuccess) return nullptr;
+    g_pw_bytes = want;
+  }
+  return (u32x4*)g_pw;
+}
+inline int up(int v, int q) { return (v + q - 1) / q * q; }
+// forward / dX: parts of the (tap, channel chunk) reduction per output tile.  The chip holds 512 workgroups (two per CU); below
+// ~0.75 of that the tiles are split, as long as a part keeps >= 16 steps (the two-deep prefetch needs a few to reach its stride).
+inline int reduction_split(long tiles, int steps) {
+  static const int forced = getenv("LDC_MM3_KSPLIT") ? atoi(getenv("LDC_MM3_KSPLIT")) : 0;
+  if (forced > 0) return std::max(1, std::min(forced, steps));
+  if (tiles >= 384) return 1;
+  const int want = (int)((512 + tiles - 1) / tiles);
+  return std::max(1, std::min({want, steps / 16, 8}));
+}
+
+}  // namespace
+
+hipError_t launch_mm3_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
+                              float* y, hipStream_t s) {
+  const int MP = up(Cout, 128), RP = up(Cin, 32);
+  u32x4* pw = pack_workspace((size_t)K * MP * RP * 4, s);
+  if (!pw) return hipErrorOutOfMemory;
+  const long total = (long)K * MP * (RP / 8);
+  hipLaunchKernelGGL((mm3_pack_kernel<0>), dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, w, Cin, Cout, K, MP, RP, pw);
+  const long N = (long)B * Lout;
+  const int ks = reduction_split((long)((N + 127) / 128) * (MP / 128), K * (RP / 32));
+  if (ks > 1) (void)hipMemsetAsync(y, 0, (size_t)B * Cout * Lout * sizeof(float), s);
+  const dim3 grid((unsigned)((N + 127) / 128), MP / 128, ks);
+  if (Cin % 32 == 0)
+    hipLaunchKernelGGL((mm3_kernel<0, false>), grid, dim3(256), 0, s, (const void*)pw, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+  else
+    hipLaunchKernelGGL((mm3_kernel<0, true>), grid, dim3(256), 0, s, (const void*)pw, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+  return hipGetLastError();
+}
+hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s) {
+  const int MP = up(Cin, 128), RP = up(Cout, 32);
+  u32x4* pw = pack_workspace((size_t)K * MP * RP * 4, s);
+  if (!pw) return hipErrorOutOfMemory;
+  const long total = (long)K * MP * (RP / 8);
+  hipLaunchKernelGGL((mm3_pack_kernel<1>), dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, w, Cin, Cout, K, MP, RP, pw);
+  const long N = (long)B * Lin;
+  const int ks = reduction_split((long)((N + 127) / 128) * (MP / 128), K * (RP / 32));
+  if (ks > 1) (void)hipMemsetAsync(dx, 0, (size_t)B * Cin * Lin * sizeof(float), s);
+  const dim3 grid((unsigned)((N + 127) / 128), MP / 128, ks);
+  if (Cout % 32 == 0)
+    hipLaunchKernelGGL((mm3_kernel<1, false>), grid, dim3(256), 0, s, (const void*)pw, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+  else
+    hipLaunchKernelGGL((mm3_kernel<1, true>), grid, dim3(256), 0, s, (const void*)pw, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+  return hipGetLastError();
+}
+hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s) {
+  // few output tiles, a long reduction over the items: split the items over workgroups (fp32 atomics into the zeroed gradient) until
+  // the grid fills the chip (two workgroups per CU)
+  const int tiles = ((Cin + 127) / 128) * ((Cout + 127) / 128) * K;
+  const int nsplit = std::max(1, std::min(B, (512 + tiles - 1) / tiles));
+  if (nsplit > 1) (void)hipMemsetAsync(dw, 0, (size_t)Cout * Cin * K * sizeof(float), s);
+  const dim3 grid((Cin + 127) / 128, (Cout + 127) / 128, K * nsplit);
+  if (Lout % 4 == 0)
+    hipLaunchKernelGGL((mm3_kernel<2, false>), grid, dim3(256), 0, s, (const void*)dy, x, nullptr, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0);
+  else
+    hipLaunchKernelGGL((mm3_kernel<2, true>), grid, dim3(256), 0, s, (const void*)dy, x, nullptr, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0);
+  return hipGetLastError();
+}
+
+}  // namespace ldc

@@ -71,7 +71,8 @@ class Engine:
         self._finalized = False
 
     def set_option(self, name: str, value: int) -> None:
-        """ldc_set_option: 'split' (chains per batch), 'lstm_stream' (no cooperative LSTM), 'side_streams'."""
+        """ldc_set_option: 'split' (chains per batch), 'lstm_stream' (no cooperative LSTM), 'side_streams', 'fp8_act',
+        'train_fp32_mfma' (training GEMMs on the exact-fp32 MFMA instead of the split-bf16 path; process-wide)."""
         L.check(self.lib.ldc_set_option(self._ctx, name.encode(), int(value)))
 
     def host_stats(self, reset: bool = True):

@@ -1,6 +1,10 @@
 """GPU training-step slice through the C ABI: q_sample, the p_losses objective and Block forward / backward against the
 reference's own autograd results (tests/golden/train_block.npz) and, at a wider shape, against autograd of the oracle.
-Tolerance 1e-4 relative (fp32 kernels; different reduction orders only)."""
+Tolerance 1e-4 relative.  The GEMM shapes run on the split-bf16 MFMA path by default (csrc/train_mm3.hip: three bf16 MFMAs per
+product, 2^-16-class products, 4e-6 of a tensor's maximum measured) and, with the option train_fp32_mfma, on the exact-fp32 MFMA;
+every test here runs on both (`gemm` fixture).  Two assertions are conditioned on it, both for the same reason -- they look at a
+DISCONTINUOUS function of the network output: the L1 objective's gradient is sign(pred - noise) (one flipped element of 3e5 moves
+final_conv.bias by 1.8e-3 of its maximum), and Adam's first step is lr * sign(g)."""
 import numpy as np
 import pytest
 import torch
@@ -13,6 +17,15 @@ from helpers import T, load_golden  # noqa: E402
 from gpu_common import engine, rel  # noqa: E402
 
 TOL = 1e-4
+
+
+@pytest.fixture(params=["split_bf16", "fp32_mfma"], autouse=True)
+def gemm(request):
+    """both GEMM paths under every test of this file (the option is process-wide: restored to the default afterwards)"""
+    e = engine("r84", "f32")
+    e.set_option("train_fp32_mfma", int(request.param == "fp32_mfma"))
+    yield request.param
+    e.set_option("train_fp32_mfma", 0)
 
 
 def test_block_forward_backward_reference_vectors():
@@ -168,21 +181,32 @@ def test_assembled_unet_forward_backward_reference_vectors():
     assert set(grads) == set(sd), (set(sd) - set(grads), set(grads) - set(sd))
     worst = max((rel(grads[k].cpu().numpy().reshape(g["g." + k].shape), g["g." + k]), k) for k in sd)
     assert worst[0] < 2e-4, worst
-    # one optimiser step over the flat buffers (the layout parallel.allreduce_gradients reduces)
+    # one optimiser step over the flat buffers (the layout parallel.allreduce_gradients reduces).  Adam's first step is
+    # lr * g / (|g| + 1e-8): it maps a gradient element to +-lr whatever its size, so it amplifies any rounding of the elements that are
+    # ~0 relative to their tensor.  The kernel is therefore pinned on the REFERENCE's gradients (tight), and the step from this path's
+    # own gradients (split-bf16 GEMMs: 2^-16-class products, csrc/train_mm3.hip) is required to agree wherever the gradient is not
+    # negligible against its tensor's scale.
     names = sorted(sd)
-    flat_p = torch.cat([sd[k].reshape(-1) for k in names]).cuda().contiguous()
-    flat_g = torch.cat([grads[k].reshape(-1) for k in names]).contiguous()
-    ref_p = torch.nn.Parameter(flat_p.cpu().clone())
+    flat_p0 = torch.cat([sd[k].reshape(-1) for k in names]).cuda().contiguous()
+    ref_g = torch.cat([T(g["g." + k]).reshape(-1) for k in names])
+    ref_p = torch.nn.Parameter(flat_p0.cpu().clone())
     opt = torch.optim.Adam([ref_p], lr=1e-3)
-    ref_p.grad = torch.cat([T(g["g." + k]).reshape(-1) for k in names])
+    ref_p.grad = ref_g.clone()
     opt.step()
-    TR.Adam(e, flat_p, lr=1e-3).step(flat_g)
-    # Adam's first step is lr * g / (|g| + 1e-8): where |g| is far above eps the update is +-lr whatever the rounding of g, where
-    # g ~ eps it amplifies the 1e-7-class differences of the summation order -- compare the former tightly, bound the latter by lr
+    flat_p = flat_p0.clone()
+    TR.Adam(e, flat_p, lr=1e-3).step(ref_g.cuda().contiguous())
     dev = (flat_p.cpu() - ref_p.detach()).abs()
-    big = ref_p.grad.abs() > 1e-5
+    big = ref_g.abs() > 1e-5
     assert float(dev[big].max()) < 2e-6 and float(big.float().mean()) > 0.9
     assert float(dev.max()) <= 1.05e-3
+    flat_g = torch.cat([grads[k].reshape(-1) for k in names]).contiguous()
+    flat_p = flat_p0.clone()
+    TR.Adam(e, flat_p, lr=1e-3).step(flat_g)
+    dev = (flat_p.cpu() - ref_p.detach()).abs()
+    scale = torch.cat([T(g["g." + k]).abs().max().expand(g["g." + k].size) for k in names])
+    clear = ref_g.abs() > 1e-3 * scale
+    assert float(dev[clear].max()) < 2e-6 and float(clear.float().mean()) > 0.8, (float(dev[clear].max()), float(clear.float().mean()))
+    assert float(dev.max()) <= 2.1e-3
 
 
 def test_training_steps_follow_the_reference_loop():
@@ -231,7 +255,7 @@ def test_assembled_unet_with_process_cond_reference_vectors():
     assert worst[0] < 2e-4, worst
 
 
-def test_training_step_from_audio_matches_oracle():
+def test_training_step_from_audio_matches_oracle(gemm):
     """train.py's step driven from audio on the small fixture model (five UNet levels, two upsamplers, scaled condition): frozen
     SEANet encoder + condition codec on the inference kernels, then q_sample -> UNet -> objective -> backward -> Adam; the loss
     and the updated parameters against the oracle's encoders + autograd + torch.optim.Adam."""
@@ -265,10 +289,11 @@ def test_training_step_from_audio_matches_oracle():
     opt.step()
     final = tr.state_dict()
     dev = torch.cat([(final[k[len("diff_model."):]].cpu() - v.detach()).abs().reshape(-1) for k, v in params.items()])
-    assert float(dev.mean()) < 1e-5 and float((dev > 1e-4).float().mean()) < 2e-3, (float(dev.mean()), float(dev.max()))   # first step: every parameter moves by ~lr = 1e-3
+    flips = 2e-3 if gemm == "fp32_mfma" else 2e-2    # share of parameters whose first Adam step differs: sign(g) of gradients ~0
+    assert float(dev.mean()) < 1e-5 and float((dev > 1e-4).float().mean()) < flips, (float(dev.mean()), float(dev.max()), float((dev > 1e-4).float().mean()))   # first step: every parameter moves by ~lr = 1e-3
 
 
-def test_full_width_training_step_reference_vectors():
+def test_full_width_training_step_reference_vectors(gemm):
     """ONE optimisation step at the size BASELINE configs[3] names (diff_dims 256, seq_length 1200, enc_ratios 8 4; the grids
     `bench.py --config c4` times) driven from audio, against the reference under torch autograd (tests/golden/train256.npz,
     tools/gen_golden_train256.py: DiffAudioRep.forward of srcs/model.py:146-209): diff_loss, x_t, predicted_x_start, the decoder's
@@ -301,12 +326,14 @@ def test_full_width_training_step_reference_vectors():
     assert np.abs(rep["neg_per_item"].cpu().numpy() - g["neg_per_item"]).max() < 2e-3          # dB
     assert abs(float(rep["neg_loss"].cpu()) - float(g["neg_loss"][0])) < 2e-3
     grads = tr.gradients()
-    worst = (0.0, "")
+    errs = []
     for k in [k for k in g if k.startswith("g.") and not k.endswith(".stride")]:
         name = k[2:]
         got = grads[name].cpu().numpy().reshape(-1)[::int(g[k + ".stride"])]
-        worst = max(worst, (rel(got, g[k]), name))
-    assert worst[0] < 5e-4, worst
+        errs.append((rel(got, g[k]), name))
+    errs.sort(reverse=True)
+    # split-bf16: a handful of L1 sign flips in 307 200 outputs (module docstring); measured 1.8e-3 (final_conv), 1.0e-3 elsewhere
+    assert errs[0][0] < (5e-4 if gemm == "fp32_mfma" else 4e-3), errs[:6]
     sums = {str(n): float(v) for n, v in zip(g["names"], g["abs_sums"])}
     off = max((abs(float(grads[n].double().abs().sum().cpu()) - sums[n]) / (sums[n] + 1e-12), n) for n in tr.names)
     assert off[0] < 2e-3, off
