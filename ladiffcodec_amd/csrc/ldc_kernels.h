@@ -249,8 +249,12 @@ extern int g_train_fp32_mfma;   // LDC_TRAIN_FP32_MFMA: the round-2 exact-fp32 M
 // split-bf16 (3 x bf16 MFMA, fp32-class accuracy) GEMM shapes of a Conv1d under training: train_mm3.hip
 hipError_t launch_mm3_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
                               float* y, hipStream_t s);
-hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s);
-hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s);
+// (bias: per output row = input channel; only the transposed-conv forward, which is this GEMM shape, passes one)
+hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s,
+                         const float* bias = nullptr);
+// (db: optional bias gradient [Cout] = sum over items and positions of dy, accumulated by the workgroups that stage dy anyway)
+hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
+                         float* db = nullptr);
 extern int g_train_valu;   // LDC_TRAIN_VALU: the training path's GEMM shapes on the VALU reference kernels instead of the fp32 MFMA ones
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, hipStream_t s);
 hipError_t launch_train_ln_forward(const float* x, const float* g, int B, int C, int L, float* y, float* stats, hipStream_t s);

@@ -412,8 +412,10 @@ static void convmm_dx(const float* dy, const float* w, int B, int Cin, int Cout,
   else
     hipLaunchKernelGGL((convmm_kernel<1, 1, 1>), dim3((Lin + 63) / 64, (Cin + 63) / 64, B), dim3(256), 0, s, w, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, 1);
 }
-static void convmm_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s) {
-  if (!g_train_fp32_mfma) { (void)launch_mm3_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s); return; }
+// -> true when the bias gradient was produced too (split-bf16 path: fused into the dW kernel)
+static bool convmm_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
+                      float* db = nullptr) {
+  if (!g_train_fp32_mfma) { (void)launch_mm3_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s, db); return db != nullptr; }
   // few output tiles, a long reduction over the items: split the items over workgroups (fp32 atomics into the zeroed gradient:
   // the sum order varies from run to run at the 1e-7 level) until the grid fills the chip
   const bool big = convmm_big(Cout, Cin, (long)K * B);
@@ -427,6 +429,7 @@ static void convmm_dw(const float* dy, const float* x, int B, int Cin, int Cout,
   else
     hipLaunchKernelGGL((convmm_kernel<2, 1, 1>), dim3((Cin + 63) / 64, (Cout + 63) / 64, K * nsplit), dim3(256), 0, s, x, dy, nullptr, dw, B, Cin, Cout, Lin, Lout, K,
                        S, P, nsplit);
+  return false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -609,9 +612,10 @@ hipError_t launch_train_block_backward(const float* dy, const float* x, const fl
   hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pgam, B, Cout, dgamma);
   hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pbet, B, Cout, dbeta);
   hipLaunchKernelGGL(gn_silu_backward2_kernel, dim3(groups, B), dim3(256), 0, s, k.h, k.stats, Cout, L, groups, k.tmp);   // tmp := dh
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, k.tmp, B, Cout, L, db);
-  if (convmm_ok(L, L)) convmm_dw(k.tmp, x, B, Cin, Cout, L, L, 3, 1, 1, k.dwn, s);
+  bool db_done = false;
+  if (convmm_ok(L, L)) db_done = convmm_dw(k.tmp, x, B, Cin, Cout, L, L, 3, 1, 1, k.dwn, s, db);
   else hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, k.tmp, x, B, Cin, Cout, L, k.dwn);
+  if (!db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, k.tmp, B, Cout, L, db);
   hipLaunchKernelGGL(ws_backward_kernel, dim3(Cout), dim3(256), 0, s, k.dwn, k.wn, k.rstd_w, Cin * 3, dw);
   if (dx) {
     if (convmm_ok(L, L)) convmm_dx(k.tmp, k.wn, B, Cin, Cout, L, L, 3, 1, 1, dx, s);
@@ -829,8 +833,43 @@ __global__ __launch_bounds__(256) void lin_dw_kernel(const float* dy, const floa
     dw[(size_t)o * Cin + i] = a;
   }
 }
+// elementwise helpers of the L == 1 (nn.Linear) path on the GEMM kernels: a = SiLU(x) into the workspace, dx *= SiLU'(x)
+__global__ __launch_bounds__(256) void silu_map_kernel(const float* x, int64_t n, float* y) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = silu_f(x[i]);
+}
+__global__ __launch_bounds__(256) void silu_grad_mul_kernel(const float* x, int64_t n, float* dx) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dx[i] *= silu_grad_f(x[i]);
+}
+static float* g_lin_ws = nullptr;     // SiLU(x) of the Linear being processed (one training context per process, one stream)
+static size_t g_lin_ws_floats = 0;
+static float* lin_workspace(size_t n, hipStream_t s) {
+  if (n > g_lin_ws_floats) {
+    (void)hipStreamSynchronize(s);
+    if (g_lin_ws) (void)hipFree(g_lin_ws);
+    g_lin_ws = nullptr;
+    g_lin_ws_floats = 0;
+    const size_t want = std::max(n, (size_t)1 << 18);
+    if (hipMalloc((void**)&g_lin_ws, want * sizeof(float)) != hipSuccess) return nullptr;
+    g_lin_ws_floats = want;
+  }
+  return g_lin_ws;
+}
+// nn.Linear on [B, Cin] (the time-embedding MLPs; 24 of them per step at B x 1024 x <= 2048): the round-2 kernels read the weight once
+// per item (forward), column-wise (dX: 179 us a call) or the activations once per output (dW); here they are the same three GEMM
+// shapes as a k = 1 conv at L = 1 (N = B columns: a quarter of one tile, which the matrix pipe does not notice).
+static bool lin_mm() { return !g_train_valu && !g_train_fp32_mfma; }
 hipError_t launch_train_pw_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int pre_silu, float* y,
                                    hipStream_t s) {
+  if (L == 1 && lin_mm()) {
+    const float* a = x;
+    if (pre_silu) {
+      float* ws = lin_workspace((size_t)B * Cin, s);
+      if (!ws) return hipErrorOutOfMemory;
+      hipLaunchKernelGGL(silu_map_kernel, dim3((B * Cin + 255) / 256), dim3(256), 0, s, x, (int64_t)B * Cin, ws);
+      a = ws;
+    }
+    return launch_mm3_forward(a, w, bias, B, Cin, Cout, 1, 1, 1, 1, 0, y, s);
+  }
   if (L == 1 && !g_train_valu) hipLaunchKernelGGL(lin_forward_kernel, dim3(Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, pre_silu, y);
   else if (!pre_silu && convmm_ok(L, L)) convmm_forward(x, w, bias, B, Cin, Cout, L, L, 1, 1, 0, y, s);
   else hipLaunchKernelGGL(pw_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, L, pre_silu, y);
@@ -839,6 +878,21 @@ hipError_t launch_train_pw_forward(const float* x, const float* w, const float* 
 hipError_t launch_train_pw_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int pre_silu, float* dx,
                                     float* dw, float* db, hipStream_t s) {
   const bool mm = !pre_silu && convmm_ok(L, L);
+  if (L == 1 && lin_mm()) {
+    if (dx) {
+      hipError_t e = launch_mm3_dx(dy, w, B, Cin, Cout, 1, 1, 1, 1, 0, dx, s);
+      if (e != hipSuccess) return e;
+      if (pre_silu) hipLaunchKernelGGL(silu_grad_mul_kernel, dim3((B * Cin + 255) / 256), dim3(256), 0, s, x, (int64_t)B * Cin, dx);
+    }
+    const float* a = x;
+    if (pre_silu) {
+      float* ws = lin_workspace((size_t)B * Cin, s);
+      if (!ws) return hipErrorOutOfMemory;
+      hipLaunchKernelGGL(silu_map_kernel, dim3((B * Cin + 255) / 256), dim3(256), 0, s, x, (int64_t)B * Cin, ws);
+      a = ws;
+    }
+    return launch_mm3_dw(dy, a, B, Cin, Cout, 1, 1, 1, 1, 0, dw, s, db);
+  }
   if (L == 1 && !g_train_valu) {
     if (dx) hipLaunchKernelGGL(lin_dx_kernel, dim3(Cin, B), dim3(256), 0, s, dy, x, w, Cin, Cout, pre_silu, dx);
     hipLaunchKernelGGL(lin_dw_kernel, dim3(Cout), dim3(256), 0, s, dy, x, B, Cin, Cout, pre_silu, dw);
@@ -849,9 +903,10 @@ hipError_t launch_train_pw_backward(const float* dy, const float* x, const float
     if (mm) convmm_dx(dy, w, B, Cin, Cout, L, L, 1, 1, 0, dx, s);
     else hipLaunchKernelGGL(pw_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, dy, x, w, Cin, Cout, L, pre_silu, dx);
   }
-  if (mm) convmm_dw(dy, x, B, Cin, Cout, L, L, 1, 1, 0, dw, s);
+  bool db_done = false;
+  if (mm) db_done = convmm_dw(dy, x, B, Cin, Cout, L, L, 1, 1, 0, dw, s, db);
   else hipLaunchKernelGGL(pw_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, dy, x, B, Cin, Cout, L, pre_silu, dw);
-  if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L, db);
+  if (db && !db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L, db);
   return hipGetLastError();
 }
 
@@ -1056,9 +1111,10 @@ hipError_t launch_train_conv_backward(const float* dy, const float* x, const flo
     if (mm) convmm_dx(dy, w, B, Cin, Cout, Lin, Lout, K, S, P, dx, s);
     else hipLaunchKernelGGL(convg_dx_kernel, dim3((Lin + 255) / 256, Cin, B), dim3(256), 0, s, dy, w, Cin, Cout, Lin, Lout, K, S, P, dx);
   }
-  if (mm) convmm_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s);
+  bool db_done = false;
+  if (mm) db_done = convmm_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s, db);
   else hipLaunchKernelGGL(convg_dw_kernel, dim3(Cin, Cout, K), dim3(256), 0, s, dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw);
-  if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, Lout, db);
+  if (db && !db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, Lout, db);
   return hipGetLastError();
 }
 
@@ -1243,11 +1299,24 @@ __global__ __launch_bounds__(256) void convtr_dw_kernel(const float* dy, const f
 }
 hipError_t launch_train_convtr_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int r, float* y,
                                        hipStream_t s) {
+  // the transposed conv IS the dX GEMM of a stride-r conv with the same weight layout ([Cin, Cout, 2r] = [Cout', Cin', K]) and
+  // padding r - r/2; its dX is that conv's forward, its dW that conv's dW with the operands swapped
+  if (lin_mm()) return launch_mm3_dx(x, w, B, Cout, Cin, L * r, L, 2 * r, r, r - r / 2, y, s, bias);
   hipLaunchKernelGGL(convtr_forward_kernel, dim3((L * r + 255) / 256, Cout, B), dim3(256), 0, s, x, w, bias, Cin, Cout, L, r, y);
   return hipGetLastError();
 }
 hipError_t launch_train_convtr_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int r, float* dx,
                                         float* dw, float* db, hipStream_t s) {
+  if (lin_mm()) {
+    if (dx) {
+      hipError_t e = launch_mm3_forward(dy, w, nullptr, B, Cout, Cin, L * r, L, 2 * r, r, r - r / 2, dx, s);
+      if (e != hipSuccess) return e;
+    }
+    hipError_t e = launch_mm3_dw(x, dy, B, Cout, Cin, L * r, L, 2 * r, r, r - r / 2, dw, s);
+    if (e != hipSuccess) return e;
+    if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L * r, db);
+    return hipGetLastError();
+  }
   if (dx) hipLaunchKernelGGL(convtr_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, dy, w, Cin, Cout, L, r, dx);
   hipLaunchKernelGGL(convtr_dw_kernel, dim3(Cout, Cin, 2 * r), dim3(256), 0, s, dy, x, B, Cin, Cout, L, r, dw);
   if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L * r, db);

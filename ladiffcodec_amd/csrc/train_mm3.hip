@@ -236,6 +236,8 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
       if (++f_outer < outer_hi) setup_outer(f_outer);
     }
   };
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};   // MODE 2, bias gradient: sums of this thread's dy values per row pass
+  const bool do_db = MODE == 2 && bias != nullptr && blockIdx.x == 0 && z == 0;
   auto store = [&](const Stage& r, int st) {
     if (MODE != 2) {
       const int sw = (r128 >> 2) & 3;
@@ -272,8 +274,14 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
         u32x2 hi, lo;
         // (rows past M / N are clamped reads of row 0: they only reach output rows / columns that are never stored; the clamped
         // loads are of real tensor data, so the 0 / 1 multiply is a safe mask)
-        if (edge) split4(r.a[4 * p] * ma[0], r.a[4 * p + 1] * ma[1], r.a[4 * p + 2] * ma[2], r.a[4 * p + 3] * ma[3], hi, lo);
-        else split4(r.a[4 * p], r.a[4 * p + 1], r.a[4 * p + 2], r.a[4 * p + 3], hi, lo);
+        if (edge) {
+          const float a0 = r.a[4 * p] * ma[0], a1 = r.a[4 * p + 1] * ma[1], a2 = r.a[4 * p + 2] * ma[2], a3 = r.a[4 * p + 3] * ma[3];
+          if (do_db) rs[p] += (a0 + a1) + (a2 + a3);
+          split4(a0, a1, a2, a3, hi, lo);
+        } else {
+          if (do_db) rs[p] += (r.a[4 * p] + r.a[4 * p + 1]) + (r.a[4 * p + 2] + r.a[4 * p + 3]);
+          split4(r.a[4 * p], r.a[4 * p + 1], r.a[4 * p + 2], r.a[4 * p + 3], hi, lo);
+        }
         ((u32x2*)lds[st][0])[at] = hi;
         ((u32x2*)lds[st][1])[at] = lo;
         if (edge) split4(r.b[4 * p] * mb[0], r.b[4 * p + 1] * mb[1], r.b[4 * p + 2] * mb[2], r.b[4 * p + 3] * mb[3], hi, lo);
@@ -379,6 +387,15 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
     }
   }
 
+  if (do_db) {   // bias gradient: db[o] += sum over this part's items and positions of dy (the eight lanes of a row meet by shuffles)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float v = rs[p];
+      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+      const int o = m0 + 32 * p + (tid >> 3);
+      if ((tid & 7) == 0 && o < Cout) atomicAdd(const_cast<float*>(bias) + o, v);
+    }
+  }
   // C/D layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
   for (int b2 = 0; b2 < 2; ++b2) {
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
         const int m = m0 + 64 * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * g;
         if (m >= M) continue;
         const float v = acc[a][b2][r];
-        const float add = (MODE == 0 && bias && kpart == 0) ? bias[m] : 0.f;
+        const float add = (MODE != 2 && bias && kpart == 0) ? bias[m] : 0.f;
         if (nsplit == 1) colp[(size_t)m * rstride] = v + add;
         else atomicAdd(&colp[(size_t)m * rstride], v + add);
       }
@@ -456,7 +473,8 @@ hipError_t launch_mm3_forward(const float* x, const float* w, const float* bias,
     hipLaunchKernelGGL((mm3_kernel<0, true>), grid, dim3(256), 0, s, (const void*)pw, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
   return hipGetLastError();
 }
-hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s) {
+hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s,
+                         const float* bias) {
   const int MP = up(Cin, 128), RP = up(Cout, 32);
   u32x4* pw = pack_workspace((size_t)K * MP * RP * 4, s);
   if (!pw) return hipErrorOutOfMemory;
@@ -467,22 +485,25 @@ hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Co
   if (ks > 1) (void)hipMemsetAsync(dx, 0, (size_t)B * Cin * Lin * sizeof(float), s);
   const dim3 grid((unsigned)((N + 127) / 128), MP / 128, ks);
   if (Cout % 32 == 0)
-    hipLaunchKernelGGL((mm3_kernel<1, false>), grid, dim3(256), 0, s, (const void*)pw, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    hipLaunchKernelGGL((mm3_kernel<1, false>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, dx, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
   else
-    hipLaunchKernelGGL((mm3_kernel<1, true>), grid, dim3(256), 0, s, (const void*)pw, dy, nullptr, dx, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    hipLaunchKernelGGL((mm3_kernel<1, true>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, dx, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
   return hipGetLastError();
 }
-hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s) {
+hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
+                         float* db) {
   // few output tiles, a long reduction over the items: split the items over workgroups (fp32 atomics into the zeroed gradient) until
   // the grid fills the chip (two workgroups per CU)
   const int tiles = ((Cin + 127) / 128) * ((Cout + 127) / 128) * K;
-  const int nsplit = std::max(1, std::min(B, (512 + tiles - 1) / tiles));
+  static const int target = getenv("LDC_MM3_DW_WGS") ? atoi(getenv("LDC_MM3_DW_WGS")) : 512;
+  const int nsplit = std::max(1, std::min(B, (target + tiles - 1) / tiles));
   if (nsplit > 1) (void)hipMemsetAsync(dw, 0, (size_t)Cout * Cin * K * sizeof(float), s);
+  if (db) (void)hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s);   // the first column tile of tap 0 adds the row sums of its dy tiles
   const dim3 grid((Cin + 127) / 128, (Cout + 127) / 128, K * nsplit);
   if (Lout % 4 == 0)
-    hipLaunchKernelGGL((mm3_kernel<2, false>), grid, dim3(256), 0, s, (const void*)dy, x, nullptr, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0);
+    hipLaunchKernelGGL((mm3_kernel<2, false>), grid, dim3(256), 0, s, (const void*)dy, x, db, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0);
   else
-    hipLaunchKernelGGL((mm3_kernel<2, true>), grid, dim3(256), 0, s, (const void*)dy, x, nullptr, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0);
+    hipLaunchKernelGGL((mm3_kernel<2, true>), grid, dim3(256), 0, s, (const void*)dy, x, db, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0);
   return hipGetLastError();
 }
 
