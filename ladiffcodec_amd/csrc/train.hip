@@ -168,6 +168,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threa
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
+// 1024 threads (16 waves): red[16]
+__device__ __forceinline__ float block_sum16(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += red[k];
+  return t;
+}
 __device__ __forceinline__ float block_max(float v, float* red) {   // 256 threads
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -488,22 +500,29 @@ __global__ __launch_bounds__(256) void conv3_dw_kernel(const float* dh, const fl
 // ---------------------------------------------------------------------------------------------
 // GroupNorm + (scale + 1, shift) + SiLU: forward and backward.  One block per (item, group).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_silu_forward_kernel(const float* h, const float* gamma, const float* beta, const float* ss,
-                                                              int C, int L, int groups, float* y, float* stats) {
-  __shared__ float red[4];
+// One workgroup of 1024 threads per (item, group) (round 3; the first form had 256 threads -- one workgroup of four waves per CU
+// does not keep enough loads in flight to stream its 150 KB three times -- and an integer division per element).
+__global__ __launch_bounds__(1024) void gn_silu_forward_kernel(const float* h, const float* gamma, const float* beta, const float* ss,
+                                                               int C, int L, int groups, float* y, float* stats) {
+  __shared__ float red[16];
   const int b = blockIdx.y, g = blockIdx.x, cpg = C / groups, n = cpg * L;
   const float* p = h + ((size_t)b * C + (size_t)g * cpg) * L;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += p[i];
-  const float mean = block_sum(s, red) / (float)n;
+  for (int i = threadIdx.x; i < n; i += 1024) s += p[i];
+  const float mean = block_sum16(s, red) / (float)n;
   float q = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) { const float d = p[i] - mean; q += d * d; }
-  const float rstd = rsqrtf(block_sum(q, red) / (float)n + 1e-5f);
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int c = g * cpg + i / L;
-    float v = (p[i] - mean) * rstd * gamma[c] + beta[c];
-    if (ss) v = v * (ss[(size_t)b * 2 * C + c] + 1.0f) + ss[(size_t)b * 2 * C + C + c];
-    y[((size_t)b * C + (size_t)g * cpg) * L + i] = v / (1.0f + expf(-v));
+  for (int i = threadIdx.x; i < n; i += 1024) { const float d = p[i] - mean; q += d * d; }
+  const float rstd = rsqrtf(block_sum16(q, red) / (float)n + 1e-5f);
+  for (int cc = 0; cc < cpg; ++cc) {
+    const int c = g * cpg + cc;
+    const float sc = ss ? ss[(size_t)b * 2 * C + c] + 1.0f : 1.0f, sh = ss ? ss[(size_t)b * 2 * C + C + c] : 0.0f;
+    const float* pr = p + (size_t)cc * L;
+    float* yr = y + ((size_t)b * C + c) * L;
+    for (int l = threadIdx.x; l < L; l += 1024) {
+      float v = (pr[l] - mean) * rstd * gamma[c] + beta[c];
+      if (ss) v = v * sc + sh;
+      yr[l] = v / (1.0f + expf(-v));
+    }
   }
   if (threadIdx.x == 0) { stats[((size_t)b * groups + g) * 2] = mean; stats[((size_t)b * groups + g) * 2 + 1] = rstd; }
 }
@@ -538,19 +557,19 @@ __global__ __launch_bounds__(256) void gn_silu_backward1_kernel(const float* dy,
   }
 }
 // pass 2: per (item, group): dh = rstd / n * (n * dxhat - sum dxhat - xhat * sum(dxhat * xhat))
-__global__ __launch_bounds__(256) void gn_silu_backward2_kernel(const float* h, const float* stats, int C, int L, int groups, float* tmp_dh) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(1024) void gn_silu_backward2_kernel(const float* h, const float* stats, int C, int L, int groups, float* tmp_dh) {
+  __shared__ float red[16];
   const int b = blockIdx.y, g = blockIdx.x, cpg = C / groups, n = cpg * L;
   const float mean = stats[((size_t)b * groups + g) * 2], rstd = stats[((size_t)b * groups + g) * 2 + 1];
   const size_t base = ((size_t)b * C + (size_t)g * cpg) * L;
   float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += 1024) {
     const float d = tmp_dh[base + i];
     s1 += d; s2 += d * (h[base + i] - mean) * rstd;
   }
-  const float t1 = block_sum(s1, red), t2 = block_sum(s2, red);
+  const float t1 = block_sum16(s1, red), t2 = block_sum16(s2, red);
   const float inv_n = 1.0f / (float)n;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += 1024) {
     const float xh = (h[base + i] - mean) * rstd;
     tmp_dh[base + i] = rstd * (tmp_dh[base + i] - t1 * inv_n - xh * t2 * inv_n);
   }
@@ -599,7 +618,7 @@ hipError_t launch_train_block_forward(const float* x, const float* w, const floa
   hipLaunchKernelGGL(ws_forward_kernel, dim3(Cout), dim3(256), 0, s, w, Cin * 3, k.wn, k.rstd_w);
   if (convmm_ok(L, L)) convmm_forward(x, k.wn, bias, B, Cin, Cout, L, L, 3, 1, 1, k.h, s);
   else hipLaunchKernelGGL(conv3_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, k.wn, bias, Cin, Cout, L, k.h);
-  hipLaunchKernelGGL(gn_silu_forward_kernel, dim3(groups, B), dim3(256), 0, s, k.h, gamma, beta, ss, Cout, L, groups, y, k.stats);
+  hipLaunchKernelGGL(gn_silu_forward_kernel, dim3(groups, B), dim3(1024), 0, s, k.h, gamma, beta, ss, Cout, L, groups, y, k.stats);
   return hipGetLastError();
 }
 
@@ -611,7 +630,7 @@ hipError_t launch_train_block_backward(const float* dy, const float* x, const fl
                      dss, k.pgam, k.pbet);
   hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pgam, B, Cout, dgamma);
   hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pbet, B, Cout, dbeta);
-  hipLaunchKernelGGL(gn_silu_backward2_kernel, dim3(groups, B), dim3(256), 0, s, k.h, k.stats, Cout, L, groups, k.tmp);   // tmp := dh
+  hipLaunchKernelGGL(gn_silu_backward2_kernel, dim3(groups, B), dim3(1024), 0, s, k.h, k.stats, Cout, L, groups, k.tmp);   // tmp := dh
   bool db_done = false;
   if (convmm_ok(L, L)) db_done = convmm_dw(k.tmp, x, B, Cin, Cout, L, L, 3, 1, 1, k.dwn, s, db);
   else hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, k.tmp, x, B, Cin, Cout, L, k.dwn);
