@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void mm3_pack_kernel(const float* w, int Cin, 
 
 // TAIL (MODE 0 / 1): the reduction extent is not a multiple of 32 (never in the UNet itself): the last chunk's loads are clamped and masked;
 // TAIL (MODE 2): Lout is not a multiple of 4 (the L = 150 / 75 levels): dy is read as dwords instead of dwordx4
-template <int MODE, bool TAIL>
+// VECB (MODE 2): stride 1 -- x is read as one (unaligned) dwordx4 per pass from a start clamped into the row; the threads whose four
+// positions straddle the padding (first / last of a row) get them shifted, which store() undoes for exactly those lanes
+template <int MODE, bool TAIL, bool VECB = false>
 __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ Asrc, const float* __restrict__ Bsrc, const float* __restrict__ bias,
                                                      float* __restrict__ out, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
                                                      int nsplit, int MP, int RP) {
@@ -227,8 +229,14 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
 #pragma unroll
           for (int e = 0; e < 4; ++e) r.a[4 * p + e] = baseA[qa[p] - 4 * (tid & 7) + min(lq + e, Lout - 1)];
         }
+        if (VECB) {
+          const f32x4u v = *(const f32x4u*)(baseB + qb[p] + min(max(lq + z - P, 0), Lin - 4));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r.b[4 * p + e] = baseB[qb[p] + min(max((lq + e) * S + z - P, 0), Lin - 1)];
+          for (int e = 0; e < 4; ++e) r.b[4 * p + e] = v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r.b[4 * p + e] = baseB[qb[p] + min(max((lq + e) * S + z - P, 0), Lin - 1)];
+        }
       }
     }
     if (++f_chunk == nchunk) {
@@ -284,8 +292,18 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
         }
         ((u32x2*)lds[st][0])[at] = hi;
         ((u32x2*)lds[st][1])[at] = lo;
-        if (edge) split4(r.b[4 * p] * mb[0], r.b[4 * p + 1] * mb[1], r.b[4 * p + 2] * mb[2], r.b[4 * p + 3] * mb[3], hi, lo);
-        else split4(r.b[4 * p], r.b[4 * p + 1], r.b[4 * p + 2], r.b[4 * p + 3], hi, lo);
+        if (edge) {
+          float b0 = r.b[4 * p], b1 = r.b[4 * p + 1], b2 = r.b[4 * p + 2], b3 = r.b[4 * p + 3];
+          if (VECB) {   // loaded from pos0 + d (d = clamp shift): element e is loaded[e - d]
+            const int d = min(max(pos0, 0), Lin - 4) - pos0;
+            const float l0 = b0, l1 = b1, l2 = b2, l3 = b3;
+            auto pick = [&](int k) { return k == 0 ? l0 : (k == 1 ? l1 : (k == 2 ? l2 : (k == 3 ? l3 : 0.f))); };
+            b0 = pick(0 - d); b1 = pick(1 - d); b2 = pick(2 - d); b3 = pick(3 - d);
+          }
+          split4(b0 * mb[0], b1 * mb[1], b2 * mb[2], b3 * mb[3], hi, lo);
+        } else {
+          split4(r.b[4 * p], r.b[4 * p + 1], r.b[4 * p + 2], r.b[4 * p + 3], hi, lo);
+        }
         ((u32x2*)lds[st][2])[at] = hi;
         ((u32x2*)lds[st][3])[at] = lo;
       }
@@ -500,10 +518,12 @@ hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Co
   if (nsplit > 1) (void)hipMemsetAsync(dw, 0, (size_t)Cout * Cin * K * sizeof(float), s);
   if (db) (void)hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s);   // the first column tile of tap 0 adds the row sums of its dy tiles
   const dim3 grid((Cin + 127) / 128, (Cout + 127) / 128, K * nsplit);
-  if (Lout % 4 == 0)
-    hipLaunchKernelGGL((mm3_kernel<2, false>), grid, dim3(256), 0, s, (const void*)dy, x, db, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0);
-  else
-    hipLaunchKernelGGL((mm3_kernel<2, true>), grid, dim3(256), 0, s, (const void*)dy, x, db, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0);
+  const bool vecb = S == 1 && Lin >= 4;
+#define LDC_MM3_DW(TAIL_, VECB_) \
+  hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_>), grid, dim3(256), 0, s, (const void*)dy, x, db, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0)
+  if (Lout % 4 == 0) { if (vecb) LDC_MM3_DW(false, true); else LDC_MM3_DW(false, false); }
+  else { if (vecb) LDC_MM3_DW(true, true); else LDC_MM3_DW(true, false); }
+#undef LDC_MM3_DW
   return hipGetLastError();
 }
 
