@@ -97,7 +97,8 @@ def cpu_baseline(cc, mc, u, sd_cond, sd_main, n_steps, seconds, batch, budget_s=
 def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, dev, result_fd):
     """BASELINE configs[3]: one optimisation step of the diffusion UNet per bench step (srcs/train.py --run_diff: frozen encoders,
     q_sample, UNet forward, l1 objective, UNet backward, gradient averaging over ranks, Adam) on B utterances per GPU.  The training
-    path is csrc/train.hip (fp32; GEMM shapes on the exact-fp32 MFMA), pinned to the reference's autograd."""
+    path is csrc/train.hip + csrc/train_mm3.hip (fp32 tensors; the GEMM shapes on the bf16 MFMA with every operand split into two bf16 --
+    three MFMAs per product, 2^-16-class -- or, with LDC_TRAIN_FP32_MFMA=1, on the exact-fp32 MFMA), pinned to the reference's autograd."""
     from ladiffcodec_amd import train as TR
     B = wav.shape[0]
     sd = {k[len("diff_model."):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_main.items() if k.startswith("diff_model.")}
@@ -122,20 +123,27 @@ def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, 
     n_par = sum(v.numel() for v in sd.values())
     fwd_flops, _ = eng.unet_step_cost(B, T // mc.hop_length)
     ach = 3.0 * fwd_flops * args.steps / elapsed / 1e12           # forward + dX + dW of every conv-shaped layer
+    exact = bool(os.environ.get("LDC_TRAIN_FP32_MFMA"))
     result = {
         "metric": "audio-sec per wall-sec through ONE optimisation step of the diffusion UNet (training, --run_diff)",
         "value": world * B * (T / 16000.0) * args.steps / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio, device-drawn t / noise)",
+        "dtype": "f32" if exact else "bf16x3 (fp32 tensors; GEMM operands split into bf16 hi + lo, three MFMAs per product, fp32 accumulate)",
+        "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio, device-drawn t / noise)",
         "config": {"workload": f"diffusion training step, diff_dims={u.dim}, seq_length {T // mc.hop_length}, batch={B}x{T / 16000.0:.1f} s per GPU, "
                                f"Adam over {n_par / 1e6:.1f} M parameters", "name": "c4", "global_batch": world * B,
                    "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                    "parallelism": f"dp{world} (flat fp32 gradient reduce-scatter + all-gather per step: {4 * n_par / 1e6:.0f} MB)"},
-        "roofline": {"bound": "mfma", "kernel": "convmm_kernel<0|1|2>: forward, dX and dW of every conv / pointwise layer on the exact-fp32 MFMA (csrc/train.hip)",
-                     "achieved": ach, "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS["f32"], "traffic": None,
-                     "note": "whole-step average: 3 x the UNet's forward conv flops / step time (frozen encoders, norms, attention cores and "
-                             "Adam included in the time)"},
+        "roofline": ({"bound": "mfma", "kernel": "convmm_kernel<0|1|2>: forward, dX and dW of every conv / pointwise layer on the exact-fp32 MFMA (csrc/train.hip)",
+                      "achieved": ach, "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS["f32"], "traffic": None}
+                     if exact else
+                     {"bound": "mfma", "kernel": "mm3_kernel<0|1|2>: forward, dX and dW of every conv / pointwise / Linear / transposed-conv layer as three "
+                                                 "bf16 MFMAs per fp32 product (csrc/train_mm3.hip)",
+                      "achieved": ach, "peak": MFMA_PEAK_TFLOPS["bf16"] / 3.0, "unit": "TFLOP/s", "frac": 3.0 * ach / MFMA_PEAK_TFLOPS["bf16"], "traffic": None,
+                      "peak_note": "dense bf16 MFMA peak / 3: `achieved` counts the algorithmic (fp32-equivalent) flops, each of which is three bf16 MFMA flops"}),
     }
+    result["roofline"]["note"] = ("whole-step average: 3 x the UNet's forward conv flops / step time (frozen encoders, norms, attention cores and "
+                                  "Adam included in the time)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ldc_oracle as O, train_oracle as TO
         cores = host_threads()

@@ -14,6 +14,7 @@ if [[ $STAGE == all || $STAGE == bench ]]; then
   for c in c3 c8 c5 c4; do
     timeout 900 python bench.py --config $c --steps 3 --warmup 1 > $O/bench_$c.json 2> $O/bench_$c.err; tail -1 $O/bench_$c.err
   done
+  LDC_TRAIN_FP32_MFMA=1 timeout 600 python bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c4_fp32_mfma.json 2> /dev/null
   LDC_FP8_ACT=0 timeout 600 python bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined > $O/bench_c5_weights_only.json 2> /dev/null
   timeout 600 python bench.py --dtype fp8 --steps 4 --warmup 1 --no-cpu-baseline --no-pipelined > $O/bench_c2_fp8.json 2> /dev/null
   python - <<PY
