@@ -102,10 +102,19 @@ def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, 
     from ladiffcodec_amd import train as TR
     B = wav.shape[0]
     sd = {k[len("diff_model."):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_main.items() if k.startswith("diff_model.")}
+    # a second engine with the same frozen codec weights: the encoders of the NEXT batch run on a side stream under this batch's UNet
+    # (every step still runs its encoders inside the timed region, once; LDC_TRAIN_NO_PREFETCH=1 keeps them in line)
+    front = None
+    if not os.environ.get("LDC_TRAIN_NO_PREFETCH"):
+        from ladiffcodec_amd.model import Engine
+        front = Engine(mc, u, cc, dtype="f32", device=dev.index if dev.index is not None else 0, noise_seed=99)
+        front.load_state_dict(L.MODEL_MAIN, sd_main)
+        front.load_state_dict(L.MODEL_COND, sd_cond)
+        front.finalize(strict=True)
     tr = TR.DiffusionTrainer(eng, sd, dim=u.dim, dim_mults=u.dim_mults, lr=1e-4, upsampling_ratios=u.upsampling_ratios,
-                             unet_scale_cond=u.unet_scale_cond)
+                             unet_scale_cond=u.unet_scale_cond, frontend=front)
     for i in range(args.warmup):
-        tr.step_from_wav(wav)
+        tr.step_from_wav(wav, next_wav=wav)
         torch.cuda.synchronize(dev)
         log(f"warmup {i} done")
     if torch.distributed.is_initialized():
@@ -113,7 +122,7 @@ def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, 
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.step_from_wav(wav)
+        loss = tr.step_from_wav(wav, next_wav=wav)
     torch.cuda.synchronize(dev)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
@@ -132,6 +141,7 @@ def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, 
         "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio, device-drawn t / noise)",
         "config": {"workload": f"diffusion training step, diff_dims={u.dim}, seq_length {T // mc.hop_length}, batch={B}x{T / 16000.0:.1f} s per GPU, "
                                f"Adam over {n_par / 1e6:.1f} M parameters", "name": "c4", "global_batch": world * B,
+                   "frozen_encoders": "next batch's, on a side stream under this step's UNet" if front is not None else "in line",
                    "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                    "parallelism": f"dp{world} (flat fp32 gradient reduce-scatter + all-gather per step: {4 * n_par / 1e6:.0f} MB)"},
         "roofline": ({"bound": "mfma", "kernel": "convmm_kernel<0|1|2>: forward, dX and dW of every conv / pointwise layer on the exact-fp32 MFMA (csrc/train.hip)",

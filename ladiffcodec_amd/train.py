@@ -673,10 +673,16 @@ class DiffusionTrainer:
     buffers the gradient reduction and Adam work on (until round 3 the network was rebuilt and 135 M gradient elements were
     concatenated every step)."""
 
-    def __init__(self, eng, sd: dict, dim: int, dim_mults=(1, 2, 4, 8), lr: float = 1e-4, **kw):
-        """kw: heads, dim_head, groups, upsampling_ratios, unet_scale_cond of Unet1D (with upsampling_ratios the raw condition is passed to step)."""
+    def __init__(self, eng, sd: dict, dim: int, dim_mults=(1, 2, 4, 8), lr: float = 1e-4, frontend=None, **kw):
+        """kw: heads, dim_head, groups, upsampling_ratios, unet_scale_cond of Unet1D (with upsampling_ratios the raw condition is passed to step).
+        frontend: a second Engine holding the same (frozen) codec weights.  With it, `step_from_wav(wav, next_wav=...)` runs the two
+        frozen encoders of the NEXT batch on a side stream while this batch's UNet forward / backward occupy the main one (they
+        do not depend on the parameters being optimised; the LSTM recurrences are latency-bound and use a fraction of the CUs)."""
         t = eng.torch
         self.eng, self.torch = eng, t
+        self.frontend = frontend
+        self._side = t.cuda.Stream(device=eng.device) if frontend is not None else None
+        self._prefetched = None        # (wav, cond, x_rep (unscaled), event)
         self.dim, self.dim_mults, self.kw = dim, tuple(dim_mults), kw
         # the trainable parameters are what Unet1D consumes for this configuration (not every key of the state dict: buffers,
         # or the upsampling layers when upsampling_ratios is None, are not parameters of the step)
@@ -741,21 +747,47 @@ class DiffusionTrainer:
             rep["neg_loss"] = rep["neg_per_item"].mean()
         return rep
 
-    def step_from_wav(self, wav, t=None, noise=None, latent_scale: float = 18.0, generator=None, monitor: bool = False):
+    def step_from_wav(self, wav, t=None, noise=None, latent_scale: float = 18.0, generator=None, monitor: bool = False, next_wav=None):
         """The step as srcs/train.py:110-160 + DiffAudioRep.forward (model.py:146-182) drive it from audio: cond =
         model_for_cond.get_cond(x); x_rep = encoder(x) (frozen) / 18 (--scaling_global); t ~ U{0..T-1}, noise ~ N(0, I)
         (ddpm_loss.py:443-449) unless given; then `step`.  The engine's inference kernels run the two frozen encoders."""
         from . import lib as LL
         tt = self.torch
         wav = wav.to(self.eng.device, tt.float32).contiguous()
-        cond = self.eng.get_cond(wav)
-        x_rep = self.eng.encode(LL.MODEL_MAIN, wav) / float(latent_scale)
+        pf, self._prefetched = self._prefetched, None
+        if pf is not None and pf[0].data_ptr() == wav.data_ptr() and pf[0].shape == wav.shape:
+            tt.cuda.current_stream(self.eng.device).wait_event(pf[3])
+            cond, x_rep = pf[1], pf[2] / float(latent_scale)
+        else:
+            cond = self.eng.get_cond(wav)
+            x_rep = self.eng.encode(LL.MODEL_MAIN, wav) / float(latent_scale)
         B = x_rep.shape[0]
         if t is None:
             t = tt.randint(0, self.num_timesteps, (B,), generator=generator)
         if noise is None:      # on the device unless a (CPU) generator asks for a reproducible host draw
             noise = tt.randn(x_rep.shape, generator=generator) if generator is not None else tt.randn(x_rep.shape, device=self.eng.device)
+        # enqueued BEFORE this step's ~1 600 launches: the host needs most of a step's GPU time to issue them, so anything queued
+        # behind them would start when the GPU is nearly through
+        if next_wav is not None and self.frontend is not None:
+            self.prefetch(next_wav)
         return self.step(x_rep, cond, t, noise, monitor=monitor, wav=wav, latent_scale=latent_scale)
+
+    def prefetch(self, wav):
+        """frozen encoders of a coming batch on the side stream / second engine (consumed by the step_from_wav call that gets the same tensor)"""
+        from . import lib as LL
+        tt = self.torch
+        dev = self.eng.device
+        wav = wav.to(dev, tt.float32).contiguous()
+        main = tt.cuda.current_stream(dev)
+        self._side.wait_stream(main)                   # the audio is ready (it may have been produced on the main stream)
+        with tt.cuda.stream(self._side):
+            cond = self.frontend.get_cond(wav)
+            x_rep = self.frontend.encode(LL.MODEL_MAIN, wav)
+            ev = tt.cuda.Event()
+            ev.record(self._side)
+        for x in (cond, x_rep):
+            x.record_stream(main)
+        self._prefetched = (wav, cond, x_rep, ev)
 
 
 class _KeyRecorder(dict):

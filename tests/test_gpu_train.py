@@ -293,6 +293,41 @@ def test_training_step_from_audio_matches_oracle(gemm):
     assert float(dev.mean()) < 1e-5 and float((dev > 1e-4).float().mean()) < flips, (float(dev.mean()), float(dev.max()), float((dev > 1e-4).float().mean()))   # first step: every parameter moves by ~lr = 1e-3
 
 
+def test_frozen_encoders_prefetched_on_a_second_engine_give_the_same_steps():
+    """DiffusionTrainer(frontend=...): the encoders of the next batch run on a side stream / second engine under the current step; three
+    steps over two alternating batches must give the encodings (bitwise) and the losses of the in-line trainer."""
+    from ladiffcodec_amd import lib as L, synth
+    from ladiffcodec_amd.model import Engine
+    from helpers import CASES, COND_CFG, cond_sd_np, main_sd_np
+    mc, u, _ = CASES["r84"]
+    e = engine("r84", "f32")
+    front = Engine(mc, u, COND_CFG, dtype="f32")
+    front.load_state_dict(L.MODEL_MAIN, main_sd_np("r84"))
+    front.load_state_dict(L.MODEL_COND, cond_sd_np())
+    front.finalize(strict=True)
+    sd = {k[len("diff_model."):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in main_sd_np("r84").items() if k.startswith("diff_model.")}
+    kw = dict(dim=u.dim, dim_mults=u.dim_mults, lr=1e-3, upsampling_ratios=u.upsampling_ratios, unet_scale_cond=u.unet_scale_cond)
+    wavs = [torch.from_numpy(synth.synthetic_wav(2, 2560, seed=s)).cuda() for s in (5, 6)]
+    gen = torch.Generator().manual_seed(3)
+    ts = [torch.tensor([10, 900]), torch.tensor([500, 77]), torch.tensor([3, 650])]
+    noises = [torch.randn(2, 128, 2560 // mc.hop_length, generator=gen) for _ in ts]
+    order = [0, 1, 0]
+    plain = TR.DiffusionTrainer(e, {k: v.clone() for k, v in sd.items()}, **kw)
+    want = [float(plain.step_from_wav(wavs[i], t=t, noise=n).cpu()[0]) for i, t, n in zip(order, ts, noises)]
+    pre = TR.DiffusionTrainer(e, {k: v.clone() for k, v in sd.items()}, frontend=front, **kw)
+    got = []
+    for k, (i, t, n) in enumerate(zip(order, ts, noises)):
+        nxt = wavs[order[k + 1]] if k + 1 < len(order) else None
+        got.append(float(pre.step_from_wav(wavs[i], t=t, noise=n, next_wav=nxt).cpu()[0]))
+        assert (pre._prefetched is not None) == (nxt is not None)
+        if nxt is not None:       # what the side stream produced is what the in-line engine produces, bit for bit
+            torch.cuda.current_stream().wait_event(pre._prefetched[3])
+            assert torch.equal(pre._prefetched[1], e.get_cond(nxt)) and torch.equal(pre._prefetched[2], e.encode(L.MODEL_MAIN, nxt))
+    # the first loss is bit-identical; later ones see parameters after Adam's first steps (lr * sign(g): the fp32 atomics of the split
+    # reductions decide the sign of ~0 gradients, also between two runs of the SAME trainer), hence the looser bar
+    assert got[0] == want[0] and max(abs(a - b) for a, b in zip(got, want)) < 2e-4, (got, want)
+
+
 def test_full_width_training_step_reference_vectors(gemm):
     """ONE optimisation step at the size BASELINE configs[3] names (diff_dims 256, seq_length 1200, enc_ratios 8 4; the grids
     `bench.py --config c4` times) driven from audio, against the reference under torch autograd (tests/golden/train256.npz,
