@@ -1343,37 +1343,50 @@ hipError_t launch_train_convtr_backward(const float* dy, const float* x, const f
 }
 // one block per item.  forward (dy == nullptr): out = x / (max|x| + 1e-20).  backward: out = dy / (s + eps) - [j == argmax] * sign(x_j) *
 // sum_k dy_k x_k / (s + eps)^2 (torch's max sends the gradient to the first maximal element)
-__global__ __launch_bounds__(256) void maxscale_kernel(const float* x, const float* dy, int64_t n, float* out) {
-  __shared__ float red[4];
+// (1024 threads: one workgroup per item is all the parallelism this op has at B = 32, so each at least keeps 16 waves of loads in flight;
+// the block reductions keep their fixed order)
+__device__ __forceinline__ float block_max16(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) t = fmaxf(t, red[k]);
+  return t;
+}
+__global__ __launch_bounds__(1024) void maxscale_kernel(const float* x, const float* dy, int64_t n, float* out) {
+  __shared__ float red[16];
   __shared__ long long s_arg;
   const float* xb = x + (size_t)blockIdx.x * n;
   float m = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(xb[i]));
-  m = block_max(m, red);
+  for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(xb[i]));
+  m = block_max16(m, red);
   const float inv = 1.0f / (m + 1e-20f);
   float* ob = out + (size_t)blockIdx.x * n;
   if (!dy) {
-    for (int64_t i = threadIdx.x; i < n; i += 256) ob[i] = xb[i] * inv;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) ob[i] = xb[i] * inv;
     return;
   }
   const float* db = dy + (size_t)blockIdx.x * n;
   float dot = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) dot = fmaf(db[i], xb[i], dot);
-  dot = block_sum(dot, red);
+  for (int64_t i = threadIdx.x; i < n; i += 1024) dot = fmaf(db[i], xb[i], dot);
+  dot = block_sum16(dot, red);
   if (threadIdx.x == 0) s_arg = (long long)n;
   __syncthreads();
-  for (int64_t i = threadIdx.x; i < n; i += 256)
+  for (int64_t i = threadIdx.x; i < n; i += 1024)
     if (fabsf(xb[i]) == m) atomicMin(&s_arg, (long long)i);
   __syncthreads();
   const long long arg = s_arg;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
     float g = db[i] * inv;
     if (i == arg) g -= (xb[i] < 0.f ? -1.0f : 1.0f) * dot * inv * inv;
     ob[i] = g;
   }
 }
 hipError_t launch_train_maxscale(const float* x, const float* dy, int B, int64_t n_per_item, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(maxscale_kernel, dim3(B), dim3(256), 0, s, x, dy, n_per_item, out);
+  hipLaunchKernelGGL(maxscale_kernel, dim3(B), dim3(1024), 0, s, x, dy, n_per_item, out);
   return hipGetLastError();
 }
 

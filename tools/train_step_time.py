@@ -1,6 +1,6 @@
-"""Wall time of ONE optimisation step of the full-width diffusion UNet (BASELINE config 4 shape: diff_dims 256, seq_length 1200,
-upsampling 5 2) on the fp32 VALU reference kernels of the training path.  Not a benchmark: the MFMA backward kernels do not
-exist yet; this records what the correctness path costs.  usage: python tools/train_step_time.py [B]"""
+"""Two optimisation steps of the full-width diffusion UNet (BASELINE config 4 shape: diff_dims 256, seq_length 1200, upsampling 5 2),
+the workload of tools/run_r03.sh's `train` profile; then (HOST=1) the host's share: time until step_from_wav RETURNS (everything
+enqueued) against time until the GPU is through.  usage: [HOST=1] python tools/train_step_time.py [B]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,3 +25,13 @@ for it in range(2):
     loss = tr.step_from_wav(wav, generator=torch.Generator().manual_seed(it))
     torch.cuda.synchronize()
     print(f"step {it}: loss {float(loss.cpu()[0]):.4f}, {time.perf_counter() - t0:.2f} s for B = {B} x 2.4 s (L = 1200, {sum(v.numel() for v in sd.values()) / 1e6:.1f} M parameters)")
+
+if os.environ.get("HOST"):
+    wav = wav.cuda()
+    for it in range(6):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        loss = tr.step_from_wav(wav)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"step {it}: host returned after {1e3 * (t1 - t0):.1f} ms, GPU done after {1e3 * (t2 - t0):.1f} ms")
