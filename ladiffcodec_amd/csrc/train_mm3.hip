@@ -422,8 +422,13 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
     float* colp;
     size_t rstride;
     if (MODE == 2) {
-      colp = out + (size_t)n * K + z;
-      rstride = (size_t)Cin * K;
+      if (nsplit > 1) {   // partial tile of this part: workspace [part][tap][Cout][Cin], summed in fixed order by mm3_dw_reduce_kernel
+        colp = out + (((size_t)part * K + z) * Cout) * Cin + n;
+        rstride = (size_t)Cin;
+      } else {
+        colp = out + (size_t)n * K + z;
+        rstride = (size_t)Cin * K;
+      }
     } else {
       const int bb = n / Lcol, l = n - bb * Lcol;
       colp = out + (size_t)bb * M * Lcol + l;
@@ -437,9 +442,22 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
         if (m >= M) continue;
         const float v = acc[a][b2][r];
         const float add = (MODE != 2 && bias && kpart == 0) ? bias[m] : 0.f;
-        if (nsplit == 1) colp[(size_t)m * rstride] = v + add;
+        if (nsplit == 1 || MODE == 2) colp[(size_t)m * rstride] = v + add;
         else atomicAdd(&colp[(size_t)m * rstride], v + add);
       }
+  }
+}
+
+// dW of a split reduction: dw[o][i][t] = sum over parts of ws[part][t][o][i], parts in order (the fp32 atomics this replaces cost 43 % of
+// the dW kernel at 32 parts -- device-scope atomics go to memory, the eight L2s are not coherent -- and made dW differ from run to run)
+__global__ __launch_bounds__(256) void mm3_dw_reduce_kernel(const float* ws, int nsplit, int K, int Cout, int Cin, float* dw) {
+  const size_t plane = (size_t)Cout * Cin, total = plane * K;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int t = (int)(idx / plane);
+    const size_t mn = idx - (size_t)t * plane;
+    float sacc = 0.f;
+    for (int p = 0; p < nsplit; ++p) sacc += ws[((size_t)p * K + t) * plane + mn];
+    dw[mn * K + t] = sacc;
   }
 }
 
@@ -460,6 +478,20 @@ u32x4* pack_workspace(size_t bytes, hipStream_t s) {
     g_pw_bytes = want;
   }
   return (u32x4*)g_pw;
+}
+void* g_dw_ws = nullptr;      // partial dW tiles of a split reduction (same ownership rules as g_pw)
+size_t g_dw_ws_bytes = 0;
+float* dw_workspace(size_t bytes, hipStream_t s) {
+  if (bytes > g_dw_ws_bytes) {
+    (void)hipStreamSynchronize(s);
+    if (g_dw_ws) (void)hipFree(g_dw_ws);
+    g_dw_ws = nullptr;
+    g_dw_ws_bytes = 0;
+    const size_t want = std::max(bytes + bytes / 4, (size_t)64 << 20);
+    if (hipMalloc(&g_dw_ws, want) != hipSuccess) return nullptr;
+    g_dw_ws_bytes = want;
+  }
+  return (float*)g_dw_ws;
 }
 inline int up(int v, int q) { return (v + q - 1) / q * q; }
 // forward / dX: parts of the (tap, channel chunk) reduction per output tile.  The chip holds 512 workgroups (two per CU); below
@@ -510,20 +542,28 @@ hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Co
 }
 hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
                          float* db) {
-  // few output tiles, a long reduction over the items: split the items over workgroups (fp32 atomics into the zeroed gradient) until
-  // the grid fills the chip (two workgroups per CU)
+  // few output tiles, a long reduction over the items: split the items over workgroups until the grid fills the chip (two workgroups
+  // per CU); the parts write their tiles to a workspace and a second kernel sums them in order (deterministic)
   const int tiles = ((Cin + 127) / 128) * ((Cout + 127) / 128) * K;
-  static const int target = getenv("LDC_MM3_DW_WGS") ? atoi(getenv("LDC_MM3_DW_WGS")) : 512;
-  const int nsplit = std::max(1, std::min(B, (target + tiles - 1) / tiles));
-  if (nsplit > 1) (void)hipMemsetAsync(dw, 0, (size_t)Cout * Cin * K * sizeof(float), s);
+  static const int want_wgs = getenv("LDC_MM3_DW_WGS") ? atoi(getenv("LDC_MM3_DW_WGS")) : 512;
+  const int nsplit = std::max(1, std::min(B, (want_wgs + tiles - 1) / tiles));
+  float* target = dw;
+  if (nsplit > 1) {
+    target = dw_workspace((size_t)nsplit * K * Cout * Cin * sizeof(float), s);
+    if (!target) return hipErrorOutOfMemory;
+  }
   if (db) (void)hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s);   // the first column tile of tap 0 adds the row sums of its dy tiles
   const dim3 grid((Cin + 127) / 128, (Cout + 127) / 128, K * nsplit);
   const bool vecb = S == 1 && Lin >= 4;
 #define LDC_MM3_DW(TAIL_, VECB_) \
-  hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_>), grid, dim3(256), 0, s, (const void*)dy, x, db, dw, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0)
+  hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_>), grid, dim3(256), 0, s, (const void*)dy, x, db, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0)
   if (Lout % 4 == 0) { if (vecb) LDC_MM3_DW(false, true); else LDC_MM3_DW(false, false); }
   else { if (vecb) LDC_MM3_DW(true, true); else LDC_MM3_DW(true, false); }
 #undef LDC_MM3_DW
+  if (nsplit > 1) {
+    const size_t total = (size_t)K * Cout * Cin;
+    hipLaunchKernelGGL(mm3_dw_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, (const float*)target, nsplit, K, Cout, Cin, dw);
+  }
   return hipGetLastError();
 }
 
