@@ -938,10 +938,11 @@ hipError_t launch_train_pw_backward(const float* dy, const float* x, const float
 //   dks[d, n]  = sum_e dctx[d, e] v[e, n]         dv[e, n]  = sum_d ks[d, n] dctx[d, e]
 //   dq = s (g - sum_d s g), s = qs / scale, g = dqs * scale        dk = ks (dks - sum_n ks dks)
 // ---------------------------------------------------------------------------------------------
+constexpr int kLaParts = 4;   // position ranges a (item, head)'s D x D product is split into (partials summed in order)
 size_t train_linattn_ws_floats(int B, int H, int D, int N) {
-  return (size_t)2 * B * H * D * N + (size_t)2 * B * H * D * D + (size_t)B * H * D + 64;
+  return (size_t)2 * B * H * D * N + (size_t)(2 + kLaParts) * B * H * D * D + (size_t)B * H * D + 64;
 }
-struct LaWs { float *qs, *ks, *ctx, *dctx, *rowdot; };
+struct LaWs { float *qs, *ks, *ctx, *dctx, *rowdot, *part; };
 static LaWs la_carve(float* ws, int B, int H, int D, int N) {
   LaWs w;
   float* p = ws;
@@ -949,7 +950,8 @@ static LaWs la_carve(float* ws, int B, int H, int D, int N) {
   w.ks = p; p += (size_t)B * H * D * N;
   w.ctx = p; p += (size_t)B * H * D * D;
   w.dctx = p; p += (size_t)B * H * D * D;
-  w.rowdot = p;
+  w.rowdot = p; p += (size_t)B * H * D + 64;
+  w.part = p;
   return w;
 }
 // one block per (b, h, d): ks[d, :] = softmax over positions of k[d, :]
@@ -978,22 +980,61 @@ __global__ __launch_bounds__(256) void la_qsoftmax_kernel(const float* qkv, int 
   float* out = qs + ((size_t)b * HD + h * D) * N + n;
   for (int d = 0; d < D; ++d) out[(size_t)d * N] = expf(qr[(size_t)d * N] - m) / sum * scale;
 }
-// one block per (b, h, d): out[d, e] = sum_n a[d, n] * bsrc[e, n]   (ctx from (ks, v); dctx from (qs, do)); fixed-order reduction
+// out[d, e] = sum_n a[d, n] * bsrc[e, n]   (ctx from (ks, v); dctx from (qs, do)).  One workgroup per (item, head, position range):
+// 64-position chunks of both operands staged through LDS with coalesced row reads, thread (e = tid % D, d = tid / D + (256 / D) j) owns
+// D * D / 256 outputs; the ranges' partials go to `part` and la_outer_sum_kernel adds them in order.  (The first form gave every lane
+// its own row of bsrc -- 64 cache lines per load instruction -- and re-read bsrc once per d: 112 us a call, 318 at N = 1200.)
 __global__ __launch_bounds__(256) void la_outer_kernel(const float* a, const float* bsrc, size_t a_item, size_t b_item, int H, int D, int N,
-                                                       float* out) {
-  __shared__ float part[256];
-  const int d = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const float* ar = a + (size_t)b * a_item + (size_t)(h * D + d) * N;
-  const int e = threadIdx.x % D, grp = threadIdx.x / D, ngrp = 256 / D;   // D divides 256 (32, 64)
-  const float* br = bsrc + (size_t)b * b_item + (size_t)(h * D + e) * N;
-  float acc = 0.f;
-  for (int n = grp; n < N; n += ngrp) acc = fmaf(ar[n], br[n], acc);
-  part[threadIdx.x] = acc;
-  __syncthreads();
-  if (threadIdx.x < D) {
+                                                       float* part) {
+  __shared__ float As[64][65], Bs[64][65];
+  const int h = blockIdx.y, b = blockIdx.z, pr = blockIdx.x, np = gridDim.x;
+  const int n_lo = (int)((long long)N * pr / np), n_hi = (int)((long long)N * (pr + 1) / np);
+  const float* ab = a + (size_t)b * a_item + (size_t)(h * D) * N;
+  const float* bb = bsrc + (size_t)b * b_item + (size_t)(h * D) * N;
+  const int e = threadIdx.x % D, d0 = threadIdx.x / D, dstep = 256 / D;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int n0 = n_lo; n0 < n_hi; n0 += 64) {
+    const int len = min(64, n_hi - n0);
+    for (int idx = threadIdx.x; idx < D * 64; idx += 256) {
+      const int d = idx >> 6, nn = idx & 63;
+      const bool ok = nn < len;
+      As[d][nn] = ok ? ab[(size_t)d * N + n0 + nn] : 0.f;
+      Bs[d][nn] = ok ? bb[(size_t)d * N + n0 + nn] : 0.f;
+    }
+    __syncthreads();
+    for (int nn = 0; nn < 64; ++nn) {
+      const float bv = Bs[e][nn];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int d = d0 + dstep * j;
+        if (d < D) acc[j] = fmaf(As[d][nn], bv, acc[j]);
+      }
+    }
+    __syncthreads();
+  }
+  float* o = part + (((size_t)pr * gridDim.z + b) * H + h) * D * D;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int d = d0 + dstep * j;
+    if (d < D) o[d * D + e] = acc[j];
+  }
+}
+__global__ __launch_bounds__(256) void la_outer_sum_kernel(const float* part, int np, size_t n, float* out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float t = 0.f;
-    for (int g = 0; g < ngrp; ++g) t += part[g * D + threadIdx.x];
-    out[(((size_t)b * H + h) * D + d) * D + threadIdx.x] = t;
+    for (int p = 0; p < np; ++p) t += part[(size_t)p * n + i];
+    out[i] = t;
+  }
+}
+static void la_outer(const float* a, const float* bsrc, size_t a_item, size_t b_item, int B, int H, int D, int N, float* part, float* out,
+                     hipStream_t s) {
+  const int np = N >= 256 ? kLaParts : 1;
+  hipLaunchKernelGGL(la_outer_kernel, dim3(np, H, B), dim3(256), 0, s, a, bsrc, a_item, b_item, H, D, N, np == 1 ? out : part);
+  if (np > 1) {
+    const size_t n = (size_t)B * H * D * D;
+    hipLaunchKernelGGL(la_outer_sum_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, s, part, np, n, out);
   }
 }
 // one thread per (b, h, n): y[e, n] = sum_d m[d, e] * x[d, n]  (TRANS = false: o from (ctx, qs)) or y[d, n] = sum_e m[d, e] * x[e, n] (TRANS = true)
@@ -1042,7 +1083,7 @@ hipError_t launch_train_linattn_forward(const float* qkv, int B, int H, int D, i
   const float scale = 1.0f / sqrtf((float)D);
   hipLaunchKernelGGL(la_ksoftmax_kernel, dim3(D, H, B), dim3(256), 0, s, qkv, H, D, N, w.ks);
   hipLaunchKernelGGL(la_qsoftmax_kernel, dim3((N + 255) / 256, H, B), dim3(256), 0, s, qkv, H, D, N, scale, w.qs);
-  hipLaunchKernelGGL(la_outer_kernel, dim3(D, H, B), dim3(256), 0, s, w.ks, qkv + 2 * HD * N, HD * N, 3 * HD * N, H, D, N, w.ctx);
+  la_outer(w.ks, qkv + 2 * HD * N, HD * N, 3 * HD * N, B, H, D, N, w.part, w.ctx, s);
   hipLaunchKernelGGL(la_apply_kernel<false>, dim3((N + 255) / 256, H, B), dim3(256), (size_t)D * D * 4, s, w.ctx, w.qs, HD * N, H, D, N, o, HD * N);
   return hipGetLastError();
 }
@@ -1053,7 +1094,7 @@ hipError_t launch_train_linattn_backward(const float* d_o, const float* qkv, int
   const size_t HD = (size_t)H * D;
   const float scale = 1.0f / sqrtf((float)D);
   const dim3 gn((N + 255) / 256, H, B), gd(D, H, B);
-  hipLaunchKernelGGL(la_outer_kernel, gd, dim3(256), 0, s, w.qs, d_o, HD * N, HD * N, H, D, N, w.dctx);                       // dctx[d, e]
+  la_outer(w.qs, d_o, HD * N, HD * N, B, H, D, N, w.part, w.dctx, s);                                                       // dctx[d, e]
   hipLaunchKernelGGL(la_apply_kernel<true>, gn, dim3(256), (size_t)D * D * 4, s, w.ctx, d_o, HD * N, H, D, N, dqkv, 3 * HD * N);   // dqs -> dq slot
   hipLaunchKernelGGL(la_dq_kernel, gn, dim3(256), 0, s, w.qs, H, D, N, scale, dqkv, 3 * HD * N);
   hipLaunchKernelGGL(la_apply_kernel<true>, gn, dim3(256), (size_t)D * D * 4, s, w.dctx, qkv + 2 * HD * N, 3 * HD * N, H, D, N, dqkv + HD * N,
