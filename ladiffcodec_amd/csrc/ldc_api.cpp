@@ -3080,6 +3080,12 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     cc.sk_part = (float*)part; cc.sk_part_cap = (long long)8 << 20; cc.sk_count = (unsigned*)cnt; cc.sk_count_cap = 1024;
     cc.tune = &c->tune;
   }
+  if (getenv("LDC_MB_GN")) {   // tuning aid: the fused GroupNorm statistics of the UNet's block convs (8 groups) ride along
+    void* gs = nullptr;
+    LDCCHK(keep.alloc(&gs, (size_t)B * 8 * kGnPad * 4));
+    HIPCHK(hipMemset(gs, 0, (size_t)B * 8 * kGnPad * 4));
+    cc.gn_sum = (float*)gs; cc.gn_groups = 8;
+  }
   hipStream_t s = c->own_stream;
   for (int i = 0; i < 3; ++i) HIPCHK(launch_conv(ly, cc, s));
   hipEvent_t e0, e1;
