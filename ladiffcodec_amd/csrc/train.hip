@@ -744,6 +744,40 @@ __global__ __launch_bounds__(256) void ln_backward_dx_kernel(const float* dy, co
     dx[base + (size_t)c * L] = rstd * (dxh - s1 - xh * s2);
   }
 }
+// Register-resident forward for C = 4 * NC (NC = 64: the C = 256 level, the largest tensors): a thread's channels are loaded once, all loads
+// in flight together, and the three passes run over registers -- same operations in the same order as the kernel above, so the results
+// are bit-identical; x is read once instead of three times.  (NC = 128 needs 239 registers, and a register-resident backward 286-444:
+// one or two waves per SIMD: not kept.)
+template <int NC>
+__global__ __launch_bounds__(256) void ln_forward_reg_kernel(const float* x, const float* g, int C, int L, float* y, float* stats) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.y, lx = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int l = blockIdx.x * 64 + lx;
+  const bool ok = l < L;
+  const float* xb = x + (size_t)b * C * L + (ok ? l : 0);
+  float v[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) v[k] = xb[(size_t)(w + 4 * k) * L];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NC; k += 4) s += (v[k] + v[k + 1]) + (v[k + 2] + v[k + 3]);
+  const float mean = ln_quad_sum(s, red, w, lx) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NC; k += 4) {
+    const float d0 = v[k] - mean, d1 = v[k + 1] - mean, d2 = v[k + 2] - mean, d3 = v[k + 3] - mean;
+    ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  const float rstd = rsqrtf(ln_quad_sum(ss, red, w, lx) / (float)C + 1e-5f);
+  if (!ok) return;
+  float* yb = y + (size_t)b * C * L + l;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) yb[(size_t)(w + 4 * k) * L] = (v[k] - mean) * rstd * g[w + 4 * k];
+  if (w == 0) {
+    stats[((size_t)b * L + l) * 2] = mean;
+    stats[((size_t)b * L + l) * 2 + 1] = rstd;
+  }
+}
 // one block per channel: dg[c] = sum_{b,l} dy * xhat in a fixed order
 __global__ __launch_bounds__(256) void ln_backward_dg_kernel(const float* dy, const float* x, const float* stats, int B, int C, int L, float* dg) {
   const int c = blockIdx.x;
@@ -764,12 +798,15 @@ __global__ __launch_bounds__(256) void ln_backward_dg_kernel(const float* dy, co
   if (threadIdx.x == 0) dg[c] = red[0];
 }
 hipError_t launch_train_ln_forward(const float* x, const float* g, int B, int C, int L, float* y, float* stats, hipStream_t s) {
-  hipLaunchKernelGGL(ln_forward_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, x, g, C, L, y, stats);
+  const dim3 grid((L + 63) / 64, B);
+  if (C == 256) hipLaunchKernelGGL((ln_forward_reg_kernel<64>), grid, dim3(256), 0, s, x, g, C, L, y, stats);
+  else hipLaunchKernelGGL(ln_forward_kernel, grid, dim3(256), 0, s, x, g, C, L, y, stats);
   return hipGetLastError();
 }
 hipError_t launch_train_ln_backward(const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L, float* dx,
                                     float* dg, hipStream_t s) {
-  hipLaunchKernelGGL(ln_backward_dx_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, dy, x, g, stats, C, L, dx);
+  const dim3 grid((L + 63) / 64, B);
+  hipLaunchKernelGGL(ln_backward_dx_kernel, grid, dim3(256), 0, s, dy, x, g, stats, C, L, dx);
   hipLaunchKernelGGL(ln_backward_dg_kernel, dim3(C), dim3(256), 0, s, dy, x, stats, B, C, L, dg);
   return hipGetLastError();
 }
