@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
   const int Lsrc = MODE == 0 ? Lin : Lout;                        // MODE 0 / 1: row length of the gathered activation
   // reduction steps of this workgroup, flattened as (outer, chunk): MODE 2 takes the items of its part (grid z = tap * nsplit + part),
   // MODE 0 / 1 an even share of the (tap, channel chunk) steps when the output tiles alone do not fill the chip (grid z = part;
-  // parts add into the zeroed output)
+  // parts write their partial outputs to a workspace, mm3_sum_parts_kernel adds them in order: no atomics anywhere, the step is
+  // bit-reproducible)
   const int nchunk = (red + 31) / 32;
   const int outer_lo = MODE == 2 ? (int)((long long)B * part / nsplit) : 0;
   const int outer_hi = MODE == 2 ? (int)((long long)B * (part + 1) / nsplit) : K;
@@ -405,13 +406,13 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
     }
   }
 
-  if (do_db) {   // bias gradient: db[o] += sum over this part's items and positions of dy (the eight lanes of a row meet by shuffles)
+  if (do_db) {   // bias gradient of this part: db[part][o] = sum over its items and positions of dy (the eight lanes of a row meet by shuffles)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       float v = rs[p];
       v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
       const int o = m0 + 32 * p + (tid >> 3);
-      if ((tid & 7) == 0 && o < Cout) atomicAdd(const_cast<float*>(bias) + o, v);
+      if ((tid & 7) == 0 && o < Cout) const_cast<float*>(bias)[(size_t)part * Cout + o] = v;   // (`bias` = db, or the parts' rows of the workspace)
     }
   }
   // C/D layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
       }
     } else {
       const int bb = n / Lcol, l = n - bb * Lcol;
-      colp = out + (size_t)bb * M * Lcol + l;
+      colp = out + (size_t)kpart * B * M * Lcol + (size_t)bb * M * Lcol + l;   // (split reduction: `out` is the parts' workspace)
       rstride = (size_t)Lcol;
     }
 #pragma unroll
@@ -442,15 +443,15 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
         if (m >= M) continue;
         const float v = acc[a][b2][r];
         const float add = (MODE != 2 && bias && kpart == 0) ? bias[m] : 0.f;
-        if (nsplit == 1 || MODE == 2) colp[(size_t)m * rstride] = v + add;
-        else atomicAdd(&colp[(size_t)m * rstride], v + add);
+        colp[(size_t)m * rstride] = v + add;
       }
   }
 }
 
 // dW of a split reduction: dw[o][i][t] = sum over parts of ws[part][t][o][i], parts in order (the fp32 atomics this replaces cost 43 % of
 // the dW kernel at 32 parts -- device-scope atomics go to memory, the eight L2s are not coherent -- and made dW differ from run to run)
-__global__ __launch_bounds__(256) void mm3_dw_reduce_kernel(const float* ws, int nsplit, int K, int Cout, int Cin, float* dw) {
+__global__ __launch_bounds__(256) void mm3_dw_reduce_kernel(const float* ws, int nsplit, int K, int Cout, int Cin, float* dw, const float* db_ws,
+                                                            float* db) {
   const size_t plane = (size_t)Cout * Cin, total = plane * K;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int t = (int)(idx / plane);
@@ -458,6 +459,20 @@ __global__ __launch_bounds__(256) void mm3_dw_reduce_kernel(const float* ws, int
     float sacc = 0.f;
     for (int p = 0; p < nsplit; ++p) sacc += ws[((size_t)p * K + t) * plane + mn];
     dw[mn * K + t] = sacc;
+  }
+  if (db)
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < Cout; o += gridDim.x * 256) {
+      float sacc = 0.f;
+      for (int p = 0; p < nsplit; ++p) sacc += db_ws[(size_t)p * Cout + o];
+      db[o] = sacc;
+    }
+}
+// forward / dX of a split reduction: out = sum over parts (in order) of the partial outputs
+__global__ __launch_bounds__(256) void mm3_sum_parts_kernel(const float* ws, int np, size_t n, float* out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float sacc = 0.f;
+    for (int p = 0; p < np; ++p) sacc += ws[(size_t)p * n + i];
+    out[i] = sacc;
   }
 }
 
@@ -515,12 +530,19 @@ hipError_t launch_mm3_forward(const float* x, const float* w, const float* bias,
   hipLaunchKernelGGL((mm3_pack_kernel<0>), dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, w, Cin, Cout, K, MP, RP, pw);
   const long N = (long)B * Lout;
   const int ks = reduction_split((long)((N + 127) / 128) * (MP / 128), K * (RP / 32));
-  if (ks > 1) (void)hipMemsetAsync(y, 0, (size_t)B * Cout * Lout * sizeof(float), s);
+  const size_t n_out = (size_t)B * Cout * Lout;
+  float* target = y;
+  if (ks > 1) {
+    target = dw_workspace((size_t)ks * n_out * sizeof(float), s);
+    if (!target) return hipErrorOutOfMemory;
+  }
   const dim3 grid((unsigned)((N + 127) / 128), MP / 128, ks);
   if (Cin % 32 == 0)
-    hipLaunchKernelGGL((mm3_kernel<0, false>), grid, dim3(256), 0, s, (const void*)pw, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    hipLaunchKernelGGL((mm3_kernel<0, false>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
   else
-    hipLaunchKernelGGL((mm3_kernel<0, true>), grid, dim3(256), 0, s, (const void*)pw, x, bias, y, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    hipLaunchKernelGGL((mm3_kernel<0, true>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+  if (ks > 1)
+    hipLaunchKernelGGL(mm3_sum_parts_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 8192)), dim3(256), 0, s, (const float*)target, ks, n_out, y);
   return hipGetLastError();
 }
 hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dx, hipStream_t s,
@@ -532,12 +554,19 @@ hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Co
   hipLaunchKernelGGL((mm3_pack_kernel<1>), dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, w, Cin, Cout, K, MP, RP, pw);
   const long N = (long)B * Lin;
   const int ks = reduction_split((long)((N + 127) / 128) * (MP / 128), K * (RP / 32));
-  if (ks > 1) (void)hipMemsetAsync(dx, 0, (size_t)B * Cin * Lin * sizeof(float), s);
+  const size_t n_out = (size_t)B * Cin * Lin;
+  float* target = dx;
+  if (ks > 1) {
+    target = dw_workspace((size_t)ks * n_out * sizeof(float), s);
+    if (!target) return hipErrorOutOfMemory;
+  }
   const dim3 grid((unsigned)((N + 127) / 128), MP / 128, ks);
   if (Cout % 32 == 0)
-    hipLaunchKernelGGL((mm3_kernel<1, false>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, dx, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    hipLaunchKernelGGL((mm3_kernel<1, false>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
   else
-    hipLaunchKernelGGL((mm3_kernel<1, true>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, dx, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    hipLaunchKernelGGL((mm3_kernel<1, true>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+  if (ks > 1)
+    hipLaunchKernelGGL(mm3_sum_parts_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 8192)), dim3(256), 0, s, (const float*)target, ks, n_out, dx);
   return hipGetLastError();
 }
 hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
@@ -548,21 +577,23 @@ hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Co
   static const int want_wgs = getenv("LDC_MM3_DW_WGS") ? atoi(getenv("LDC_MM3_DW_WGS")) : 512;
   const int nsplit = std::max(1, std::min(B, (want_wgs + tiles - 1) / tiles));
   float* target = dw;
+  float* db_target = db;          // the first column tile of tap 0 writes the row sums of its dy tiles (per part)
   if (nsplit > 1) {
-    target = dw_workspace((size_t)nsplit * K * Cout * Cin * sizeof(float), s);
+    const size_t n_dw = (size_t)nsplit * K * Cout * Cin;
+    target = dw_workspace((n_dw + (size_t)nsplit * Cout) * sizeof(float), s);
     if (!target) return hipErrorOutOfMemory;
+    if (db) db_target = target + n_dw;
   }
-  if (db) (void)hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s);   // the first column tile of tap 0 adds the row sums of its dy tiles
   const dim3 grid((Cin + 127) / 128, (Cout + 127) / 128, K * nsplit);
   const bool vecb = S == 1 && Lin >= 4;
 #define LDC_MM3_DW(TAIL_, VECB_) \
-  hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_>), grid, dim3(256), 0, s, (const void*)dy, x, db, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0)
+  hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_>), grid, dim3(256), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0)
   if (Lout % 4 == 0) { if (vecb) LDC_MM3_DW(false, true); else LDC_MM3_DW(false, false); }
   else { if (vecb) LDC_MM3_DW(true, true); else LDC_MM3_DW(true, false); }
 #undef LDC_MM3_DW
   if (nsplit > 1) {
     const size_t total = (size_t)K * Cout * Cin;
-    hipLaunchKernelGGL(mm3_dw_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, (const float*)target, nsplit, K, Cout, Cin, dw);
+    hipLaunchKernelGGL(mm3_dw_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, (const float*)target, nsplit, K, Cout, Cin, dw, (const float*)db_target, db);
   }
   return hipGetLastError();
 }

@@ -293,6 +293,41 @@ def test_training_step_from_audio_matches_oracle(gemm):
     assert float(dev.mean()) < 1e-5 and float((dev > 1e-4).float().mean()) < flips, (float(dev.mean()), float(dev.max()), float((dev > 1e-4).float().mean()))   # first step: every parameter moves by ~lr = 1e-3
 
 
+def test_split_bf16_step_is_bit_reproducible(gemm):
+    """No atomics on the split-bf16 path (split reductions go through ordered partial sums): the same forward / backward twice gives
+    the same bits, at a size where dW, db, forward and dX all split (B = 8, 256 -> 256 channels, L = 1200: 12 dW tiles -> 8 parts)."""
+    if gemm != "split_bf16":
+        pytest.skip("the exact-fp32 path adds its dW parts with fp32 atomics")
+    e = engine("r84", "f32")
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 256, 1200, generator=gen).cuda()
+    w = (torch.randn(256, 256, 3, generator=gen) * 0.05).cuda()
+    b = (torch.randn(256, generator=gen) * 0.1).cuda()
+    dy = torch.randn(8, 256, 1200, generator=gen).cuda()
+    outs = []
+    for _ in range(2):
+        cv = TR.Conv1d(e, w, b, 1, 1)
+        y = cv.forward(x)
+        g = cv.backward(dy)
+        outs.append((y.clone(), g["dx"].clone(), g["dw"].clone(), g["db"].clone()))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    # and a deep-level shape whose forward / dX split their reduction (19 x 8 tiles -> 4 parts)
+    x = torch.randn(32, 1024, 75, generator=gen).cuda()
+    w = (torch.randn(1024, 1024, 3, generator=gen) * 0.02).cuda()
+    dy = torch.randn(32, 1024, 75, generator=gen).cuda()
+    outs = []
+    for _ in range(2):
+        cv = TR.Conv1d(e, w, None, 1, 1)
+        y = cv.forward(x)
+        g = cv.backward(dy)
+        outs.append((y.clone(), g["dx"].clone(), g["dw"].clone()))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    want = torch.nn.functional.conv1d(x.cpu().double(), w.cpu().double(), None, padding=1)
+    assert rel(outs[0][0].cpu().numpy(), want.numpy()) < 2e-5
+
+
 def test_frozen_encoders_prefetched_on_a_second_engine_give_the_same_steps():
     """DiffusionTrainer(frontend=...): the encoders of the next batch run on a side stream / second engine under the current step; three
     steps over two alternating batches must give the encodings (bitwise) and the losses of the in-line trainer."""
