@@ -89,3 +89,47 @@ class BenchGolden:
         c = checksums(got)
         r = self.g[key + ".sum"]
         return float(np.abs(c - r).max() / (np.abs(r[1]) + 1e-30))
+
+
+# ---- inputs of the two 50-step CLI tests (tests/test_gpu_frontend.py) and of their fixture generator (tools/gen_golden_cli.py) ----
+def cli50_default_audio(k, n=5120):
+    from ladiffcodec_amd import synth
+    return (synth.synthetic_wav(1, n, seed=300 + k)[0, 0] * 0.5).astype(np.float32)
+
+
+def cli50_default_tape(i, Lz, steps=50):
+    return torch.randn(steps, 1, 128, Lz, generator=torch.Generator().manual_seed(9000 + i))
+
+
+def cli50_c5_audio(chunk=38400):
+    from ladiffcodec_amd import synth
+    n = 12 * chunk + chunk // 2 + 100                              # 30 s (and a few samples more)
+    return (synth.synthetic_wav(1, n, seed=515)[0, 0] * 0.5).astype(np.float32)
+
+
+def cli50_c5_plan(n, chunk=38400):
+    tail = (n - 12 * chunk) // 2560 * 2560                          # 1.12 s: whole 2560-sample quanta (cond frames x UNet halvings)
+    return [(k * chunk, chunk) for k in range(12)] + [(12 * chunk, tail)], chunk
+
+
+def cli50_c5_tape(k, Lz, steps=50):
+    return torch.randn(steps, 1, 128, Lz, generator=torch.Generator().manual_seed(7000 + k))
+
+
+def fake_quantise_unet(sd_np, u):
+    """What the library does to every UNet conv weight in an fp8-weight context: weight-standardise the Block convs
+    (unet.py:73-78), then per output channel scale = max|w| / 448 and OCP e4m3 round-to-nearest-even; returns the state
+    dict with the dequantised values (Block convs stay standardised: the oracle runs with WS_PREFOLDED)."""
+    from oracle import ldc_oracle as O
+    out = {}
+    for k, v in sd_np.items():
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        is_conv = k.startswith("diff_model.") and t.dim() == 3 and "upsampling_layers" not in k and not k.endswith(".g")
+        if is_conv:
+            if ".block1.proj.weight" in k or ".block2.proj.weight" in k:
+                t = O.ws_fold(t)
+            amax = t.abs().amax(dim=(1, 2), keepdim=True)
+            sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+            t = (t / sc).to(torch.float8_e4m3fn).float() * sc
+        out[k] = t
+    return out

@@ -290,22 +290,7 @@ def test_plan_cache_is_bounded():
 
 
 # ------------------------------------------------------------------------------------------- fp8 UNet weights (BASELINE config 5)
-def fake_quantise_unet(sd_np, u):
-    """What the library does to every UNet conv weight in an fp8-weight context: weight-standardise the Block convs
-    (unet.py:73-78), then per output channel scale = max|w| / 448 and OCP e4m3 round-to-nearest-even; returns the state
-    dict with the dequantised values (Block convs stay standardised: the oracle runs with WS_PREFOLDED)."""
-    out = {}
-    for k, v in sd_np.items():
-        t = torch.from_numpy(np.ascontiguousarray(v))
-        is_conv = k.startswith("diff_model.") and t.dim() == 3 and "upsampling_layers" not in k and not k.endswith(".g")
-        if is_conv:
-            if ".block1.proj.weight" in k or ".block2.proj.weight" in k:
-                t = O.ws_fold(t)
-            amax = t.abs().amax(dim=(1, 2), keepdim=True)
-            sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-            t = (t / sc).to(torch.float8_e4m3fn).float() * sc
-        out[k] = t
-    return out
+from helpers import fake_quantise_unet  # noqa: E402,F401  (shared with tools/gen_golden_cli.py)
 
 
 @pytest.mark.parametrize("act8", [0, 1])

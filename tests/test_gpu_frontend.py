@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 from ladiffcodec_amd import synth  # noqa: E402
 from oracle import ldc_oracle as O, resample_oracle as RO  # noqa: E402
-from helpers import CASES, COND_CFG, T, cond_sd_np, main_sd_np  # noqa: E402
+from helpers import (CASES, COND_CFG, T, cli50_c5_audio, cli50_c5_plan, cli50_c5_tape, cli50_default_audio, cli50_default_tape, cond_sd_np,  # noqa: E402
+                     load_golden, main_sd_np)
 from gpu_common import engine, rel  # noqa: E402
 
 
@@ -128,28 +129,20 @@ def test_cli_default_mode_bf16_50_steps_in_flight(tmp_path):
     ind.mkdir()
     n, steps = 5120, 50
     names = [f"u{k}.wav" for k in range(7)]                       # sorted glob order = this order
-    xs = {}
     for k, name in enumerate(names):
-        xs[name] = (synth.synthetic_wav(1, n, seed=300 + k)[0, 0] * 0.5).astype(np.float32)
-        wavfile.write(str(ind / name), 16000, xs[name])
-    Lz = n // mc.hop_length
-
-    def tape(i):
-        return torch.randn(steps, 1, 128, Lz, generator=torch.Generator().manual_seed(9000 + i))
-
+        wavfile.write(str(ind / name), 16000, cli50_default_audio(k, n))
     args = cli.build_parser().parse_args([
         "--model_for_cond", str(tmp_path / "codec.amlt"), "--model_path", str(tmp_path / "ladiff.amlt"), "--run_diff", "--scaling_global",
         "--cond_bandwidth", "3", "--unet_scale_cond", "--enc_ratios", "8", "4", "--upsampling_ratios", "5", "2", "--diff_dims", "32",
         "--input_dir", str(ind) + "/", "--output_dir", str(outd) + "/", "--midway_t", str(steps), "--batch_size", "2"])
     assert args.dtype == "bf16" and args.in_flight == 2
-    args.noise_provider = lambda idxs, n_steps, L: torch.cat([tape(i) for i in idxs], dim=1)
+    args.noise_provider = lambda idxs, n_steps, L: torch.cat([cli50_default_tape(i, L, n_steps) for i in idxs], dim=1)
     written = cli.synthesis(args)
     assert len(written) == 7
-    sdc, sdm = synth.to_torch(cond_sd_np()), synth.to_torch(main_sd_np("r84"))
+    g = load_golden("cli50")                 # the oracle's decode of every file alone with the same tape (tools/gen_golden_cli.py)
     for i, name in enumerate(names):
         y = wavfile.read(str(outd / name))[1]
-        ref = O.decode_utterances(sdc, COND_CFG, sdm, mc, u, T(xs[name]).reshape(1, 1, n), steps, tape(i))
-        check("bf16", "wav_cli50", rel(y, ref["wav"].numpy().reshape(-1)), name)
+        check("bf16", "wav_cli50", rel(y, g[f"default.{i}"]), name)
 
 
 def test_cli_config5_long_form_fp8_50_steps(tmp_path):
@@ -160,43 +153,25 @@ def test_cli_config5_long_form_fp8_50_steps(tmp_path):
     from scipy.io import wavfile
     from ladiffcodec_amd import sample as cli
     from drift_tolerances import check
-    from test_gpu_bench_shape import fake_quantise_unet
     mc, u, _ = CASES["r84"]
     synth.save_amlt(main_sd_np("r84"), str(tmp_path / "ladiff.amlt"))
     synth.save_amlt(cond_sd_np(), str(tmp_path / "codec.amlt"))
     ind, outd = tmp_path / "in", tmp_path / "out"
     ind.mkdir()
-    chunk, steps = 38400, 50
-    n = 12 * chunk + chunk // 2 + 100                              # 30 s (and a few samples more)
-    tail = (n - 12 * chunk) // 2560 * 2560                          # 1.12 s: whole 2560-sample quanta (cond frames x UNet halvings)
-    x = (synth.synthetic_wav(1, n, seed=515)[0, 0] * 0.5).astype(np.float32)
+    steps = 50
+    x = cli50_c5_audio()
+    plan, chunk = cli50_c5_plan(x.size)
+    tail = plan[12][1]
     wavfile.write(str(ind / "long.wav"), 16000, x)
-    plan = [(k * chunk, chunk) for k in range(12)] + [(12 * chunk, tail)]
-
-    def tape(k, Lz):
-        return torch.randn(steps, 1, 128, Lz, generator=torch.Generator().manual_seed(7000 + k))
-
     args = cli.build_parser().parse_args([
         "--model_for_cond", str(tmp_path / "codec.amlt"), "--model_path", str(tmp_path / "ladiff.amlt"), "--run_diff", "--scaling_global",
         "--cond_bandwidth", "3", "--unet_scale_cond", "--enc_ratios", "8", "4", "--upsampling_ratios", "5", "2", "--diff_dims", "32",
         "--input_dir", str(ind) + "/", "--output_dir", str(outd) + "/", "--midway_t", str(steps), "--dtype", "fp8", "--chunk_sec", "2.4"])
-    args.noise_provider = lambda keys, n_steps, Lz: torch.cat([tape(k, Lz) for _, k in keys], dim=1)
+    args.noise_provider = lambda keys, n_steps, Lz: torch.cat([cli50_c5_tape(k, Lz, n_steps) for _, k in keys], dim=1)
     written = cli.synthesis(args)
     assert len(written) == 1
     sr_out, y = wavfile.read(str(outd / "long.wav"))
     assert sr_out == 16000 and y.shape == (12 * chunk + tail,)
-    sdc = synth.to_torch(cond_sd_np())
-    sd_q = fake_quantise_unet(main_sd_np("r84"), u)
-    O.WS_PREFOLDED, O.ACT_FP8 = True, True
-    try:
-        # the twelve full chunks as one oracle batch (utterances do not interact), the tail alone
-        xb = torch.stack([T(x[st:st + chunk]) for st, _ in plan[:12]]).reshape(12, 1, chunk)
-        nb = torch.cat([tape(k, chunk // mc.hop_length) for k in range(12)], dim=1)
-        full = O.decode_utterances(sdc, COND_CFG, sd_q, mc, u, xb, steps, nb, per_item=True)["wav_raw"]
-        st, ln = plan[12]
-        last = O.decode_utterances(sdc, COND_CFG, sd_q, mc, u, T(x[st:st + ln]).reshape(1, 1, ln), steps, tape(12, ln // mc.hop_length), per_item=True)["wav_raw"]
-    finally:
-        O.WS_PREFOLDED, O.ACT_FP8 = False, False
-    raws = [full[k:k + 1] for k in range(12)] + [last]
-    whole = O.output_normalise(torch.cat(raws, dim=-1))
-    check("fp8", "wav_c5", rel(y, whole.numpy().reshape(-1)))
+    # the oracle's result (chunk by chunk on the fake-quantised weights / activations, joined, normalised over the recording) is a
+    # fixture since round 3: tools/gen_golden_cli.py, tests/golden/cli50.npz
+    check("fp8", "wav_c5", rel(y, load_golden("cli50")["c5.whole"]))
