@@ -10,7 +10,8 @@
 // the tolerance the training parity tests already carry against the reference's own autograd).  Three v_mfma_f32_32x32x16_bf16 cost
 // 96 cycles for 16 reduction steps where the fp32 MFMA takes 512: the bound moves from the matrix pipe to staging, so the kernel is
 // built around that:
-//   * 128 x 128 output tile per workgroup (2 x 2 waves of 64 x 64 = 2 x 2 MFMA blocks), reduction chunks of 32, LDS double-buffered
+//   * 128 x 128 output tile per workgroup (eight waves of 32 x 64 = 1 x 2 MFMA blocks: 127 registers, four waves per SIMD; LDC_MM3_NW=4
+//     selects 2 x 2 waves of 64 x 64), reduction chunks of 32, LDS double-buffered
 //     (4 planes -- A hi / A lo / B hi / B lo -- of 128 rows x 64 B, 16-byte slots XOR-swizzled by (row >> 2) & 3: fragment reads and
 //     staging writes are conflict-free ds_read/write_b128), one barrier per chunk, the global loads of chunk i + 1 in flight under
 //     the MFMAs of chunk i;
@@ -97,11 +98,17 @@ __global__ __launch_bounds__(256) void mm3_pack_kernel(const float* w, int Cin, 
 // TAIL (MODE 2): Lout is not a multiple of 4 (the L = 150 / 75 levels): dy is read as dwords instead of dwordx4
 // VECB (MODE 2): stride 1 -- x is read as one (unaligned) dwordx4 per pass from a start clamped into the row; the threads whose four
 // positions straddle the padding (first / last of a row) get them shifted, which store() undoes for exactly those lanes
-template <int MODE, bool TAIL, bool VECB = false>
-__global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ Asrc, const float* __restrict__ Bsrc, const float* __restrict__ bias,
+// NW: waves per workgroup (4: 2 x 2 waves of 64 x 64; 8: 4 x 2 waves of 32 x 64 -- half the registers per wave, four waves per SIMD)
+template <int MODE, bool TAIL, bool VECB = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __restrict__ Asrc, const float* __restrict__ Bsrc, const float* __restrict__ bias,
                                                      float* __restrict__ out, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
                                                      int nsplit, int MP, int RP) {
   __shared__ u32x4 lds[2][4][512];   // [stage][A hi, A lo, B hi, B lo][row * 4 + (slot ^ swizzle)]
+  constexpr int NT = 64 * NW;          // threads
+  constexpr int TMW = 8 / NW;          // 32-row blocks per wave (the wave tile is 32 TMW x 64)
+  constexpr int KPT = 64 / NW;         // MODE 0 / 1: reduction indices per thread and chunk (two octets or one)
+  constexpr int PASSES = 16 / NW;      // MODE 2: row passes per chunk (8 NW rows each)
+  constexpr int RPP = 8 * NW;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, i32 = lane & 31, g = lane >> 5;
   const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
   const int z = MODE == 2 ? (int)blockIdx.z / nsplit : 0, part = MODE == 2 ? (int)blockIdx.z % nsplit : 0;
@@ -122,9 +129,9 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
   const int it_begin = MODE == 2 ? 0 : (int)((long long)it_all * kpart / nsplit);
   const int n_it = (MODE == 2 ? it_all : (int)((long long)it_all * (kpart + 1) / nsplit)) - it_begin;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TMW][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TMW; ++a)
 #pragma unroll
     for (int b2 = 0; b2 < 2; ++b2)
 #pragma unroll
@@ -137,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
   // HBM / far-L2 round trip with two workgroups per CU).
   struct Stage {
     u32x4 a0, a1, a2, a3;   // MODE 0 / 1: packed weights (hi, lo of two k-octets)
-    float a[16];            // MODE 2: dy
-    float b[16];            // activations
+    float a[4 * PASSES];    // MODE 2: dy
+    float b[KPT > 4 * PASSES ? KPT : 4 * PASSES];   // activations
     int nv;                 // TAIL: valid reduction indices of this thread's 16
     bool ok;                // MODE 0 / 1: this thread's column is inside the item for the chunk's tap (applied when the set is
                             // written to LDS: a select right after the load would wait for it inside fetch)
@@ -157,16 +164,16 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
   bool bok = false;
   // MODE 2: per-pass row pointers (advanced by a chunk of positions), row predicates
   // (32-bit element offsets from the item's wave-uniform base: eight 64-bit pointers spilled)
-  int qa[4] = {0, 0, 0, 0}, qb[4] = {0, 0, 0, 0};
+  int qa[PASSES], qb[PASSES];
   int a_last = 0;
   const float* baseA = nullptr;
   const float* baseB = nullptr;
-  bool oka[4] = {false, false, false, false}, okb[4] = {false, false, false, false};
+  bool oka[PASSES], okb[PASSES];
   int f_outer = outer_lo + it_begin / nchunk, f_chunk = it_begin % nchunk;
 
   auto setup_outer = [&](int outer) {
     if (MODE != 2) {
-      pA = (const u32x4*)Asrc + (((size_t)outer * MP + m0 + r128) * (RP / 8) + 2 * h) * 2;
+      pA = (const u32x4*)Asrc + (((size_t)outer * MP + m0 + r128) * (RP / 8) + (KPT / 8) * h) * 2;
       int pos;
       if (MODE == 0) {
         pos = cl * S + outer - P;
@@ -177,13 +184,13 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
         pos = bok ? (S == 1 ? u : u / S) : 0;
         bok = bok && pos < Lout;
       }
-      pB = Bsrc + ((size_t)cb * red + 16 * h) * Lsrc + (bok ? pos : 0);
+      pB = Bsrc + ((size_t)cb * red + KPT * h) * Lsrc + (bok ? pos : 0);
       pA += 8 * f_chunk;                       // (non-zero only for the first step of a split reduction)
       pB += (size_t)32 * f_chunk * Lsrc;
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int row = 32 * p + (tid >> 3);
+      for (int p = 0; p < PASSES; ++p) {
+        const int row = RPP * p + (tid >> 3);
         const int o = m0 + row, i = n0 + row;
         oka[p] = o < Cout;
         okb[p] = i < Cin;
@@ -200,14 +207,15 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
   auto fetch = [&](Stage& r) {
     const int k0 = f_chunk * 32;
     if (MODE != 2) {
-      r.a0 = pA[0]; r.a1 = pA[1]; r.a2 = pA[2]; r.a3 = pA[3];
+      r.a0 = pA[0]; r.a1 = pA[1];
+      if (KPT == 16) { r.a2 = pA[2]; r.a3 = pA[3]; }
       pA += 8;
       // straight-line on purpose: with a branch in here the compiler's s_waitcnt bookkeeping falls back to "everything older", which
       // drains the set that was loaded one iteration ago together with the one just issued
       r.ok = bok;
-      r.nv = red - (k0 + 16 * h);
+      r.nv = red - (k0 + KPT * h);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < KPT; ++j) {
         const float* q = pB + (size_t)j * Lsrc;
         if (TAIL) q = j < r.nv ? q : Bsrc;
         r.b[j] = *q;
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
       const int lq = k0 + 4 * (tid & 7);
       r.nv = lq;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < PASSES; ++p) {
         if (!TAIL) {
           const f32x4u v = *(const f32x4u*)(baseA + min(qa[p] + k0, a_last));
 #pragma unroll
@@ -245,25 +253,32 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
       if (++f_outer < outer_hi) setup_outer(f_outer);
     }
   };
-  float rs[4] = {0.f, 0.f, 0.f, 0.f};   // MODE 2, bias gradient: sums of this thread's dy values per row pass
+  float rs[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) rs[p] = 0.f;   // MODE 2, bias gradient: sums of this thread's dy values per row pass
   const bool do_db = MODE == 2 && bias != nullptr && blockIdx.x == 0 && z == 0;
   auto store = [&](const Stage& r, int st) {
     if (MODE != 2) {
       const int sw = (r128 >> 2) & 3;
-      lds[st][0][r128 * 4 + ((2 * h) ^ sw)] = r.a0;
-      lds[st][1][r128 * 4 + ((2 * h) ^ sw)] = r.a1;
-      lds[st][0][r128 * 4 + ((2 * h + 1) ^ sw)] = r.a2;
-      lds[st][1][r128 * 4 + ((2 * h + 1) ^ sw)] = r.a3;
+      constexpr int NOCT = KPT / 8;                       // octets (16-byte LDS slots) per thread: 2 or 1
+      lds[st][0][r128 * 4 + ((NOCT * h) ^ sw)] = r.a0;
+      lds[st][1][r128 * 4 + ((NOCT * h) ^ sw)] = r.a1;
+      if (NOCT == 2) {
+        lds[st][0][r128 * 4 + ((2 * h + 1) ^ sw)] = r.a2;
+        lds[st][1][r128 * 4 + ((2 * h + 1) ^ sw)] = r.a3;
+      }
       u32x4 hi, lo;
-      float b[16];
+      float b[KPT];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) b[j] = (r.ok && (!TAIL || j < r.nv)) ? r.b[j] : 0.f;
+      for (int j = 0; j < KPT; ++j) b[j] = (r.ok && (!TAIL || j < r.nv)) ? r.b[j] : 0.f;
       split8(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], hi, lo);
-      lds[st][2][r128 * 4 + ((2 * h) ^ sw)] = hi;
-      lds[st][3][r128 * 4 + ((2 * h) ^ sw)] = lo;
-      split8(b[8], b[9], b[10], b[11], b[12], b[13], b[14], b[15], hi, lo);
-      lds[st][2][r128 * 4 + ((2 * h + 1) ^ sw)] = hi;
-      lds[st][3][r128 * 4 + ((2 * h + 1) ^ sw)] = lo;
+      lds[st][2][r128 * 4 + ((NOCT * h) ^ sw)] = hi;
+      lds[st][3][r128 * 4 + ((NOCT * h) ^ sw)] = lo;
+      if (NOCT == 2) {
+        split8(b[KPT - 8], b[KPT - 7], b[KPT - 6], b[KPT - 5], b[KPT - 4], b[KPT - 3], b[KPT - 2], b[KPT - 1], hi, lo);
+        lds[st][2][r128 * 4 + ((2 * h + 1) ^ sw)] = hi;
+        lds[st][3][r128 * 4 + ((2 * h + 1) ^ sw)] = lo;
+      }
     } else {
       const int slot = (tid & 7) >> 1, half = tid & 1;
       const int lq = r.nv, pos0 = lq * S + z - P;
@@ -277,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
         mb[e] = (pos >= 0 && pos < Lin) ? 1.f : 0.f;
       }
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int row = 32 * p + (tid >> 3), sw = (row >> 2) & 3;
+      for (int p = 0; p < PASSES; ++p) {
+        const int row = RPP * p + (tid >> 3), sw = (row >> 2) & 3;
         const int at = (row * 4 + (slot ^ sw)) * 2 + half;     // in 8-byte units
         u32x2 hi, lo;
         // (rows past M / N are clamped reads of row 0: they only reach output rows / columns that are never stored; the clamped
@@ -315,10 +330,10 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int slot = ((2 * ks + g) ^ swl);
-      V8 ah[2], al[2], bh[2], bl[2];
+      V8 ah[TMW], al[TMW], bh[2], bl[2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int row = 64 * wm + 32 * a + i32;
+      for (int a = 0; a < TMW; ++a) {
+        const int row = 32 * TMW * wm + 32 * a + i32;
         ah[a].u = lds[st][0][row * 4 + slot];
         al[a].u = lds[st][1][row * 4 + slot];
       }
@@ -328,17 +343,17 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
         bh[b2].u = lds[st][2][row * 4 + slot];
         bl[b2].u = lds[st][3][row * 4 + slot];
       }
-      // term-major: four independent accumulators between two MFMAs into the same one
+      // term-major: independent accumulators between two MFMAs into the same one
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TMW; ++a)
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a].v, bh[b2].v, acc[a][b2], 0, 0, 0);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TMW; ++a)
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bl[b2].v, acc[a][b2], 0, 0, 0);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TMW; ++a)
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bh[b2].v, acc[a][b2], 0, 0, 0);
     }
@@ -408,10 +423,10 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
 
   if (do_db) {   // bias gradient of this part: db[part][o] = sum over its items and positions of dy (the eight lanes of a row meet by shuffles)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < PASSES; ++p) {
       float v = rs[p];
       v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-      const int o = m0 + 32 * p + (tid >> 3);
+      const int o = m0 + RPP * p + (tid >> 3);
       if ((tid & 7) == 0 && o < Cout) const_cast<float*>(bias)[(size_t)part * Cout + o] = v;   // (`bias` = db, or the parts' rows of the workspace)
     }
   }
@@ -436,10 +451,10 @@ __global__ __launch_bounds__(256, 2) void mm3_kernel(const void* __restrict__ As
       rstride = (size_t)Lcol;
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TMW; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 64 * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const int m = m0 + 32 * TMW * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * g;
         if (m >= M) continue;
         const float v = acc[a][b2][r];
         const float add = (MODE != 2 && bias && kpart == 0) ? bias[m] : 0.f;
@@ -509,6 +524,11 @@ float* dw_workspace(size_t bytes, hipStream_t s) {
   return (float*)g_dw_ws;
 }
 inline int up(int v, int q) { return (v + q - 1) / q * q; }
+// waves per workgroup of the GEMM kernels (LDC_MM3_NW = 4 | 8; see mm3_kernel)
+inline int mm3_nw() {
+  static const int nw = getenv("LDC_MM3_NW") ? atoi(getenv("LDC_MM3_NW")) : 8;   // 8 measured 3 % faster per step (dW 10 %)
+  return nw == 4 ? 4 : 8;
+}
 // forward / dX: parts of the (tap, channel chunk) reduction per output tile.  The chip holds 512 workgroups (two per CU); below
 // ~0.75 of that the tiles are split, as long as a part keeps >= 16 steps (the two-deep prefetch needs a few to reach its stride).
 inline int reduction_split(long tiles, int steps) {
@@ -537,9 +557,10 @@ hipError_t launch_mm3_forward(const float* x, const float* w, const float* bias,
     if (!target) return hipErrorOutOfMemory;
   }
   const dim3 grid((unsigned)((N + 127) / 128), MP / 128, ks);
-  if (Cin % 32 == 0)
-    hipLaunchKernelGGL((mm3_kernel<0, false>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
-  else
+  if (Cin % 32 == 0) {
+    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<0, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    else hipLaunchKernelGGL((mm3_kernel<0, false, false, 4>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+  } else
     hipLaunchKernelGGL((mm3_kernel<0, true>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
   if (ks > 1)
     hipLaunchKernelGGL(mm3_sum_parts_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 8192)), dim3(256), 0, s, (const float*)target, ks, n_out, y);
@@ -561,9 +582,10 @@ hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Co
     if (!target) return hipErrorOutOfMemory;
   }
   const dim3 grid((unsigned)((N + 127) / 128), MP / 128, ks);
-  if (Cout % 32 == 0)
-    hipLaunchKernelGGL((mm3_kernel<1, false>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
-  else
+  if (Cout % 32 == 0) {
+    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<1, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    else hipLaunchKernelGGL((mm3_kernel<1, false, false, 4>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+  } else
     hipLaunchKernelGGL((mm3_kernel<1, true>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
   if (ks > 1)
     hipLaunchKernelGGL(mm3_sum_parts_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 8192)), dim3(256), 0, s, (const float*)target, ks, n_out, dx);
@@ -587,7 +609,10 @@ hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Co
   const dim3 grid((Cin + 127) / 128, (Cout + 127) / 128, K * nsplit);
   const bool vecb = S == 1 && Lin >= 4;
 #define LDC_MM3_DW(TAIL_, VECB_) \
-  hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_>), grid, dim3(256), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0)
+  do { \
+    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 8>), grid, dim3(512), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0); \
+    else hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 4>), grid, dim3(256), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0); \
+  } while (0)
   if (Lout % 4 == 0) { if (vecb) LDC_MM3_DW(false, true); else LDC_MM3_DW(false, false); }
   else { if (vecb) LDC_MM3_DW(true, true); else LDC_MM3_DW(true, false); }
 #undef LDC_MM3_DW
