@@ -133,3 +133,31 @@ def fake_quantise_unet(sd_np, u):
             t = (t / sc).to(torch.float8_e4m3fn).float() * sc
         out[k] = t
     return out
+
+
+def libri_tree(root):
+    """A LibriSpeech-shaped tree of int16 wavs (tests/test_dataset_cpu.py, tools/gen_golden_dataset.py): train-clean-100 with files
+    of different lengths, one silent, one shorter than a 0.5 s crop, one with a -32768 sample and a long silent stretch; dev-clean
+    with two files (one shorter than the crop)."""
+    import scipy.io.wavfile as wavfile
+    rng = np.random.default_rng(77)
+
+    def put(split, spk, chap, k, x):
+        d = os.path.join(root, split, str(spk), str(chap))
+        os.makedirs(d, exist_ok=True)
+        wavfile.write(os.path.join(d, f"{spk}-{chap}-{k:04d}.wav"), 16000, x.astype(np.int16))
+
+    def tone(n, f, amp):
+        t = np.arange(n) / 16000.0
+        return amp * np.sin(2 * np.pi * f * t) + 0.05 * amp * rng.standard_normal(n)
+
+    put("train-clean-100", 103, 1240, 0, tone(20000, 220.0, 9000))
+    put("train-clean-100", 103, 1240, 1, np.zeros(12000))                              # silent: skipped
+    put("train-clean-100", 103, 1241, 0, tone(5000, 330.0, 12000))                     # shorter than the crop: skipped
+    x = tone(30000, 150.0, 20000)
+    x[4000:26000] = 0                                                                   # silent stretch: crops there are redrawn
+    x[100] = -32768                                                                     # int16 abs wraps
+    put("train-clean-100", 1034, 121119, 0, x)
+    put("train-clean-100", 1034, 121119, 1, tone(8000, 440.0, 3000))                   # exactly the crop length
+    put("dev-clean", 84, 121123, 0, tone(16000, 200.0, 15000))
+    put("dev-clean", 84, 121123, 1, tone(3000, 500.0, 7000))                           # shorter than the crop

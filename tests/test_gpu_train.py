@@ -363,6 +363,42 @@ def test_frozen_encoders_prefetched_on_a_second_engine_give_the_same_steps():
     assert got[0] == want[0] and max(abs(a - b) for a, b in zip(got, want)) < 2e-4, (got, want)
 
 
+def test_training_loop_from_the_dataset_walker(tmp_path):
+    """The pieces of the reference's --run_diff loop together (srcs/train.py:110-177, 322-336): Dataset_Libri-shaped walker -> float32
+    [B, 1, T] batches uploaded one ahead on a side stream -> DiffusionTrainer.step_from_wav with the next batch's frozen encoders
+    prefetched on a second engine; the losses must be those of the plain loop over the same crops."""
+    from ladiffcodec_amd import lib as L
+    from ladiffcodec_amd.dataset import BatchWalker, DatasetLibri
+    from ladiffcodec_amd.model import Engine
+    from helpers import CASES, COND_CFG, cond_sd_np, libri_tree, main_sd_np
+    mc, u, _ = CASES["r84"]
+    libri_tree(str(tmp_path))
+    e = engine("r84", "f32")
+    front = Engine(mc, u, COND_CFG, dtype="f32")
+    front.load_state_dict(L.MODEL_MAIN, main_sd_np("r84"))
+    front.load_state_dict(L.MODEL_COND, cond_sd_np())
+    front.finalize(strict=True)
+    sd = {k[len("diff_model."):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in main_sd_np("r84").items() if k.startswith("diff_model.")}
+    kw = dict(dim=u.dim, dim_mults=u.dim_mults, lr=1e-3, upsampling_ratios=u.upsampling_ratios, unet_scale_cond=u.unet_scale_cond)
+    ds = DatasetLibri(task="train", seq_len_p_sec=0.16, data_folder_path=str(tmp_path))      # 2560-sample crops
+    ds.files = sorted(ds.files)
+    gen = torch.Generator().manual_seed(4)
+    ts = [torch.randint(0, 1000, (2,), generator=gen) for _ in range(3)]
+    noises = [torch.randn(2, 128, 2560 // mc.hop_length, generator=gen) for _ in range(3)]
+    torch.manual_seed(7)
+    crops = [torch.from_numpy(np.stack([np.asarray(ds[i]) for i in idx])).unsqueeze(1).float() for idx in ([0, 1], [2, 3], [4])]
+    plain = TR.DiffusionTrainer(e, {k: v.clone() for k, v in sd.items()}, **kw)
+    want = [float(plain.step_from_wav(c, t=t[:c.shape[0]], noise=n[:c.shape[0]]).cpu()[0]) for c, t, n in zip(crops, ts, noises)]
+    torch.manual_seed(7)
+    tr = TR.DiffusionTrainer(e, {k: v.clone() for k, v in sd.items()}, frontend=front, **kw)
+    walker = BatchWalker(ds, batch_size=2, device="cuda")
+    got = []
+    for k, wav in enumerate(walker):
+        assert wav.is_cuda and wav.dtype == torch.float32 and torch.equal(wav.cpu(), crops[k])
+        got.append(float(tr.step_from_wav(wav, t=ts[k][:wav.shape[0]], noise=noises[k][:wav.shape[0]], next_wav=walker.peek()).cpu()[0]))
+    assert len(got) == 3 and got[0] == want[0] and max(abs(a - b) for a, b in zip(got, want)) < 2e-4, (got, want)
+
+
 def test_full_width_training_step_reference_vectors(gemm):
     """ONE optimisation step at the size BASELINE configs[3] names (diff_dims 256, seq_length 1200, enc_ratios 8 4; the grids
     `bench.py --config c4` times) driven from audio, against the reference under torch autograd (tests/golden/train256.npz,
