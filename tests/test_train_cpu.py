@@ -104,3 +104,32 @@ def test_oracle_unet_with_process_cond_matches_reference_autograd():
     assert rel_err(x.grad.numpy(), g["u.dx"]) < 1e-4 and rel_err(c.grad.numpy(), g["u.dcond"]) < 1e-4
     worst = max((rel_err(v.grad.numpy(), g["u.g." + k[len("diff_model."):]]), k) for k, v in sd.items())
     assert worst[0] < 1e-4, worst
+
+
+def test_trained_unet_goes_back_into_a_checkpoint_sample_py_loads(tmp_path):
+    """checkpoint.merged_state_dict + save_checkpoints (srcs/utils.py:85-95, train.py:410-414): the trained diff_model tensors land
+    under BOTH prefixes the reference's state dict carries (diff_model.* and its alias diffusion.model.*), the frozen parts are
+    carried over, the file is named model_<note>.amlt and reads back through the loader the decode path uses."""
+    import numpy as np
+    import torch
+    from ladiffcodec_amd import checkpoint, synth
+    from ladiffcodec_amd.spec import CodecConfig, UnetConfig
+    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    u = UnetConfig(dim=16, dim_mults=(1, 2), upsampling_ratios=(5, 2), unet_scale_cond=True)
+    base = synth.ladiff_state_dict(mc, u, seed=3)
+    assert any(k.startswith("diffusion.model.") for k in base) and any(k.startswith("diff_model.") for k in base)
+    trained = {k[len("diff_model."):]: torch.from_numpy(np.ascontiguousarray(v)) + 1.0 for k, v in base.items() if k.startswith("diff_model.")}
+    merged = checkpoint.merged_state_dict(base, trained)
+    assert list(merged) == list(base)
+    path = checkpoint.save_checkpoints(merged, str(tmp_path), "exp", note="best")
+    assert path.endswith("/exp/model_best.amlt")
+    back = checkpoint.read_amlt(path)
+    for k, v in base.items():
+        want = v + 1.0 if k.startswith(("diff_model.", "diffusion.model.")) and k.split(".", 2 if k.startswith("diffusion.") else 1)[-1] in trained else v
+        assert np.array_equal(back[k], np.asarray(want, np.float32)), k
+    try:
+        checkpoint.merged_state_dict(base, {"no.such.key": torch.zeros(1)})
+    except KeyError:
+        pass
+    else:
+        raise AssertionError("unknown trained key accepted")
