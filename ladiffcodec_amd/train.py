@@ -714,14 +714,20 @@ class DiffusionTrainer:
         """views of the flat gradient buffer, keyed like the state dict (valid after `step`)"""
         return self._views(self.flat_g)
 
-    def step(self, x_start, cond, t, noise, monitor: bool = False, wav=None, latent_scale: float = 18.0):
+    def step(self, x_start, cond, t, noise, monitor: bool = False, wav=None, latent_scale: float = 18.0, update: bool = True):
         """-> loss (float tensor [1]) of this step, evaluated before the update.  monitor=True returns what DiffAudioRep.forward
         reports besides (model.py:181-209): {'diff_loss', 'neg_loss', 'predicted_x_start', 'x_hat', 'x_t'} -- predicted_x_start
         from the step's own forward pass (the reference runs the UNet a second time under no_grad for the same numbers,
         ddpm_loss.py:416-420), x_hat = decoder(predicted_x_start * scale), neg_loss = mean clamp(-SD-SDR(wav, x_hat), -30):
-        the value srcs/train.py:401-408 selects the best checkpoint by."""
+        the value srcs/train.py:401-408 selects the best checkpoint by.  update=False is the validation pass of the reference
+        (model.eval() under torch.no_grad(), train.py:396-399): forward and losses only, no backward, no optimiser step."""
         from . import lib as LL, parallel
         eng = self.eng
+        if not update:
+            x_t = q_sample(eng, x_start, t, noise)
+            out = self.net.forward(x_t, t, cond)
+            loss = p_losses_objective(eng, out, noise, t, want_grad=False)
+            return self._report(loss, x_t, out, t, wav, latent_scale) if monitor else loss
         eng._grad_views, eng._grad_written = self._grad_views, set()
         try:
             x_t = q_sample(eng, x_start, t, noise)
@@ -736,8 +742,11 @@ class DiffusionTrainer:
             eng._grad_views = None
         parallel.allreduce_gradients(self.flat_g)      # no-op without a process group
         self.opt.step(self.flat_g)
-        if not monitor:
-            return loss
+        return self._report(loss, x_t, out, t, wav, latent_scale) if monitor else loss
+
+    def _report(self, loss, x_t, out, t, wav, latent_scale):
+        from . import lib as LL
+        eng = self.eng
         x0 = predict_x_start(eng, x_t, out, t)
         rep = {"diff_loss": loss, "predicted_x_start": x0, "x_t": x_t}
         if wav is not None:
@@ -747,7 +756,8 @@ class DiffusionTrainer:
             rep["neg_loss"] = rep["neg_per_item"].mean()
         return rep
 
-    def step_from_wav(self, wav, t=None, noise=None, latent_scale: float = 18.0, generator=None, monitor: bool = False, next_wav=None):
+    def step_from_wav(self, wav, t=None, noise=None, latent_scale: float = 18.0, generator=None, monitor: bool = False, next_wav=None,
+                      update: bool = True):
         """The step as srcs/train.py:110-160 + DiffAudioRep.forward (model.py:146-182) drive it from audio: cond =
         model_for_cond.get_cond(x); x_rep = encoder(x) (frozen) / 18 (--scaling_global); t ~ U{0..T-1}, noise ~ N(0, I)
         (ddpm_loss.py:443-449) unless given; then `step`.  The engine's inference kernels run the two frozen encoders."""
@@ -770,7 +780,7 @@ class DiffusionTrainer:
         # behind them would start when the GPU is nearly through
         if next_wav is not None and self.frontend is not None:
             self.prefetch(next_wav)
-        return self.step(x_rep, cond, t, noise, monitor=monitor, wav=wav, latent_scale=latent_scale)
+        return self.step(x_rep, cond, t, noise, monitor=monitor, wav=wav, latent_scale=latent_scale, update=update)
 
     def prefetch(self, wav):
         """frozen encoders of a coming batch on the side stream / second engine (consumed by the step_from_wav call that gets the same tensor)"""

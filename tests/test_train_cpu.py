@@ -133,3 +133,30 @@ def test_trained_unet_goes_back_into_a_checkpoint_sample_py_loads(tmp_path):
         pass
     else:
         raise AssertionError("unknown trained key accepted")
+
+
+def test_sampler_indices_are_the_distributed_samplers():
+    """train_loop.sampler_indices = torch's DistributedSampler(shuffle=True) after set_epoch (srcs/train.py:327, 386), incl. the padding
+    by wrapping when the file count does not divide by the world size; one rank = the reference's plain sequential DataLoader."""
+    from torch.utils.data import DistributedSampler
+    from ladiffcodec_amd.train_loop import sampler_indices
+    for n, world in ((10, 2), (7, 4), (3, 8), (16, 8)):
+        for epoch in (0, 3):
+            for rank in range(world):
+                ref = DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=True)
+                ref.set_epoch(epoch)
+                assert sampler_indices(n, rank, world, epoch=epoch) == list(ref), (n, world, epoch, rank)
+    assert sampler_indices(5, 0, 1, epoch=9) == [0, 1, 2, 3, 4]
+
+
+def test_train_loop_refuses_what_it_does_not_implement():
+    import pytest
+    from ladiffcodec_amd import train_loop
+    p = train_loop.build_parser()
+    with pytest.raises(SystemExit, match="only --run_diff"):
+        train_loop._unsupported(p.parse_args(["--freeze_ed", "--scaling_global", "--model_for_cond", "c", "--finetune_model", "m"]))
+    with pytest.raises(SystemExit, match="--use_disc"):
+        train_loop._unsupported(p.parse_args(["--run_diff", "--freeze_ed", "--scaling_global", "--model_for_cond", "c", "--finetune_model", "m", "--use_disc"]))
+    train_loop._unsupported(p.parse_args(["--run_diff", "--freeze_ed", "--scaling_global", "--model_for_cond", "c", "--finetune_model", "m"]))
+    a = p.parse_args([])
+    assert a.lr == 5e-4 and a.batch_size == 5 and a.seq_len_p_sec == 1.0 and a.diff_dims == 128 and a.output_dir == "saved_models"   # train.py:233-262
