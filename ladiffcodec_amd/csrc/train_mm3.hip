@@ -6,20 +6,22 @@
 //
 // Here every fp32 operand a is split into two bf16 numbers, a = hi + lo + O(2^-17 |a|) with hi = bf16(a), lo = bf16(a - hi), and a
 // product is three bf16 MFMAs accumulated in fp32:   a b ~= hi_a hi_b + hi_a lo_b + lo_a hi_b   (the dropped lo_a lo_b and the two
-// residuals are 2^-16 |a b| each, random in sign: the sums agree with an fp32 fmaf chain to ~1e-6 relative in the tests, well inside
-// the tolerance the training parity tests already carry against the reference's own autograd).  Three v_mfma_f32_32x32x16_bf16 cost
+// residuals are 2^-16 |a b| each, random in sign: 4-5e-6 of a tensor's maximum against float64 conv1d where the exact-fp32 MFMA gives 1e-6,
+// inside the 1e-4 the training parity tests carry against the reference's own autograd).  Three v_mfma_f32_32x32x16_bf16 cost
 // 96 cycles for 16 reduction steps where the fp32 MFMA takes 512: the bound moves from the matrix pipe to staging, so the kernel is
 // built around that:
 //   * 128 x 128 output tile per workgroup (eight waves of 32 x 64 = 1 x 2 MFMA blocks: 127 registers, four waves per SIMD; LDC_MM3_NW=4
 //     selects 2 x 2 waves of 64 x 64), reduction chunks of 32, LDS double-buffered
 //     (4 planes -- A hi / A lo / B hi / B lo -- of 128 rows x 64 B, 16-byte slots XOR-swizzled by (row >> 2) & 3: fragment reads and
-//     staging writes are conflict-free ds_read/write_b128), one barrier per chunk, the global loads of chunk i + 1 in flight under
-//     the MFMAs of chunk i;
+//     staging writes are conflict-free ds_read/write_b128), one barrier per chunk, two register sets of global loads in flight (chunks
+//     i + 1 and i + 2 under the MFMAs of chunk i) with branch-free fetches -- see the notes at the loop;
 //   * the batch is folded into the GEMM's N (columns = (item, position)), so the L = 75 / 150 levels fill their tiles;
 //   * weights are split once per use by a pack kernel into [tap][row][k/8][hi x 8 | lo x 8] (rows and k zero-padded to the tile), so
 //     the A operand of forward / dX is four 16-byte loads per thread and chunk and needs no arithmetic;
-//   * activations ([B, C, L] fp32, the training layout) are gathered with the positions along the lanes (coalesced), 16 channels per
-//     thread, split in registers and written as whole 16-byte k-vectors.
+//   * activations ([B, C, L] fp32, the training layout) are gathered with the positions along the lanes (coalesced), 8 or 16 channels per
+//     thread, split in registers and written as whole 16-byte k-vectors;
+//   * no atomics: split reductions (dW over items, forward / dX over taps x channels when the tiles do not fill the chip, the bias
+//     gradient) write per-part partials that a second kernel sums in order -- device-scope fp32 atomics cost 43 % of the dW kernel.
 //   MODE 0 forward  y  [Cout x (B Lout)] = sum_t  W_t   [Cout x Cin]  . x  shifted by t    (+ bias)
 //   MODE 1 dX       dx [Cin  x (B Lin)]  = sum_t  W_t^T [Cin x Cout]  . dy shifted by -t
 //   MODE 2 dW       dW_t [Cout x Cin]    = sum_b  dy[b] [Cout x Lout] . x[b]^T shifted by t     (grid z = tap * nsplit + part)
