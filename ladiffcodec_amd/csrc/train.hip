@@ -527,6 +527,45 @@ __global__ __launch_bounds__(1024) void gn_silu_forward_kernel(const float* h, c
   if (threadIdx.x == 0) { stats[((size_t)b * groups + g) * 2] = mean; stats[((size_t)b * groups + g) * 2 + 1] = rstd; }
 }
 
+// The same op with the (item, group) slab kept in LDS (150 KB at every level of the full-width UNet: 32 x 1200, 64 x 600 ... floats; gfx950
+// gives one workgroup up to 160 KB): ONE read of h from memory instead of three, identical arithmetic in identical order (the
+// partial sums are per thread over i = tid, tid + 1024, ... exactly as above), so the results are bit-identical.
+__global__ __launch_bounds__(1024) void gn_silu_forward_lds_kernel(const float* h, const float* gamma, const float* beta, const float* ss,
+                                                                   int C, int L, int groups, float* y, float* stats) {
+  extern __shared__ float slab[];
+  __shared__ float red[16];
+  const int b = blockIdx.y, g = blockIdx.x, cpg = C / groups, n = cpg * L;
+  const float* p = h + ((size_t)b * C + (size_t)g * cpg) * L;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) { const float v = p[i]; slab[i] = v; s += v; }
+  const float mean = block_sum16(s, red) / (float)n;       // (the barriers inside make the slab visible to every thread)
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) { const float d = slab[i] - mean; q += d * d; }
+  const float rstd = rsqrtf(block_sum16(q, red) / (float)n + 1e-5f);
+  for (int cc = 0; cc < cpg; ++cc) {
+    const int c = g * cpg + cc;
+    const float sc = ss ? ss[(size_t)b * 2 * C + c] + 1.0f : 1.0f, sh = ss ? ss[(size_t)b * 2 * C + C + c] : 0.0f;
+    const float* pr = slab + (size_t)cc * L;
+    float* yr = y + ((size_t)b * C + c) * L;
+    for (int l = threadIdx.x; l < L; l += 1024) {
+      float v = (pr[l] - mean) * rstd * gamma[c] + beta[c];
+      if (ss) v = v * sc + sh;
+      yr[l] = v / (1.0f + expf(-v));
+    }
+  }
+  if (threadIdx.x == 0) { stats[((size_t)b * groups + g) * 2] = mean; stats[((size_t)b * groups + g) * 2 + 1] = rstd; }
+}
+static void launch_gn_silu_forward(const float* h, const float* gamma, const float* beta, const float* ss, int B, int C, int L, int groups,
+                                   float* y, float* stats, hipStream_t s) {
+  const size_t slab = (size_t)(C / groups) * L * sizeof(float);
+  static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gn_silu_forward_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024 - 256) == hipSuccess;
+  if (attr_ok && slab <= (size_t)160 * 1024 - 256 && !g_train_valu)
+    hipLaunchKernelGGL(gn_silu_forward_lds_kernel, dim3(groups, B), dim3(1024), slab, s, h, gamma, beta, ss, C, L, groups, y, stats);
+  else
+    hipLaunchKernelGGL(gn_silu_forward_kernel, dim3(groups, B), dim3(1024), 0, s, h, gamma, beta, ss, C, L, groups, y, stats);
+}
+
 // pass 1: per (item, channel): dz -> dn = dz * (scale + 1); writes dxhat = dn * gamma into `tmp`, the per-(b,c) sums
 // dscale = sum dz * nval, dshift = sum dz, and pgam[b][c] = sum dn * xhat, pbet[b][c] = sum dn
 __global__ __launch_bounds__(256) void gn_silu_backward1_kernel(const float* dy, const float* h, const float* gamma, const float* beta,
@@ -618,7 +657,7 @@ hipError_t launch_train_block_forward(const float* x, const float* w, const floa
   hipLaunchKernelGGL(ws_forward_kernel, dim3(Cout), dim3(256), 0, s, w, Cin * 3, k.wn, k.rstd_w);
   if (convmm_ok(L, L)) convmm_forward(x, k.wn, bias, B, Cin, Cout, L, L, 3, 1, 1, k.h, s);
   else hipLaunchKernelGGL(conv3_forward_kernel, dim3((L + 255) / 256, Cout, B), dim3(256), 0, s, x, k.wn, bias, Cin, Cout, L, k.h);
-  hipLaunchKernelGGL(gn_silu_forward_kernel, dim3(groups, B), dim3(1024), 0, s, k.h, gamma, beta, ss, Cout, L, groups, y, k.stats);
+  launch_gn_silu_forward(k.h, gamma, beta, ss, B, Cout, L, groups, y, k.stats, s);
   return hipGetLastError();
 }
 
