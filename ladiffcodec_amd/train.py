@@ -783,7 +783,9 @@ class DiffusionTrainer:
         return self.step(x_rep, cond, t, noise, monitor=monitor, wav=wav, latent_scale=latent_scale, update=update)
 
     def prefetch(self, wav):
-        """frozen encoders of a coming batch on the side stream / second engine (consumed by the step_from_wav call that gets the same tensor)"""
+        """frozen encoders of a coming batch on the side stream / second engine, consumed by the step_from_wav call that gets the SAME tensor
+        (matched by storage address and shape: the caller must not rewrite that buffer in place in between -- BatchWalker hands out a
+        fresh tensor per batch; a prefetched batch that is never stepped on is simply dropped by the next call)"""
         from . import lib as LL
         tt = self.torch
         dev = self.eng.device
