@@ -116,11 +116,15 @@ class Engine:
         return t
 
     def _enter(self):
-        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        cur = self.torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:      # (a caller already running on the engine's stream needs no hand-over:
+            self.stream.wait_stream(cur)                    # the training step makes ~1 600 calls, see DiffusionTrainer._on_engine_stream)
         return C.c_void_p(self.stream.cuda_stream)
 
     def _exit(self):
-        self.torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        cur = self.torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)
 
     def _empty(self, *shape, dtype=None):
         return self.torch.empty(*shape, device=self.device, dtype=dtype or self.torch.float32)

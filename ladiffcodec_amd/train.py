@@ -714,7 +714,29 @@ class DiffusionTrainer:
         """views of the flat gradient buffer, keyed like the state dict (valid after `step`)"""
         return self._views(self.flat_g)
 
+    def _on_engine_stream(self, fn):
+        """Run `fn` with the engine's stream as torch's current stream: every layer call then launches on the stream it is already on
+        (no event record / wait pair per call to hop streams: ~3 200 of them per step otherwise) and the ATen glue runs there too.  The
+        caller's stream waits for the result; returned tensors are marked as used on it."""
+        tt = self.torch
+        dev = self.eng.device
+        outer = tt.cuda.current_stream(dev)
+        es = self.eng.stream
+        if outer.cuda_stream == es.cuda_stream:
+            return fn()
+        es.wait_stream(outer)
+        with tt.cuda.stream(es):
+            out = fn()
+        outer.wait_stream(es)
+        for v in (out.values() if isinstance(out, dict) else (out,)):
+            if isinstance(v, tt.Tensor) and v.is_cuda:
+                v.record_stream(outer)
+        return out
+
     def step(self, x_start, cond, t, noise, monitor: bool = False, wav=None, latent_scale: float = 18.0, update: bool = True):
+        return self._on_engine_stream(lambda: self._step(x_start, cond, t, noise, monitor, wav, latent_scale, update))
+
+    def _step(self, x_start, cond, t, noise, monitor: bool = False, wav=None, latent_scale: float = 18.0, update: bool = True):
         """-> loss (float tensor [1]) of this step, evaluated before the update.  monitor=True returns what DiffAudioRep.forward
         reports besides (model.py:181-209): {'diff_loss', 'neg_loss', 'predicted_x_start', 'x_hat', 'x_t'} -- predicted_x_start
         from the step's own forward pass (the reference runs the UNet a second time under no_grad for the same numbers,
@@ -758,6 +780,10 @@ class DiffusionTrainer:
 
     def step_from_wav(self, wav, t=None, noise=None, latent_scale: float = 18.0, generator=None, monitor: bool = False, next_wav=None,
                       update: bool = True):
+        return self._on_engine_stream(lambda: self._step_from_wav(wav, t, noise, latent_scale, generator, monitor, next_wav, update))
+
+    def _step_from_wav(self, wav, t=None, noise=None, latent_scale: float = 18.0, generator=None, monitor: bool = False, next_wav=None,
+                       update: bool = True):
         """The step as srcs/train.py:110-160 + DiffAudioRep.forward (model.py:146-182) drive it from audio: cond =
         model_for_cond.get_cond(x); x_rep = encoder(x) (frozen) / 18 (--scaling_global); t ~ U{0..T-1}, noise ~ N(0, I)
         (ddpm_loss.py:443-449) unless given; then `step`.  The engine's inference kernels run the two frozen encoders."""
