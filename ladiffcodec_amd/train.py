@@ -745,6 +745,10 @@ class DiffusionTrainer:
         (model.eval() under torch.no_grad(), train.py:396-399): forward and losses only, no backward, no optimiser step."""
         from . import lib as LL, parallel
         eng = self.eng
+        # ONE upload of the timesteps (and of a host-drawn noise): a pageable host-to-device copy blocks the host until the stream has
+        # drained, and the three layers that take `t` would each do their own -- the last of them behind the whole forward pass
+        t = t.to(eng.device, self.torch.int64).contiguous()
+        noise = noise.to(eng.device, self.torch.float32).contiguous()
         if not update:
             x_t = q_sample(eng, x_start, t, noise)
             out = self.net.forward(x_t, t, cond)
@@ -798,8 +802,9 @@ class DiffusionTrainer:
             cond = self.eng.get_cond(wav)
             x_rep = self.eng.encode(LL.MODEL_MAIN, wav) / float(latent_scale)
         B = x_rep.shape[0]
-        if t is None:
-            t = tt.randint(0, self.num_timesteps, (B,), generator=generator)
+        if t is None:      # on the device like the reference (ddpm_loss.py:447) unless a (CPU) generator asks for a reproducible host draw
+            t = (tt.randint(0, self.num_timesteps, (B,), generator=generator) if generator is not None
+                 else tt.randint(0, self.num_timesteps, (B,), device=self.eng.device))
         if noise is None:      # on the device unless a (CPU) generator asks for a reproducible host draw
             noise = tt.randn(x_rep.shape, generator=generator) if generator is not None else tt.randn(x_rep.shape, device=self.eng.device)
         # enqueued BEFORE this step's ~1 600 launches: the host needs most of a step's GPU time to issue them, so anything queued
