@@ -153,12 +153,13 @@ def run(a, log=print) -> dict:
         walker = BatchWalker(ds, a.batch_size, device=dev, indices=indices)
         for wav in walker:
             rep = trainer.step_from_wav(wav, monitor=True, next_wav=walker.peek(), update=update)
-            for key in ("diff_loss", "neg_loss"):
-                tot[key] = tot.get(key, 0.0) + float(rep[key].reshape(-1)[0].cpu())
+            for key in ("diff_loss", "neg_loss"):                # summed on the device: a .cpu() per step would stall the host behind every step
+                v = rep[key].reshape(-1)[0].detach()
+                tot[key] = v.clone() if key not in tot else tot[key] + v
             n += 1
             if a.debug:
                 break                                          # train.py:170-171
-        out = {k: v / max(n, 1) for k, v in tot.items()}
+        out = {k: float(v.cpu()) / max(n, 1) for k, v in tot.items()}
         if world > 1:                                          # the reference never averaged over ranks (its DDP path was dead)
             vals = torch.tensor([out["diff_loss"], out["neg_loss"]], device=dev)
             torch.distributed.all_reduce(vals)
