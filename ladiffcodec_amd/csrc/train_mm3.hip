@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void mm3_pack_kernel(const float* w, int Cin, 
 template <int MODE, bool TAIL, bool VECB = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __restrict__ Asrc, const float* __restrict__ Bsrc, const float* __restrict__ bias,
                                                      float* __restrict__ out, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
-                                                     int nsplit, int MP, int RP) {
+                                                     int nsplit, int MP, int RP, int xmap) {
   __shared__ u32x4 lds[2][4][512];   // [stage][A hi, A lo, B hi, B lo][row * 4 + (slot ^ swizzle)]
   constexpr int NT = 64 * NW;          // threads
   constexpr int TMW = 8 / NW;          // 32-row blocks per wave (the wave tile is 32 TMW x 64)
@@ -112,11 +112,31 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __rest
   constexpr int PASSES = 16 / NW;      // MODE 2: row passes per chunk (8 NW rows each)
   constexpr int RPP = 8 * NW;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, i32 = lane & 31, g = lane >> 5;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-  const int z = MODE == 2 ? (int)blockIdx.z / nsplit : 0, part = MODE == 2 ? (int)blockIdx.z % nsplit : 0;
   const int M = MODE == 1 ? Cin : Cout;
   const int Lcol = MODE == 0 ? Lout : Lin;                       // MODE 0 / 1: positions per item along N
   const int N = MODE == 2 ? Cin : B * Lcol;
+  // Logical block coordinates.  1-D grids (gridDim.y == 1 with more than one row tile, set by the launchers) are XCD-aware: workgroup h
+  // runs on XCD h % 8 (observed dispatch rule, conv_fast.inc uses it too; used for speed only), and the eight L2s do not share.
+  //   MODE 0 / 1: XCD x takes a contiguous run of column tiles for ALL row tiles, columns fastest -- its activation columns are
+  //     fetched into ONE L2 and the weight tile of a row stays there across its columns;
+  //   MODE 2 (experiment only, slower): all tiles and taps of a part (= the same dy / x items) on one XCD, taps fastest.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int Mt = (M + 127) / 128, Nt = (N + 127) / 128;
+  if (gridDim.y == 1 && (Mt > 1 || MODE == 2) && xmap) {
+    const int hh = blockIdx.x, xcd = hh & 7, slot = hh >> 3;
+    if (MODE == 2) {
+      const int tpp = Nt * Mt * K, pg = slot / tpp, tl = slot - pg * tpp, prt = pg * 8 + xcd;
+      if (prt >= nsplit) return;
+      const int tap = tl % K, rest = tl / K;
+      bx = rest % Nt; by = rest / Nt; bz = tap * nsplit + prt;
+    } else {
+      const int W = (Nt + 7) / 8, mrow = slot / W, ncol = xcd * W + (slot - mrow * W);
+      if (ncol >= Nt) return;
+      bx = ncol; by = mrow;
+    }
+  }
+  const int m0 = by * 128, n0 = bx * 128;
+  const int z = MODE == 2 ? bz / nsplit : 0, part = MODE == 2 ? bz % nsplit : 0;
   const int red = MODE == 0 ? Cin : (MODE == 1 ? Cout : Lout);    // inner reduction extent
   const int Lsrc = MODE == 0 ? Lin : Lout;                        // MODE 0 / 1: row length of the gathered activation
   // reduction steps of this workgroup, flattened as (outer, chunk): MODE 2 takes the items of its part (grid z = tap * nsplit + part),
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __rest
   const int nchunk = (red + 31) / 32;
   const int outer_lo = MODE == 2 ? (int)((long long)B * part / nsplit) : 0;
   const int outer_hi = MODE == 2 ? (int)((long long)B * (part + 1) / nsplit) : K;
-  const int kpart = MODE == 2 ? 0 : (int)blockIdx.z;
+  const int kpart = MODE == 2 ? 0 : bz;
   const int it_all = (outer_hi - outer_lo) * nchunk;
   const int it_begin = MODE == 2 ? 0 : (int)((long long)it_all * kpart / nsplit);
   const int n_it = (MODE == 2 ? it_all : (int)((long long)it_all * (kpart + 1) / nsplit)) - it_begin;
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __rest
   float rs[PASSES];
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) rs[p] = 0.f;   // MODE 2, bias gradient: sums of this thread's dy values per row pass
-  const bool do_db = MODE == 2 && bias != nullptr && blockIdx.x == 0 && z == 0;
+  const bool do_db = MODE == 2 && bias != nullptr && bx == 0 && z == 0;
   auto store = [&](const Stage& r, int st) {
     if (MODE != 2) {
       const int sw = (r128 >> 2) & 3;
@@ -527,6 +547,11 @@ float* dw_workspace(size_t bytes, hipStream_t s) {
 }
 inline int up(int v, int q) { return (v + q - 1) / q * q; }
 // waves per workgroup of the GEMM kernels (LDC_MM3_NW = 4 | 8; see mm3_kernel)
+// XCD-aware 1-D grids (LDC_MM3_XCD=0 restores the 3-D ones)
+inline int mm3_xcd() {
+  static const int on = getenv("LDC_MM3_XCD") ? atoi(getenv("LDC_MM3_XCD")) : 1;
+  return on;
+}
 inline int mm3_nw() {
   static const int nw = getenv("LDC_MM3_NW") ? atoi(getenv("LDC_MM3_NW")) : 8;   // 8 measured 3 % faster per step (dW 10 %)
   return nw == 4 ? 4 : 8;
@@ -558,12 +583,14 @@ hipError_t launch_mm3_forward(const float* x, const float* w, const float* bias,
     target = dw_workspace((size_t)ks * n_out * sizeof(float), s);
     if (!target) return hipErrorOutOfMemory;
   }
-  const dim3 grid((unsigned)((N + 127) / 128), MP / 128, ks);
+  const int Ntl = (int)((N + 127) / 128), Mtl = MP / 128;
+  const int xm = mm3_xcd() && Mtl > 1;
+  const dim3 grid = xm ? dim3((unsigned)(8 * ((Ntl + 7) / 8) * Mtl), 1, ks) : dim3((unsigned)Ntl, Mtl, ks);
   if (Cin % 32 == 0) {
-    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<0, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
-    else hipLaunchKernelGGL((mm3_kernel<0, false, false, 4>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<0, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
+    else hipLaunchKernelGGL((mm3_kernel<0, false, false, 4>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
   } else
-    hipLaunchKernelGGL((mm3_kernel<0, true>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    hipLaunchKernelGGL((mm3_kernel<0, true>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
   if (ks > 1)
     hipLaunchKernelGGL(mm3_sum_parts_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 8192)), dim3(256), 0, s, (const float*)target, ks, n_out, y);
   return hipGetLastError();
@@ -583,12 +610,14 @@ hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Co
     target = dw_workspace((size_t)ks * n_out * sizeof(float), s);
     if (!target) return hipErrorOutOfMemory;
   }
-  const dim3 grid((unsigned)((N + 127) / 128), MP / 128, ks);
+  const int Ntl = (int)((N + 127) / 128), Mtl = MP / 128;
+  const int xm = mm3_xcd() && Mtl > 1;
+  const dim3 grid = xm ? dim3((unsigned)(8 * ((Ntl + 7) / 8) * Mtl), 1, ks) : dim3((unsigned)Ntl, Mtl, ks);
   if (Cout % 32 == 0) {
-    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<1, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
-    else hipLaunchKernelGGL((mm3_kernel<1, false, false, 4>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<1, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
+    else hipLaunchKernelGGL((mm3_kernel<1, false, false, 4>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
   } else
-    hipLaunchKernelGGL((mm3_kernel<1, true>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP);
+    hipLaunchKernelGGL((mm3_kernel<1, true>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
   if (ks > 1)
     hipLaunchKernelGGL(mm3_sum_parts_kernel, dim3((unsigned)std::min<size_t>((n_out + 255) / 256, 8192)), dim3(256), 0, s, (const float*)target, ks, n_out, dx);
   return hipGetLastError();
@@ -608,12 +637,16 @@ hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Co
     if (!target) return hipErrorOutOfMemory;
     if (db) db_target = target + n_dw;
   }
-  const dim3 grid((Cin + 127) / 128, (Cout + 127) / 128, K * nsplit);
+  // (measured: with every tile and tap of a part on one XCD the dW kernels are 1.6x SLOWER -- 3.22 vs 1.98 ms over the probe shapes --
+  // so dW keeps the 3-D grid; LDC_MM3_XCD=2 selects the mapping for experiments)
+  const int xm = mm3_xcd() == 2;
+  const int tpp = ((Cin + 127) / 128) * ((Cout + 127) / 128) * K;
+  const dim3 grid = xm ? dim3((unsigned)(8 * ((nsplit + 7) / 8) * tpp), 1, 1) : dim3((Cin + 127) / 128, (Cout + 127) / 128, K * nsplit);
   const bool vecb = S == 1 && Lin >= 4;
 #define LDC_MM3_DW(TAIL_, VECB_) \
   do { \
-    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 8>), grid, dim3(512), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0); \
-    else hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 4>), grid, dim3(256), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0); \
+    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 8>), grid, dim3(512), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0, xm); \
+    else hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 4>), grid, dim3(256), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0, xm); \
   } while (0)
   if (Lout % 4 == 0) { if (vecb) LDC_MM3_DW(false, true); else LDC_MM3_DW(false, false); }
   else { if (vecb) LDC_MM3_DW(true, true); else LDC_MM3_DW(true, false); }
