@@ -115,7 +115,8 @@ int ldc_destroy(ldc_ctx* ctx);
  * 1: never use the cooperative (co-resident workgroups) LSTM kernel, "side_streams" = 1: res_conv on a side stream (split 1
  * only), "fp8_act" (fp8 contexts, before ldc_finalize_weights), "train_fp32_mfma" = 1: the training GEMMs on the exact-fp32
  * MFMA (round-2 kernels) instead of the split-bf16 ones (three bf16 MFMAs per product, 2^-16-class: csrc/train_mm3.hip) -- this
- * one is process-wide.  Cached plans and graphs are dropped when a value changes. */
+ * one is process-wide, like "train_bf16" = 1: one bf16 MFMA per product in the training GEMMs (autocast-class numerics, opt-in).
+ * Cached plans and graphs are dropped when a value changes. */
 int ldc_set_option(ldc_ctx* ctx, const char* name, int value);
 
 /* Device-drawn noise (noise == NULL): Philox4x32-10 keyed by (noise_seed, call counter); every sampler call that

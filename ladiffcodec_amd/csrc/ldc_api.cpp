@@ -996,6 +996,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
   c->coop_launch = getenv("LDC_COOP_LAUNCH") ? 1 : 0;
   g_train_valu = getenv("LDC_TRAIN_VALU") ? 1 : 0;
+  if (getenv("LDC_TRAIN_BF16")) g_train_bf16 = 1;
   if (getenv("LDC_TRAIN_FP32_MFMA")) g_train_fp32_mfma = 1;   // (process-wide; ldc_set_option("train_fp32_mfma") changes it later)
   c->coop_resident[0] = lstm_coop_resident(256) ? 1 : 0;
   c->coop_resident[1] = lstm_coop_resident(512) ? 1 : 0;
@@ -1105,6 +1106,10 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     c->fp8_act = value ? 1 : 0;
     return LDC_OK;
   }
+  if (n == "train_bf16") {   // process-wide: plain bf16 products in the training GEMMs (opt-in; the default keeps fp32-class accuracy)
+    g_train_bf16 = value ? 1 : 0;
+    return LDC_OK;
+  }
   if (n == "train_fp32_mfma") {   // process-wide, like LDC_TRAIN_FP32_MFMA: training GEMMs on the exact-fp32 MFMA instead of split-bf16
     g_train_fp32_mfma = value ? 1 : 0;
     return LDC_OK;
@@ -1114,7 +1119,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fp8_act | train_fp32_mfma)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 extern "C" int ldc_reseed(ldc_ctx* c, uint64_t seed) {

@@ -245,6 +245,7 @@ hipError_t launch_train_convtr_forward(const float* x, const float* w, const flo
 hipError_t launch_train_convtr_backward(const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int r, float* dx,
                                         float* dw, float* db, hipStream_t s);
 hipError_t launch_train_maxscale(const float* x, const float* dy, int B, int64_t n_per_item, float* out, hipStream_t s);
+extern int g_train_bf16;        // LDC_TRAIN_BF16 / option train_bf16: the GEMM shapes with the hi terms only (plain bf16 products, fp32 accumulate)
 extern int g_train_fp32_mfma;   // LDC_TRAIN_FP32_MFMA: the round-2 exact-fp32 MFMA GEMMs (convmm_kernel) instead of the split-bf16 ones (train_mm3.hip)
 // split-bf16 (3 x bf16 MFMA, fp32-class accuracy) GEMM shapes of a Conv1d under training: train_mm3.hip
 hipError_t launch_mm3_forward(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void ws_backward_kernel(const float* dwn, cons
 // 64 x 64 output tile per workgroup (2 x 2 waves of 32 x 32), reduction in chunks of 16 through LDS (k-major, so the 32 lanes
 // of a fragment read consecutive words).  The VALU forms above stay as the reference (LDC_TRAIN_VALU=1) and for L < 16.
 // ---------------------------------------------------------------------------------------------
+int g_train_bf16 = 0;        // set by ldc_create from LDC_TRAIN_BF16 / ldc_set_option("train_bf16")
 int g_train_fp32_mfma = 0;   // set by ldc_create from LDC_TRAIN_FP32_MFMA
 int g_train_valu = 0;   // set by ldc_create from LDC_TRAIN_VALU (process-wide tuning aid, like g_conv_stamps)
 

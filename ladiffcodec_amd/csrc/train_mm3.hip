@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void mm3_pack_kernel(const float* w, int Cin, 
 // VECB (MODE 2): stride 1 -- x is read as one (unaligned) dwordx4 per pass from a start clamped into the row; the threads whose four
 // positions straddle the padding (first / last of a row) get them shifted, which store() undoes for exactly those lanes
 // NW: waves per workgroup (4: 2 x 2 waves of 64 x 64; 8: 4 x 2 waves of 32 x 64 -- half the registers per wave, four waves per SIMD)
-template <int MODE, bool TAIL, bool VECB = false, int NW = 4>
+// ONE: plain bf16 training GEMMs (hi terms only: one MFMA per product, two LDS planes; 2^-9-class products, the numerics of a bf16
+// autocast run -- opt-in, LDC_TRAIN_BF16=1 / option train_bf16, not what the parity tests pin)
+template <int MODE, bool TAIL, bool VECB = false, int NW = 4, bool ONE = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __restrict__ Asrc, const float* __restrict__ Bsrc, const float* __restrict__ bias,
                                                      float* __restrict__ out, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P,
                                                      int nsplit, int MP, int RP, int xmap) {
@@ -229,8 +231,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __rest
   auto fetch = [&](Stage& r) {
     const int k0 = f_chunk * 32;
     if (MODE != 2) {
-      r.a0 = pA[0]; r.a1 = pA[1];
-      if (KPT == 16) { r.a2 = pA[2]; r.a3 = pA[3]; }
+      r.a0 = pA[0];
+      if (!ONE) r.a1 = pA[1];
+      if (KPT == 16) { r.a2 = pA[2]; if (!ONE) r.a3 = pA[3]; }
       pA += 8;
       // straight-line on purpose: with a branch in here the compiler's s_waitcnt bookkeeping falls back to "everything older", which
       // drains the set that was loaded one iteration ago together with the one just issued
@@ -284,10 +287,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __rest
       const int sw = (r128 >> 2) & 3;
       constexpr int NOCT = KPT / 8;                       // octets (16-byte LDS slots) per thread: 2 or 1
       lds[st][0][r128 * 4 + ((NOCT * h) ^ sw)] = r.a0;
-      lds[st][1][r128 * 4 + ((NOCT * h) ^ sw)] = r.a1;
+      if (!ONE) lds[st][1][r128 * 4 + ((NOCT * h) ^ sw)] = r.a1;
       if (NOCT == 2) {
         lds[st][0][r128 * 4 + ((2 * h + 1) ^ sw)] = r.a2;
-        lds[st][1][r128 * 4 + ((2 * h + 1) ^ sw)] = r.a3;
+        if (!ONE) lds[st][1][r128 * 4 + ((2 * h + 1) ^ sw)] = r.a3;
       }
       u32x4 hi, lo;
       float b[KPT];
@@ -295,11 +298,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __rest
       for (int j = 0; j < KPT; ++j) b[j] = (r.ok && (!TAIL || j < r.nv)) ? r.b[j] : 0.f;
       split8(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], hi, lo);
       lds[st][2][r128 * 4 + ((NOCT * h) ^ sw)] = hi;
-      lds[st][3][r128 * 4 + ((NOCT * h) ^ sw)] = lo;
+      if (!ONE) lds[st][3][r128 * 4 + ((NOCT * h) ^ sw)] = lo;
       if (NOCT == 2) {
         split8(b[KPT - 8], b[KPT - 7], b[KPT - 6], b[KPT - 5], b[KPT - 4], b[KPT - 3], b[KPT - 2], b[KPT - 1], hi, lo);
         lds[st][2][r128 * 4 + ((2 * h + 1) ^ sw)] = hi;
-        lds[st][3][r128 * 4 + ((2 * h + 1) ^ sw)] = lo;
+        if (!ONE) lds[st][3][r128 * 4 + ((2 * h + 1) ^ sw)] = lo;
       }
     } else {
       const int slot = (tid & 7) >> 1, half = tid & 1;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __rest
           split4(r.a[4 * p], r.a[4 * p + 1], r.a[4 * p + 2], r.a[4 * p + 3], hi, lo);
         }
         ((u32x2*)lds[st][0])[at] = hi;
-        ((u32x2*)lds[st][1])[at] = lo;
+        if (!ONE) ((u32x2*)lds[st][1])[at] = lo;
         if (edge) {
           float b0 = r.b[4 * p], b1 = r.b[4 * p + 1], b2 = r.b[4 * p + 2], b3 = r.b[4 * p + 3];
           if (VECB) {   // loaded from pos0 + d (d = clamp shift): element e is loaded[e - d]
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __rest
           split4(r.b[4 * p], r.b[4 * p + 1], r.b[4 * p + 2], r.b[4 * p + 3], hi, lo);
         }
         ((u32x2*)lds[st][2])[at] = hi;
-        ((u32x2*)lds[st][3])[at] = lo;
+        if (!ONE) ((u32x2*)lds[st][3])[at] = lo;
       }
     }
   };
@@ -357,23 +360,23 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void mm3_kernel(const void* __rest
       for (int a = 0; a < TMW; ++a) {
         const int row = 32 * TMW * wm + 32 * a + i32;
         ah[a].u = lds[st][0][row * 4 + slot];
-        al[a].u = lds[st][1][row * 4 + slot];
+        if (!ONE) al[a].u = lds[st][1][row * 4 + slot];
       }
 #pragma unroll
       for (int b2 = 0; b2 < 2; ++b2) {
         const int row = 64 * wn + 32 * b2 + i32;
         bh[b2].u = lds[st][2][row * 4 + slot];
-        bl[b2].u = lds[st][3][row * 4 + slot];
+        if (!ONE) bl[b2].u = lds[st][3][row * 4 + slot];
       }
       // term-major: independent accumulators between two MFMAs into the same one
 #pragma unroll
       for (int a = 0; a < TMW; ++a)
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a].v, bh[b2].v, acc[a][b2], 0, 0, 0);
+        for (int b2 = 0; b2 < 2; ++b2) if (!ONE) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a].v, bh[b2].v, acc[a][b2], 0, 0, 0);
 #pragma unroll
       for (int a = 0; a < TMW; ++a)
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bl[b2].v, acc[a][b2], 0, 0, 0);
+        for (int b2 = 0; b2 < 2; ++b2) if (!ONE) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a].v, bl[b2].v, acc[a][b2], 0, 0, 0);
 #pragma unroll
       for (int a = 0; a < TMW; ++a)
 #pragma unroll
@@ -587,7 +590,8 @@ hipError_t launch_mm3_forward(const float* x, const float* w, const float* bias,
   const int xm = mm3_xcd() && Mtl > 1;
   const dim3 grid = xm ? dim3((unsigned)(8 * ((Ntl + 7) / 8) * Mtl), 1, ks) : dim3((unsigned)Ntl, Mtl, ks);
   if (Cin % 32 == 0) {
-    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<0, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
+    if (g_train_bf16) hipLaunchKernelGGL((mm3_kernel<0, false, false, 8, true>), grid, dim3(512), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
+    else if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<0, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
     else hipLaunchKernelGGL((mm3_kernel<0, false, false, 4>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
   } else
     hipLaunchKernelGGL((mm3_kernel<0, true>), grid, dim3(256), 0, s, (const void*)pw, x, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
@@ -614,7 +618,8 @@ hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Co
   const int xm = mm3_xcd() && Mtl > 1;
   const dim3 grid = xm ? dim3((unsigned)(8 * ((Ntl + 7) / 8) * Mtl), 1, ks) : dim3((unsigned)Ntl, Mtl, ks);
   if (Cout % 32 == 0) {
-    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<1, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
+    if (g_train_bf16) hipLaunchKernelGGL((mm3_kernel<1, false, false, 8, true>), grid, dim3(512), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
+    else if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<1, false, false, 8>), grid, dim3(512), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
     else hipLaunchKernelGGL((mm3_kernel<1, false, false, 4>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
   } else
     hipLaunchKernelGGL((mm3_kernel<1, true>), grid, dim3(256), 0, s, (const void*)pw, dy, bias, target, B, Cin, Cout, Lin, Lout, K, S, P, ks, MP, RP, xm);
@@ -645,7 +650,8 @@ hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Co
   const bool vecb = S == 1 && Lin >= 4;
 #define LDC_MM3_DW(TAIL_, VECB_) \
   do { \
-    if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 8>), grid, dim3(512), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0, xm); \
+    if (g_train_bf16) hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 8, true>), grid, dim3(512), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0, xm); \
+    else if (mm3_nw() == 8) hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 8>), grid, dim3(512), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0, xm); \
     else hipLaunchKernelGGL((mm3_kernel<2, TAIL_, VECB_, 4>), grid, dim3(256), 0, s, (const void*)dy, x, db_target, target, B, Cin, Cout, Lin, Lout, K, S, P, nsplit, 0, 0, xm); \
   } while (0)
   if (Lout % 4 == 0) { if (vecb) LDC_MM3_DW(false, true); else LDC_MM3_DW(false, false); }

@@ -72,7 +72,8 @@ class Engine:
 
     def set_option(self, name: str, value: int) -> None:
         """ldc_set_option: 'split' (chains per batch), 'lstm_stream' (no cooperative LSTM), 'side_streams', 'fp8_act',
-        'train_fp32_mfma' (training GEMMs on the exact-fp32 MFMA instead of the split-bf16 path; process-wide)."""
+        'train_fp32_mfma' (training GEMMs on the exact-fp32 MFMA instead of the split-bf16 path; process-wide), 'train_bf16' (plain bf16
+        products in the training GEMMs, opt-in; process-wide)."""
         L.check(self.lib.ldc_set_option(self._ctx, name.encode(), int(value)))
 
     def host_stats(self, reset: bool = True):

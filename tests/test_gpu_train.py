@@ -328,6 +328,33 @@ def test_split_bf16_step_is_bit_reproducible(gemm):
     assert rel(outs[0][0].cpu().numpy(), want.numpy()) < 2e-5
 
 
+def test_plain_bf16_option_is_bf16_class_and_off_by_default(gemm):
+    """option train_bf16 (LDC_TRAIN_BF16): the GEMM shapes with one bf16 MFMA per product (no lo terms) -- an opt-in for runs that accept
+    autocast-class numerics; errors must be bf16-class (2^-9 products: 1e-4 .. 2e-2 of the maximum), and fp32-class again once it is off."""
+    if gemm != "split_bf16":
+        pytest.skip("an option of the split-bf16 kernels")
+    import torch.nn.functional as F
+    e = engine("r84", "f32")
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 256, 300, generator=gen, requires_grad=True)
+    w = (torch.randn(128, 256, 3, generator=gen) * 0.05).requires_grad_()
+    y = F.conv1d(x.double(), w.double(), None, padding=1)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy.double())
+    errs = {}
+    for on in (1, 0):
+        e.set_option("train_bf16", on)
+        try:
+            cv = TR.Conv1d(e, w.detach(), None, 1, 1)
+            got = cv.forward(x.detach())
+            g = cv.backward(dy)
+            errs[on] = (rel(got.cpu().numpy(), y.detach().numpy()), rel(g["dx"].cpu().numpy(), x.grad.numpy()), rel(g["dw"].cpu().numpy(), w.grad.numpy()))
+        finally:
+            e.set_option("train_bf16", 0)
+    assert all(1e-4 < v < 2e-2 for v in errs[1]), errs
+    assert all(v < 2e-5 for v in errs[0]), errs
+
+
 def test_frozen_encoders_prefetched_on_a_second_engine_give_the_same_steps():
     """DiffusionTrainer(frontend=...): the encoders of the next batch run on a side stream / second engine under the current step; three
     steps over two alternating batches must give the encodings (bitwise) and the losses of the in-line trainer."""
