@@ -3,6 +3,7 @@
 #pragma once
 #include "ldc_kernels.h"
 #include "ldc_math.h"
+#include <type_traits>
 
 namespace ldc {
 
@@ -58,8 +59,22 @@ struct ConvKArgs {
   int sk_count_cap;        // tiles
   int w8;                  // weights are fp8 (generic kernel expands them while staging)
   const float* wscale;     // fp8 weights: per-output-channel scale applied to the accumulator before the bias (else null)
+  // Fused GroupNorm APPLY (fast kernel; ResnetBlock "Block", unet.py:137-153): every wave of a finished tile publishes its partial
+  // statistics, waits until every tile of the items it touches has published, and then normalises its own accumulators in
+  // registers -- GN affine, timestep scale / shift, SiLU (+ residual) (+ tanh) -- before the one store (epilogue_gn_fused).
+  // The conv output never goes to HBM un-normalised and the gn_apply launch (one read + one write of the tensor) disappears.
+  char* gn_part;           // [B][gn_mslots][WM][n / 32] x 16-byte granule pairs (zeroed by the step's first kernel) or null: not fused
+  int gn_mslots;           // M-tile slots per item in gn_part (>= the M tiles one item can touch)
+  const float* gn_gamma;   // [n]
+  const float* gn_beta;    // [n]
+  const float* gn_ss;      // [2 n]: (scale | shift) of the current timestep, or null
+  int gn_out;              // bit 2: tanh after the residual add (the final ResnetBlock feeds torch.tanh alone, unet.py:467)
+  int io_sc1;              // bit 0: the output is read inside this launch (write-through stores); bit 1: the residual was
+                           // produced inside this launch (agent-scope loads); bit 2: so was the input window (x1)
+  unsigned* fail_flag;     // host-mapped word raised when a bounded spin gives up (the output is then wrong, never a hang)
   const ConvTune* tune;    // host-only (never read on the device)
   long long* sk_need;      // host-only: dry run
+  int* bm_out;             // host-only: dry run -- rows per tile the fast kernel would use (0: generic kernel); bm_out[1] = wave rows WM
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -345,10 +360,254 @@ __device__ __forceinline__ void epilogue_rows(const ConvKArgs& a, f32x16 (&acc)[
   }
 }
 
+// 16-byte global accesses that other workgroups of the SAME launch may rely on (the eight XCD L2s are not coherent and a
+// CU's L1 is never refreshed by another CU's stores): write-through (sc1) stores, L1-bypassing (sc1) loads.  Inline asm: the
+// compiler neither counts nor waits for them -- the caller drains with wait_vm0().
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(char* p, const uint4& v) {
+  const u32x4_t x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void load16_sc1_issue(u32x4_t& dst, const char* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Fused GroupNorm apply of a wave's TM x TN accumulators (ConvKArgs::gn_part != null).
+//
+// Statistics exchange WITHOUT atomics, counters or barriers: every wave publishes the (sum, sum of squares) of its rows x 32
+// columns per item as ONE 16-byte write-through store holding two data-tagged granules {1, sum}{1, sumsq} into its own slot
+//   gn_part[item][M-tile slot of the item][wave row wm][32-column block]          (zeroed by the step's first kernel),
+// then reads back every slot of its (item, group) -- lanes in parallel, L1-bypassing loads -- until all tags are set, and sums
+// them with a fixed shuffle tree: the statistics are bit-reproducible from run to run (the atomics were not), and the chain
+// a tile waits on is one store latency + one load round trip after the item's last tile has finished its K loop (the
+// atomic form -- drain the statistics atomics, arrive at a counter, poll it, load the sums -- measured +5.4 us per launch).
+// Then: per-column affine (same arithmetic as gn_apply_cols_kernel: a1 = rstd * gamma, b1 = beta - mean * a1, the timestep
+// (scale + 1) and shift folded in) -> SiLU -> LDS transpose -> whole-row stores.  RES: the rows are staged in fp32 and the
+// residual is added to the un-rounded value as 16-byte pieces in the row phase (one rounding, like gn_apply), then the
+// optional tanh.  A tile may straddle two items (flat M tiling); the launcher guarantees L_rows >= BM, i.e. at most two.
+// The spin is bounded by the 100 MHz wall clock: tiles that are not all resident in time raise the host-mapped flag, never a hang.
+template <typename T, int TM, int TN, bool RES>
+__device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
+                                                  int col_wave0, int M, int m0, int BM, int WM, int wm) {
+  const int lane = threadIdx.x & 63;
+  const int b_first = (int)fdiv((unsigned)m0, a.lrows_div);
+  const int b_last = (int)fdiv((unsigned)(min(m0 + BM, M) - 1), a.lrows_div);
+  const int m_split = (b_first + 1) * a.L_rows;   // rows >= m_split belong to b_last
+  const int cpg = a.gn_cpg;                       // a multiple of 32: a 32-column block lies inside one group
+  const int sub_n = cpg >> 5;                     // 32-column blocks per group (a power of two)
+  const int nc32 = a.n >> 5;
+  const int mt = m0 / BM;
+  float bv[TN], wsc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col_wave0 + j * 32 + (lane & 31);
+    bv[j] = (a.bias && col < a.n) ? a.bias[col] : 0.0f;
+    wsc[j] = (a.wscale && col < a.n) ? a.wscale[col] : 1.0f;
+  }
+  // 1. publish this wave's partial statistics
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int c32 = (col_wave0 + j * 32) >> 5;
+    for (int bb = b_first; bb <= b_last; ++bb) {
+      const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
+      float s = 0.f, ss = 0.f;
+      if (b_first == b_last && m0 + BM <= M) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = fmaf(acc[i][j][r], wsc[j], bv[j]);
+            s += v;
+            ss = fmaf(v, v, ss);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m_wave0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= lo && m < hi) {
+              const float v = fmaf(acc[i][j][r], wsc[j], bv[j]);
+              s += v;
+              ss = fmaf(v, v, ss);
+            }
+          }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        ss += __shfl_xor(ss, o);
+      }
+      if (lane == 0 && c32 < nc32) {
+        const int mslot = mt - lo / BM;
+        char* dst = a.gn_part + ((((size_t)bb * a.gn_mslots + mslot) * WM + wm) * nc32 + c32) * 16;
+        store16_wt(dst, make_uint4(1u, __float_as_uint(s), 1u, __float_as_uint(ss)));
+      }
+    }
+  }
+  // 2. gather the statistics of this wave's (item, group) pairs and build the per-column affine
+  const float inv_n = 1.0f / ((float)a.L_rows * (float)cpg);
+  float ca[2][TN], cb[2][TN];
+  const unsigned long long t0 = wall_clock64();
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col_wave0 + j * 32 + (lane & 31);
+    const bool col_ok = col < a.n;
+    const int cc = col_ok ? col : 0;
+    const int g = (col_wave0 + j * 32 < a.n ? col_wave0 + j * 32 : 0) / cpg;   // wave-uniform
+    const float gam = a.gn_gamma[cc], bet = a.gn_beta[cc];
+    const float sc = a.gn_ss ? a.gn_ss[cc] + 1.0f : 1.0f, sh = a.gn_ss ? a.gn_ss[a.n + cc] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q == 1 && b_last == b_first) {
+        ca[1][j] = ca[0][j];
+        cb[1][j] = cb[0][j];
+        continue;
+      }
+      const int bb = q ? b_last : b_first;
+      const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
+      const int per_mt = WM * sub_n;
+      const int total = ((hi - 1) / BM - lo / BM + 1) * per_mt;   // granule pairs of (item bb, group g)
+      const char* base = a.gn_part + (size_t)bb * a.gn_mslots * WM * nc32 * 16 + (size_t)g * sub_n * 16;
+      float s = 0.f, ss = 0.f;
+      for (int l0 = 0; l0 < total; l0 += 64) {
+        const int l = l0 + lane;
+        const bool mine = l < total;
+        const int ms_wm = mine ? l / sub_n : 0, sub = mine ? l - ms_wm * sub_n : 0;   // (mslot * WM + wm'), block inside the group
+        const char* src = base + ((size_t)ms_wm * nc32 + sub) * 16;
+        u32x4_t v;
+        for (;;) {
+          load16_sc1_issue(v, src);
+          wait_vm0();
+          if (__all(!mine || (v[0] == 1u && v[2] == 1u))) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 > 50000000ull) {   // 0.5 s
+            if (lane == 0 && a.fail_flag) __hip_atomic_store(a.fail_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
+        }
+        if (mine) {
+          s += __uint_as_float(v[1]);
+          ss += __uint_as_float(v[3]);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        ss += __shfl_xor(ss, o);
+      }
+      const float mean = s * inv_n;
+      const float var = fmaxf(ss * inv_n - mean * mean, 0.0f);
+      const float rstd = rsqrtf(var + 1e-5f);
+      float a1 = rstd * gam;
+      float b1 = bet - mean * a1;
+      if (a.gn_ss) {
+        a1 *= sc;
+        b1 = b1 * sc + sh;
+      }
+      ca[q][j] = a1;
+      cb[q][j] = b1;
+    }
+  }
+  typedef typename std::conditional<RES, float, T>::type TS;   // staging element
+  constexpr int RBS = TN * 32 * (int)sizeof(TS);    // staged bytes per tile row
+  constexpr int PITCH = RBS + 16;
+  constexpr int EPL = 16 / (int)sizeof(T);          // output elements per lane in the row phase (16 bytes)
+  constexpr int LPR = TN * 32 / EPL;                // lanes per row
+  constexpr int RPS = 64 / LPR;                     // rows per sweep
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const bool second = m_wave0 + row >= m_split;
+        const float v = fmaf(acc[i][j][r], wsc[j], bv[j]);
+        const float o = fast_silu(fmaf(v, second ? ca[1][j] : ca[0][j], second ? cb[1][j] : cb[0][j]));
+        store_out<TS>(wave_lds, (size_t)(row * PITCH) / sizeof(TS) + j * 32 + (lane & 31), o);
+      }
+  // same wave wrote and reads: LDS executes a wave's operations in order
+  const int rsub = lane / LPR, chunk = lane % LPR;
+  const int col = col_wave0 + chunk * EPL;
+  const bool wt = (a.io_sc1 & 1) != 0;
+  if (!RES) {
+#pragma unroll
+    for (int sw = 0; sw < TM * 32 / RPS; ++sw) {
+      const int row = sw * RPS + rsub;
+      const int m = m_wave0 + row;
+      const uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * PITCH + chunk * 16);
+      if (m < M && col < a.n) {
+        char* dst = a.y + ((size_t)m * a.y_ld + col) * sizeof(T);
+        if (wt) store16_wt(dst, v);
+        else *reinterpret_cast<uint4*>(dst) = v;
+      }
+    }
+  } else {
+    constexpr int NSW = TM * 32 / RPS;
+    u32x4_t rres[NSW];
+    const bool res_sc1 = (a.io_sc1 & 2) != 0;
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw) {
+      const int m = m_wave0 + sw * RPS + rsub;
+      const bool ok = m < M && col < a.n;
+      const char* src = a.residual + ((size_t)(ok ? m : 0) * a.n + (ok ? col : 0)) * sizeof(T);
+      if (res_sc1) load16_sc1_issue(rres[sw], src);
+      else { const uint4 t = *reinterpret_cast<const uint4*>(src); rres[sw] = u32x4_t{t.x, t.y, t.z, t.w}; }
+    }
+    if (res_sc1) wait_vm0();
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw) {
+      const int row = sw * RPS + rsub;
+      const int m = m_wave0 + row;
+      float f[EPL], rr[EPL];
+      const float* sp = reinterpret_cast<const float*>(wave_lds + row * PITCH + chunk * EPL * 4);
+#pragma unroll
+      for (int e = 0; e < EPL; e += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(sp + e);
+        f[e] = t.x; f[e + 1] = t.y; f[e + 2] = t.z; f[e + 3] = t.w;
+      }
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) rr[e] = __uint_as_float(rres[sw][e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; e += 2) {
+          rr[e] = __uint_as_float(rres[sw][e >> 1] << 16);
+          rr[e + 1] = __uint_as_float(rres[sw][e >> 1] & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        f[e] += rr[e];
+        if (a.gn_out & 4) f[e] = fast_tanh(f[e]);
+      }
+      uint4 v;
+      if constexpr (sizeof(T) == 4) {
+        v = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+      } else {
+        v = make_uint4(hw_bf16x2(f[0], f[1]), hw_bf16x2(f[2], f[3]), hw_bf16x2(f[4], f[5]), hw_bf16x2(f[6], f[7]));
+      }
+      if (m < M && col < a.n) {
+        char* dst = a.y + ((size_t)m * a.y_ld + col) * sizeof(T);
+        if (wt) store16_wt(dst, v);
+        else *reinterpret_cast<uint4*>(dst) = v;
+      }
+    }
+  }
+  if (wt) wait_vm0();   // write-through stores have reached memory before anything signals them
+}
+
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void epilogue_rows_dispatch(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
-                                                       int col_wave0, int M, int m0, int BM) {
+                                                       int col_wave0, int M, int m0, int BM, int WM = 1, int wm = 0) {
   const int lane = threadIdx.x & 63;
+  if (a.gn_part) {   // fused GroupNorm apply (uniform over the launch)
+    if (a.residual) epilogue_gn_fused<T, TM, TN, true>(a, acc, wave_lds, m_wave0, col_wave0, M, m0, BM, WM, wm);
+    else epilogue_gn_fused<T, TM, TN, false>(a, acc, wave_lds, m_wave0, col_wave0, M, m0, BM, WM, wm);
+    return;
+  }
   if (a.gn_sum) epilogue_gn_stats<TM, TN>(a, acc, m_wave0 + 4 * (lane >> 5), col_wave0 + (lane & 31), m0, BM, M);
   if (a.colmax) epilogue_colmax<T, TM, TN>(a, acc, m_wave0 + 4 * (lane >> 5), col_wave0 + (lane & 31), m0, BM, M);
   if (a.residual) {

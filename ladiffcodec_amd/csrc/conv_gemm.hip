@@ -397,7 +397,10 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   a.colmax = c.colmax; a.colmax_lo = c.colmax_lo; a.colmax_hi = c.colmax_hi; a.colmax_stride = c.colmax_stride;
   if (ly.tr_stride) a.colmax = nullptr;
   a.ksplit = 1; a.sk_part = c.sk_part; a.sk_count = c.sk_count; a.sk_part_cap = c.sk_part_cap; a.sk_count_cap = c.sk_count_cap;
-  a.tune = c.tune; a.sk_need = c.sk_need;
+  a.tune = c.tune; a.sk_need = c.sk_need; a.bm_out = c.bm_out;
+  if (c.bm_out) { c.bm_out[0] = 0; c.bm_out[1] = 0; }
+  a.gn_part = (char*)c.gn_part; a.gn_mslots = c.gn_mslots; a.gn_gamma = c.gn_gamma; a.gn_beta = c.gn_beta; a.gn_ss = c.gn_ss; a.gn_out = c.gn_out; a.io_sc1 = c.io_sc1;
+  a.fail_flag = c.fail_flag;
   a.wscale = (ly.w8 || ly.dt == DT_FP8) ? ly.wscale : nullptr; a.w8 = ly.w8;
   if (c.sk_need) *c.sk_need = 0;
   if (c.gn_sum && c.gn_groups > 0 && !ly.tr_stride) {
@@ -406,6 +409,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     if (ly.n % c.gn_groups || !pow2) return hipErrorInvalidValue;   // the planner only asks for supported widths
     a.gn_sum = c.gn_sum; a.gn_groups = c.gn_groups; a.gn_cpg = cpg;
   }
+  if (c.gn_part && c.gn_groups > 0) { a.gn_groups = c.gn_groups; a.gn_cpg = ly.n / c.gn_groups; }   // fused apply: no gn_sum
   const int BM = 128;
   const int M = c.B * c.L_rows;
   if (M <= 0) return hipSuccess;
@@ -432,6 +436,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     if (e != hipSuccess || launched) return e;
   }
   if (c.sk_need) return hipSuccess;   // dry run: the generic kernel never splits K
+  if (c.gn_part) return hipErrorInvalidValue;   // the fused GroupNorm apply exists only on the pipelined kernel (the planner checks bm_out)
   if (ly.dt == DT_FP8) return hipErrorInvalidValue;   // fp8 inputs exist only on the pipelined kernel (the planner checks eligibility)
   a.win_rows = std::min(span, c.B * c.L_in) + 1;
   int bn = ly.bn;

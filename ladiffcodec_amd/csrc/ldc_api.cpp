@@ -179,6 +179,8 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
   uint64_t last_use = 0;        // LRU tick (ldc_ctx::use_tick)
   long long sk_floats = 0;      // split-K workspace this plan's convs need (sized by a dry run of the launchers)
   long long sk_need_max = 0;
+  size_t part_bytes = 0;        // granule regions of the fused GroupNorm applies (sized by the same dry run)
+  size_t part_need = 0;
   void* arena_base = nullptr;
   size_t arena_bytes = 0;
   void* zero_ptr = nullptr;     // the step's accumulators (GroupNorm sums, split-K counters, k-max keys, scale_x maxima): cleared by
@@ -274,6 +276,7 @@ struct ldc_ctx {
   unsigned long long flow_n = 0;
   int flow_depth = 8;           // LDC_FLOW_DEPTH (0 = unbounded look-ahead)
   int fuse_gn_stats = 1;
+  int fuse_gn_epi = 1;          // GroupNorm APPLY in the producing conv's epilogue behind an in-launch per-item wait (LDC_NO_GN_EPI / option "fuse_gn_epi")
   // knobs read from the environment once, at ldc_create (per context, not process-global)
   ConvTune tune;
   int lstm_stream_only = 0;     // LDC_LSTM_STREAM: never use the cooperative LSTM
@@ -979,6 +982,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->split_batch = getenv("LDC_NO_SPLIT") ? 1 : std::max(1, std::min(kMaxParts, env_int("LDC_SPLIT", 2)));
   c->side_streams = (getenv("LDC_SIDE") && c->split_batch == 1) ? 1 : 0;
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
+  c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
   c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
   c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
   c->fuse_attn_tail = getenv("LDC_NO_TAIL_FUSE") ? 0 : 1;
@@ -1114,12 +1118,16 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     g_train_fp32_mfma = value ? 1 : 0;
     return LDC_OK;
   }
+  if (n == "fuse_gn_epi") {   // GroupNorm apply in the conv epilogue (in-launch per-item wait) on / off: plans are rebuilt
+    if ((value ? 1 : 0) != c->fuse_gn_epi) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fuse_gn_epi = value ? 1 : 0; }
+    return LDC_OK;
+  }
   if (n == "side_streams") {
     if (value && c->split_batch != 1) return fail(LDC_E_INVALID, "side streams need a single chain (split 1)");
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 extern "C" int ldc_reseed(ldc_ctx* c, uint64_t seed) {
@@ -1515,6 +1523,8 @@ struct PlanBuilder {
   size_t es;   // element size of the UNet dtype
   float* stats_pool = nullptr;   // [n_gn][B][groups][2]
   int stats_used = 0;
+  char* part_pool = nullptr;     // granule regions of the fused GroupNorm applies (inside the region the step's first kernel clears)
+  size_t part_used = 0, part_cap = 0;
   float* linattn_ws = nullptr;
   int linattn_used = 0;
   float* sk_part = nullptr;        // split-K workspace shared by the plan's convs (they run one after another)
@@ -1549,11 +1559,46 @@ struct PlanBuilder {
     pl->flops += flops;
   }
   std::string info;   // description of the next op added
+  // fused GroupNorm apply of a conv (see ConvCall::gn_cnt)
+  struct GnEpi {
+    void* part = nullptr;          // granule region of this conv
+    int mslots = 0;
+    const float* gamma = nullptr; const float* beta = nullptr; const float* ss = nullptr;
+    int out = 0;
+  };
+  // rows per tile the pipelined kernel would use for this conv (0: generic kernel) -- the fused apply needs L_out >= that
+  // (out[0] = rows per tile, out[1] = wave rows)
+  void conv_bm(const ConvLayer& ly, int L_in, int L_out, bool with_stats, int* out) {
+    ConvCall d;
+    d.B = B; d.L_in = L_in; d.L_rows = L_out; d.y_ld = ly.n; d.tune = &c->tune;
+    d.sk_part = sk_part; d.sk_count = sk_count; d.sk_part_cap = sk_part_cap; d.sk_count_cap = sk_count_cap;
+    if (with_stats) { d.gn_sum = stats_pool; d.gn_groups = c->unet.groups; }
+    long long need = 0;
+    out[0] = out[1] = 0;
+    d.sk_need = &need; d.bm_out = out;
+    (void)launch_conv(ly, d, nullptr);
+  }
+  // a granule region for a fused conv with tile height bm and wm wave rows; null when the pool is exhausted (first planning pass: sizes only)
+  bool take_part(GnEpi* ge, int L, int bm, int wm, int n) {
+    ge->mslots = (L + bm - 1) / bm + 1;
+    const size_t bytes = (size_t)B * ge->mslots * wm * (n / 32) * 16;
+    pl->part_need += bytes;
+    if (!part_pool || part_used + bytes > part_cap) return false;
+    ge->part = part_pool + part_used;
+    part_used += bytes;
+    return true;
+  }
   void conv(const ConvLayer& ly, const void* x1, const void* x2, void* y, const void* residual, int L_in, int L_out,
-            float* gn_sum = nullptr, unsigned* colmax = nullptr, int cm_lo = 0, int cm_hi = 0, int cm_stride = 0) {
+            float* gn_sum = nullptr, unsigned* colmax = nullptr, int cm_lo = 0, int cm_hi = 0, int cm_stride = 0,
+            const GnEpi* ge = nullptr) {
     ConvCall cc;
     cc.B = B; cc.L_in = L_in; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.residual = residual; cc.y_ld = ly.n;
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
+    if (ge && ge->part) {
+      cc.gn_groups = c->unet.groups;
+      cc.gn_part = ge->part; cc.gn_mslots = ge->mslots; cc.gn_gamma = ge->gamma; cc.gn_beta = ge->beta; cc.gn_ss = ge->ss; cc.gn_out = ge->out;
+      cc.fail_flag = c->dev_flag_dev;
+    }
     cc.colmax = colmax; cc.colmax_lo = cm_lo; cc.colmax_hi = cm_hi; cc.colmax_stride = cm_stride;
     cc.sk_part = sk_part; cc.sk_count = sk_count; cc.sk_part_cap = sk_part_cap; cc.sk_count_cap = sk_count_cap;
     cc.tune = &c->tune;
@@ -1568,10 +1613,10 @@ struct PlanBuilder {
     {
       char buf[96];
       snprintf(buf, sizeof(buf), "k%d_s%d_u%d_c%d+%d->%d_L%d%s%s", ly.taps, ly.stride, ly.ups, ly.cin1, ly.cin2, ly.n, L_out,
-               gn_sum ? "_gn" : "", colmax ? "_kmax" : "");
+               (ge && ge->part) ? (residual ? "_gnapply+res" : "_gnapply") : (gn_sum ? "_gn" : ""), colmax ? "_kmax" : "");
       info = buf;
     }
-    const double cbytes = ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n) * es + (double)conv_packed_weight_bytes(ly);
+    const double cbytes = ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n * ((ge && ge->part && residual) ? 2 : 1)) * es + (double)conv_packed_weight_bytes(ly);
     pl->conv_bytes += cbytes;
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out, LDC_CLASS_CONV, cbytes);
   }
@@ -1590,14 +1635,26 @@ struct PlanBuilder {
     const float* cur_ss = pl->cur_ss;
     // fp8-weight context: block1's output feeds block2's conv alone, so it is produced in fp8 and that conv runs fp8 x fp8
     const bool f8 = c->w8 && c->fp8_act && r.c2_f8.w != nullptr;
-    void* a = act(rows, r.cout);
     void* b = f8 ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
-    void* d = act(rows, r.cout);
     void* out = (out_mode & 1) ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
     float* st1 = next_stats();
     float* st2 = next_stats();
     const int cpg = r.cout / g;
     const bool fuse_stats = c->fuse_gn_stats && cpg >= 4 && (cpg & (cpg - 1)) == 0;
+    // GroupNorm apply inside the conv epilogue (in-launch per-item wait): the tile height must not exceed an item's rows
+    // (a tile then straddles at most two items), and the output must be in the UNet dtype (fp8 outputs keep gn_apply)
+    const bool epi_ok = c->fuse_gn_epi && cpg % 32 == 0 && r.cout % 32 == 0;
+    bool epi1 = false, epi2 = false;
+    GnEpi ge1, ge2;
+    if (epi_ok) {
+      int t1[2], t2[2];
+      conv_bm(r.c1, L, L, false, t1);
+      epi1 = !f8 && t1[0] > 0 && t1[0] <= L && take_part(&ge1, L, t1[0], t1[1], r.cout);
+      conv_bm(f8 ? r.c2_f8 : r.c2, L, L, false, t2);
+      epi2 = !(out_mode & 1) && t2[0] > 0 && t2[0] <= L && take_part(&ge2, L, t2[0], t2[1], r.cout);
+    }
+    void* a = epi1 ? nullptr : act(rows, r.cout);   // un-normalised conv outputs exist only on the unfused path
+    void* d = epi2 ? nullptr : act(rows, r.cout);
     // the 1x1 res_conv only feeds the final add: it runs on the side stream, off the conv->norm->conv chain
     const void* res = x1;
     if (r.has_res) {
@@ -1608,21 +1665,37 @@ struct PlanBuilder {
       where = 0;
       res = rr;
     }
-    conv(r.c1, x1, x2, a, nullptr, L, L, fuse_stats ? st1 : nullptr);
     const ResnetW* rp = &r;
-    if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
-    add([=](hipStream_t s) {
-      return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, cur_ss + rp->ss_off,
-                             0, nullptr, ACT_SILU, s, nullptr, nullptr, f8 ? 1 : 0);
-    }, false, 0, LDC_CLASS_GN_APPLY, (f8 ? 1.5 : 2.0) * Bn * L * rp->cout * es);
-    conv(f8 ? r.c2_f8 : r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
-    if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
-    if (r.has_res) mark(3);
+    if (epi1) {   // block1: conv -> GroupNorm -> (scale + 1, shift) -> SiLU, one launch, one store
+      ge1.gamma = r.g1; ge1.beta = r.b1; ge1.ss = cur_ss + r.ss_off;
+      conv(r.c1, x1, x2, b, nullptr, L, L, nullptr, nullptr, 0, 0, 0, &ge1);
+    } else {
+      conv(r.c1, x1, x2, a, nullptr, L, L, fuse_stats ? st1 : nullptr);
+      if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
+      add([=](hipStream_t s) {
+        return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, cur_ss + rp->ss_off,
+                               0, nullptr, ACT_SILU, s, nullptr, nullptr, f8 ? 1 : 0);
+      }, false, 0, LDC_CLASS_GN_APPLY, (f8 ? 1.5 : 2.0) * Bn * L * rp->cout * es);
+    }
     void* xn = nullptr;
     if (ln_g && xn_out && c->fuse_ln && gn_apply_ln_fusable(r.cout)) {
       xn = xn_fp8 ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
       *xn_out = xn;
     }
+    if (epi2) {   // block2: conv -> GroupNorm -> SiLU -> + res (-> tanh), one launch; the PreNorm LayerNorm of a following attention block reads `out`
+      ge2.gamma = r.g2; ge2.beta = r.b2; ge2.ss = nullptr; ge2.out = out_mode & 4;
+      if (r.has_res) mark(3);
+      conv(f8 ? r.c2_f8 : r.c2, b, nullptr, out, res, L, L, nullptr, nullptr, 0, 0, 0, &ge2);
+      if (xn) {
+        const int C = r.cout;
+        add([=](hipStream_t s) { return launch_ln_rows(dt, out, xn, nullptr, ln_g, rows, C, s, xn_fp8 ? 1 : 0); }, false, 0, LDC_CLASS_LAYERNORM,
+            (xn_fp8 ? 1.5 : 2.0) * rows * C * es);
+      }
+      return out;
+    }
+    conv(f8 ? r.c2_f8 : r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
+    if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
+    if (r.has_res) mark(3);
     const int out8_ln = ((xn && xn_fp8) ? 2 : 0) | (gn_apply_fp8_ok(r.cout) ? out_mode : 0);
     add([=](hipStream_t s) {
       return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s, xn, ln_g, out8_ln);
@@ -1686,7 +1759,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const UnetW& u = c->unet;
   pl->B = B; pl->L = L; pl->F = F;
   pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_where.clear(); pl->step_flops.clear(); pl->step_class.clear(); pl->step_bytes.clear(); pl->step_info.clear(); pl->taps.clear();
-  pl->flops = 0; pl->act_bytes = 0; pl->conv_bytes = 0; pl->sk_need_max = 0;
+  pl->flops = 0; pl->act_bytes = 0; pl->conv_bytes = 0; pl->sk_need_max = 0; pl->part_need = 0;
   const int dt = c->dt;
   const size_t es = dt_size(dt);
   const int Cc = u.cond_channels, Cx = u.channels;
@@ -1696,10 +1769,13 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const size_t n_lin = c->fuse_kmax ? u.downs.size() + u.ups.size() : 1;
   const size_t lin_bytes = n_lin * B * linattn_ws_floats_per_item(u.heads, u.dim_head) * 4;
   const int sk_tiles_cap = 1024;
-  const size_t sk_count_bytes = (size_t)sk_tiles_cap * 4;
+  const size_t part_bytes = (pl->part_bytes + 63) / 64 * 64;   // granule regions of the fused GroupNorm applies (sized by the dry planning pass)
+  const size_t sk_count_bytes = (size_t)sk_tiles_cap * 4 + part_bytes;
   const size_t sx_bytes = c->cfg.unet_scale_x ? (size_t)B * 4 : 0;   // per-item max|cat(cond, x)| of --unet_scale_x
   pb.stats_pool = (float*)ar.alloc(gn_bytes + sk_count_bytes + lin_bytes + sx_bytes + 64);
   pb.sk_count = reinterpret_cast<unsigned*>(pb.stats_pool + gn_bytes / 4);
+  pb.part_pool = reinterpret_cast<char*>(pb.sk_count + sk_tiles_cap);
+  pb.part_cap = part_bytes;
   pb.sk_count_cap = sk_tiles_cap;
   pb.linattn_ws = pb.stats_pool + (gn_bytes + sk_count_bytes) / 4;
   // the region the step's ONE memset clears: GroupNorm sums, split-K counters, fused k-max keys, scale_x maxima
@@ -1858,6 +1934,7 @@ static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Pl
     Arena dry;
     LDCCHK(build_plan(c, pl.get(), dry, B, L, F));
     pl->sk_floats = pl->sk_need_max;
+    pl->part_bytes = pl->part_need;
   }
   Arena measure;
   LDCCHK(build_plan(c, pl.get(), measure, B, L, F));

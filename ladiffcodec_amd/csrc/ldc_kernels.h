@@ -75,8 +75,20 @@ struct ConvCall {
   unsigned* sk_count = nullptr;
   long long sk_part_cap = 0;  // floats
   int sk_count_cap = 0;       // tiles
+  // Fused GroupNorm apply in the conv epilogue (pipelined kernel only; needs gn_sum): y = SiLU(GN(conv) * (scale + 1) + shift)
+  // (+ residual) (tanh).  gn_part: [B][gn_mslots][WM][n / 32] 16-byte granule pairs the waves exchange their partial statistics
+  // through, zeroed before every launch (the step's first kernel does it); see ConvKArgs / epilogue_gn_fused in conv_device.h.
+  void* gn_part = nullptr;
+  int gn_mslots = 0;                // M-tile slots per item (>= (L_rows + BM - 1) / BM + 1 for the tile height the dry run reports)
+  const float* gn_gamma = nullptr;
+  const float* gn_beta = nullptr;
+  const float* gn_ss = nullptr;     // [2 n] scale | shift of the current timestep, or null
+  int gn_out = 0;                   // bit 2: tanh after the residual add
+  int io_sc1 = 0;                   // in-launch producer / consumer hints (ConvKArgs::io_sc1)
+  unsigned* fail_flag = nullptr;    // host-mapped word raised when the bounded in-launch wait gives up
   const ConvTune* tune = nullptr;   // null: defaults
   long long* sk_need = nullptr;     // dry run: no launch, *sk_need = split-K workspace floats this call would use
+  int* bm_out = nullptr;            // dry run (with sk_need): int[2] = rows per tile of the pipelined kernel (0 when the generic kernel would run), wave rows WM
 };
 
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);

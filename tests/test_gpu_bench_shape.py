@@ -369,3 +369,28 @@ def test_fp8_engine_50_step_decode_drift_vs_reference(act8):
         check("fp8", "lat_50" + tag, bg.compare(f"dec50.{i}.latents", got["latents"][i:i + 1].cpu().numpy()), i)
         check("fp8", "wav_50" + tag, bg.compare(f"dec50.{i}.wav", got["wav"][i:i + 1].cpu().numpy()), i)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------- fused GroupNorm apply vs gn_apply launches
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_gn_epilogue_equals_the_separate_gn_apply(dtype):
+    """Round 4: ResnetBlock's GroupNorm -> scale/shift -> SiLU (-> + res) runs in the producing conv's epilogue behind an
+    in-launch per-item wait (unet.py:137-153,176-192).  Switching it off restores the conv + gn_apply launch pairs: both forms
+    must give the same eps at the bench grid (f32: same arithmetic up to the summation order of the statistics; bf16: the
+    fused form normalises the un-rounded accumulator, the split form its bf16 rounding), several times in a row (the arrival
+    counters are re-armed by every step), and the wait must not have timed out (decode raises on the device-side flag)."""
+    e, mc, u, cc, sd, _ = full_engine("c2", dtype)
+    B, Lz, F = 32, 1200, 120
+    g = torch.Generator().manual_seed(43)
+    x = (torch.randn(B, 128, Lz, generator=g) * 0.7).cuda()
+    cond = torch.randn(B, 128, F, generator=g).cuda()
+    try:
+        e.set_option("fuse_gn_epi", 0)
+        ref = e.unet_forward(x, 211, cond).cpu().numpy()
+        e.set_option("fuse_gn_epi", 1)
+        for rep in range(3):
+            got = e.unet_forward(x, 211, cond).cpu().numpy()
+            err = rel(got, ref)
+            assert err < (2e-5 if dtype == "f32" else TOL[dtype]["eps_bench"]), (dtype, rep, err)
+    finally:
+        e.set_option("fuse_gn_epi", 1)

@@ -1,0 +1,35 @@
+#!/bin/bash
+# One GPU-box session of round 4.  Everything lands in gpurun_out/r04/; the summaries to be judged are copied into profiles/.
+#   bash tools/run_r04.sh [test|bench|benchq|prof|pmc|shapes] ...
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r04; mkdir -p $O
+cd $R
+for STAGE in "$@"; do
+case $STAGE in
+test)
+  ( time timeout 1500 python -m pytest tests -m gpu -q -x --durations=8 > $O/gputest.log 2>&1 ) 2> $O/gputest.time; tail -14 $O/gputest.log; cat $O/gputest.time
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
+benchq)   # quick c2 line, no CPU baseline
+  timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pipelined > $O/benchq_c2.json 2> $O/benchq_c2.err; tail -2 $O/benchq_c2.err; cat $O/benchq_c2.json ;;
+bench)
+  timeout 900 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; tail -2 $O/bench_c2.err; cat $O/bench_c2.json ;;
+prof)
+  rm -rf $O/prof
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-pipelined > $O/prof.log 2>&1)
+  python tools/prof_summary.py $(find $O/prof -name "*.db" | head -1) > $O/kernel_stats.md
+  find $O/prof -name "*.db" -size +30M -delete
+  head -30 $O/kernel_stats.md ;;
+pmc)
+  rm -rf $O/pmc_FETCH $O/pmc_WRITE
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_FETCH -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipelined > $O/pmc_FETCH.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_WRITE -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipelined > $O/pmc_WRITE.log 2>&1)
+  python tools/pmc_traffic.py $O/pmc_FETCH $O/pmc_WRITE $O/conv_traffic.json
+  python tools/pmc_classes.py $O/pmc_FETCH $O/pmc_WRITE $O/conv_pmc_classes.md > /dev/null
+  find $O/pmc_FETCH $O/pmc_WRITE -name "*.csv" -size +20M -delete
+  cat $O/conv_traffic.json ;;
+shapes)
+  LDC_PROFILE_DUMP=/tmp/d.txt timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined > $O/bench_shapes.json 2> $O/bench_shapes.err
+  python tools/prof_shapes.py /tmp/d.txt > $O/layer_shapes.txt 2>&1; head -30 $O/layer_shapes.txt ;;
+*) echo "unknown stage $STAGE" ;;
+esac
+done
