@@ -385,7 +385,7 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 // Then: per-column affine (same arithmetic as gn_apply_cols_kernel: a1 = rstd * gamma, b1 = beta - mean * a1, the timestep
 // (scale + 1) and shift folded in) -> SiLU -> LDS transpose -> whole-row stores.  RES: the rows are staged in fp32 and the
 // residual is added to the un-rounded value as 16-byte pieces in the row phase (one rounding, like gn_apply), then the
-// optional tanh.  A tile may straddle two items (flat M tiling); the launcher guarantees L_rows >= BM, i.e. at most two.
+// optional tanh.  A tile may straddle items (flat M tiling); the launcher guarantees 2 * L_rows >= BM, i.e. at most three.
 // The spin is bounded by the 100 MHz wall clock: tiles that are not all resident in time raise the host-mapped flag, never a hang.
 template <typename T, int TM, int TN, bool RES>
 __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
@@ -393,7 +393,8 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
   const int lane = threadIdx.x & 63;
   const int b_first = (int)fdiv((unsigned)m0, a.lrows_div);
   const int b_last = (int)fdiv((unsigned)(min(m0 + BM, M) - 1), a.lrows_div);
-  const int m_split = (b_first + 1) * a.L_rows;   // rows >= m_split belong to b_last
+  const int m_split = (b_first + 1) * a.L_rows;   // rows >= m_split belong to item b_first + 1, rows >= m_split2 to b_first + 2
+  const int m_split2 = m_split + a.L_rows;
   const int cpg = a.gn_cpg;                       // a multiple of 32: a 32-column block lies inside one group
   const int sub_n = cpg >> 5;                     // 32-column blocks per group (a power of two)
   const int nc32 = a.n >> 5;
@@ -448,8 +449,43 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
   }
   // 2. gather the statistics of this wave's (item, group) pairs and build the per-column affine
   const float inv_n = 1.0f / ((float)a.L_rows * (float)cpg);
-  float ca[2][TN], cb[2][TN];
+  float ca0[TN], cb0[TN], ca1[TN], cb1[TN], ca2[TN], cb2[TN];   // per-column affine for the (at most three) items of the tile
   const unsigned long long t0 = wall_clock64();
+  // statistics of (item bb, the group of 32-column block c32_0) -> mean, rstd (wave-uniform values, computed by every lane)
+  auto gather = [&](int bb, int g, float& mean, float& rstd) {
+    const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
+    const int total = ((hi - 1) / BM - lo / BM + 1) * WM * sub_n;   // granule pairs of (item bb, group g)
+    const char* base = a.gn_part + (size_t)bb * a.gn_mslots * WM * nc32 * 16 + (size_t)g * sub_n * 16;
+    float s = 0.f, ss = 0.f;
+    for (int l0 = 0; l0 < total; l0 += 64) {
+      const int l = l0 + lane;
+      const bool mine = l < total;
+      const int ms_wm = mine ? l / sub_n : 0, sub = mine ? l - ms_wm * sub_n : 0;   // (mslot * WM + wm'), block inside the group
+      const char* src = base + ((size_t)ms_wm * nc32 + sub) * 16;
+      u32x4_t v;
+      for (;;) {
+        load16_sc1_issue(v, src);
+        wait_vm0();
+        if (__all(!mine || (v[0] == 1u && v[2] == 1u))) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 50000000ull) {   // 0.5 s
+          if (lane == 0 && a.fail_flag) __hip_atomic_store(a.fail_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
+      if (mine) {
+        s += __uint_as_float(v[1]);
+        ss += __uint_as_float(v[3]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      ss += __shfl_xor(ss, o);
+    }
+    mean = s * inv_n;
+    rstd = rsqrtf(fmaxf(ss * inv_n - mean * mean, 0.0f) + 1e-5f);
+  };
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = col_wave0 + j * 32 + (lane & 31);
@@ -458,56 +494,26 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
     const int g = (col_wave0 + j * 32 < a.n ? col_wave0 + j * 32 : 0) / cpg;   // wave-uniform
     const float gam = a.gn_gamma[cc], bet = a.gn_beta[cc];
     const float sc = a.gn_ss ? a.gn_ss[cc] + 1.0f : 1.0f, sh = a.gn_ss ? a.gn_ss[a.n + cc] : 0.0f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (q == 1 && b_last == b_first) {
-        ca[1][j] = ca[0][j];
-        cb[1][j] = cb[0][j];
-        continue;
-      }
-      const int bb = q ? b_last : b_first;
-      const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
-      const int per_mt = WM * sub_n;
-      const int total = ((hi - 1) / BM - lo / BM + 1) * per_mt;   // granule pairs of (item bb, group g)
-      const char* base = a.gn_part + (size_t)bb * a.gn_mslots * WM * nc32 * 16 + (size_t)g * sub_n * 16;
-      float s = 0.f, ss = 0.f;
-      for (int l0 = 0; l0 < total; l0 += 64) {
-        const int l = l0 + lane;
-        const bool mine = l < total;
-        const int ms_wm = mine ? l / sub_n : 0, sub = mine ? l - ms_wm * sub_n : 0;   // (mslot * WM + wm'), block inside the group
-        const char* src = base + ((size_t)ms_wm * nc32 + sub) * 16;
-        u32x4_t v;
-        for (;;) {
-          load16_sc1_issue(v, src);
-          wait_vm0();
-          if (__all(!mine || (v[0] == 1u && v[2] == 1u))) break;
-          __builtin_amdgcn_s_sleep(1);
-          if (wall_clock64() - t0 > 50000000ull) {   // 0.5 s
-            if (lane == 0 && a.fail_flag) __hip_atomic_store(a.fail_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-          }
-        }
-        if (mine) {
-          s += __uint_as_float(v[1]);
-          ss += __uint_as_float(v[3]);
-        }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o);
-        ss += __shfl_xor(ss, o);
-      }
-      const float mean = s * inv_n;
-      const float var = fmaxf(ss * inv_n - mean * mean, 0.0f);
-      const float rstd = rsqrtf(var + 1e-5f);
-      float a1 = rstd * gam;
-      float b1 = bet - mean * a1;
+    auto affine = [&](float mean, float rstd, float& a1, float& b1) {
+      a1 = rstd * gam;
+      b1 = bet - mean * a1;
       if (a.gn_ss) {
         a1 *= sc;
         b1 = b1 * sc + sh;
       }
-      ca[q][j] = a1;
-      cb[q][j] = b1;
+    };
+    float mean, rstd;
+    gather(b_first, g, mean, rstd);
+    affine(mean, rstd, ca0[j], cb0[j]);
+    ca1[j] = ca0[j]; cb1[j] = cb0[j];
+    if (b_first + 1 <= b_last) {
+      gather(b_first + 1, g, mean, rstd);
+      affine(mean, rstd, ca1[j], cb1[j]);
+    }
+    ca2[j] = ca1[j]; cb2[j] = cb1[j];
+    if (b_first + 2 <= b_last) {
+      gather(b_first + 2, g, mean, rstd);
+      affine(mean, rstd, ca2[j], cb2[j]);
     }
   }
   typedef typename std::conditional<RES, float, T>::type TS;   // staging element
@@ -523,9 +529,9 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const bool second = m_wave0 + row >= m_split;
+        const bool second = m_wave0 + row >= m_split, third = m_wave0 + row >= m_split2;
         const float v = fmaf(acc[i][j][r], wsc[j], bv[j]);
-        const float o = fast_silu(fmaf(v, second ? ca[1][j] : ca[0][j], second ? cb[1][j] : cb[0][j]));
+        const float o = fast_silu(fmaf(v, third ? ca2[j] : (second ? ca1[j] : ca0[j]), third ? cb2[j] : (second ? cb1[j] : cb0[j])));
         store_out<TS>(wave_lds, (size_t)(row * PITCH) / sizeof(TS) + j * 32 + (lane & 31), o);
       }
   // same wave wrote and reads: LDS executes a wave's operations in order

@@ -276,6 +276,7 @@ struct ldc_ctx {
   unsigned long long flow_n = 0;
   int flow_depth = 8;           // LDC_FLOW_DEPTH (0 = unbounded look-ahead)
   int fuse_gn_stats = 1;
+  int gn_epi_min_l = 0;         // LDC_GN_EPI_MINL: shortest level (positions per item) whose ResnetBlocks fuse the GroupNorm apply
   int fuse_gn_epi = 1;          // GroupNorm APPLY in the producing conv's epilogue behind an in-launch per-item wait (LDC_NO_GN_EPI / option "fuse_gn_epi")
   // knobs read from the environment once, at ldc_create (per context, not process-global)
   ConvTune tune;
@@ -983,6 +984,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->side_streams = (getenv("LDC_SIDE") && c->split_batch == 1) ? 1 : 0;
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
+  c->gn_epi_min_l = env_int("LDC_GN_EPI_MINL", c->gn_epi_min_l);
   c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
   c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
   c->fuse_attn_tail = getenv("LDC_NO_TAIL_FUSE") ? 0 : 1;
@@ -1641,17 +1643,17 @@ struct PlanBuilder {
     float* st2 = next_stats();
     const int cpg = r.cout / g;
     const bool fuse_stats = c->fuse_gn_stats && cpg >= 4 && (cpg & (cpg - 1)) == 0;
-    // GroupNorm apply inside the conv epilogue (in-launch per-item wait): the tile height must not exceed an item's rows
-    // (a tile then straddles at most two items), and the output must be in the UNet dtype (fp8 outputs keep gn_apply)
-    const bool epi_ok = c->fuse_gn_epi && cpg % 32 == 0 && r.cout % 32 == 0;
+    // GroupNorm apply inside the conv epilogue (in-launch per-item wait): the tile height must not exceed twice an item's rows
+    // (a tile then straddles at most three items), and the output must be in the UNet dtype (fp8 outputs keep gn_apply)
+    const bool epi_ok = c->fuse_gn_epi && cpg % 32 == 0 && r.cout % 32 == 0 && L >= c->gn_epi_min_l;
     bool epi1 = false, epi2 = false;
     GnEpi ge1, ge2;
     if (epi_ok) {
       int t1[2], t2[2];
       conv_bm(r.c1, L, L, false, t1);
-      epi1 = !f8 && t1[0] > 0 && t1[0] <= L && take_part(&ge1, L, t1[0], t1[1], r.cout);
+      epi1 = !f8 && t1[0] > 0 && t1[0] <= 2 * L && take_part(&ge1, L, t1[0], t1[1], r.cout);
       conv_bm(f8 ? r.c2_f8 : r.c2, L, L, false, t2);
-      epi2 = !(out_mode & 1) && t2[0] > 0 && t2[0] <= L && take_part(&ge2, L, t2[0], t2[1], r.cout);
+      epi2 = !(out_mode & 1) && t2[0] > 0 && t2[0] <= 2 * L && take_part(&ge2, L, t2[0], t2[1], r.cout);
     }
     void* a = epi1 ? nullptr : act(rows, r.cout);   // un-normalised conv outputs exist only on the unfused path
     void* d = epi2 ? nullptr : act(rows, r.cout);
