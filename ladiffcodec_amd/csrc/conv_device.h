@@ -72,9 +72,12 @@ struct ConvKArgs {
   int io_sc1;              // bit 0: the output is read inside this launch (write-through stores); bit 1: the residual was
                            // produced inside this launch (agent-scope loads); bit 2: so was the input window (x1)
   unsigned* fail_flag;     // host-mapped word raised when a bounded spin gives up (the output is then wrong, never a hang)
+  char* y2;                // folded 1x1 conv (ConvLayer::wtaps): second output [rows][n], or null
+  const float* bias2;
+  int wtaps;               // weight slabs per channel chunk in the packed image (taps, or taps + 1 with the folded conv)
   const ConvTune* tune;    // host-only (never read on the device)
   long long* sk_need;      // host-only: dry run
-  int* bm_out;             // host-only: dry run -- rows per tile the fast kernel would use (0: generic kernel); bm_out[1] = wave rows WM
+  int* bm_out;             // host-only: dry run -- rows per tile the fast kernel would use (0: generic kernel); bm_out[1] = wave rows WM, bm_out[2] = split-K factor
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -603,6 +606,38 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
     }
   }
   if (wt) wait_vm0();   // write-through stores have reached memory before anything signals them
+}
+
+// Second output of a launch with a folded 1x1 conv (ConvKArgs::y2): acc + bias2, whole-row stores through the same LDS staging.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void epilogue_rows_second(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
+                                                     int col_wave0, int M) {
+  constexpr int RB = TN * 32 * (int)sizeof(T);
+  constexpr int PITCH = RB + 16;
+  constexpr int LPR = RB / 16;
+  constexpr int RPS = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col_wave0 + j * 32 + (lane & 31);
+    const float bv = (a.bias2 && col < a.n) ? a.bias2[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        store_out<T>(wave_lds, (size_t)(row * PITCH) / sizeof(T) + j * 32 + (lane & 31), acc[i][j][r] + bv);
+      }
+  }
+  const int rsub = lane / LPR, chunk = lane % LPR;
+  const int col = col_wave0 + chunk * (16 / (int)sizeof(T));
+#pragma unroll
+  for (int sw = 0; sw < TM * 32 / RPS; ++sw) {
+    const int row = sw * RPS + rsub;
+    const int m = m_wave0 + row;
+    const uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * PITCH + chunk * 16);
+    if (m < M && col < a.n) *reinterpret_cast<uint4*>(a.y2 + ((size_t)m * a.n + col) * sizeof(T)) = v;
+  }
 }
 
 template <typename T, int TM, int TN>

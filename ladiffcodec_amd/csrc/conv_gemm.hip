@@ -241,7 +241,7 @@ int conv_pick_bn(int n) {
 size_t conv_packed_weight_bytes(const ConvLayer& ly) {
   const int bke = kRowBytes / (int)dt_size(ly.dt);
   const int nchunks = (ly.cin1 + ly.cin2) / bke;
-  return (size_t)nchunks * ly.taps * ly.n_pad * (ly.w8 ? 32 : kRowBytes);
+  return (size_t)nchunks * (ly.wtaps ? ly.wtaps : ly.taps) * ly.n_pad * (ly.w8 ? 32 : kRowBytes);
 }
 
 // OCP fp8 e4m3fn (1-4-3, bias 7, no infinities, max 448): round to nearest even, saturate
@@ -398,9 +398,11 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   if (ly.tr_stride) a.colmax = nullptr;
   a.ksplit = 1; a.sk_part = c.sk_part; a.sk_count = c.sk_count; a.sk_part_cap = c.sk_part_cap; a.sk_count_cap = c.sk_count_cap;
   a.tune = c.tune; a.sk_need = c.sk_need; a.bm_out = c.bm_out;
-  if (c.bm_out) { c.bm_out[0] = 0; c.bm_out[1] = 0; }
+  if (c.bm_out) { c.bm_out[0] = 0; c.bm_out[1] = 0; c.bm_out[2] = 1; }
   a.gn_part = (char*)c.gn_part; a.gn_mslots = c.gn_mslots; a.gn_gamma = c.gn_gamma; a.gn_beta = c.gn_beta; a.gn_ss = c.gn_ss; a.gn_out = c.gn_out; a.io_sc1 = c.io_sc1;
   a.fail_flag = c.fail_flag;
+  a.y2 = (char*)c.y2; a.bias2 = ly.bias2; a.wtaps = ly.wtaps ? ly.wtaps : ly.taps;
+  if ((c.y2 != nullptr) != (ly.wtaps != 0)) return hipErrorInvalidValue;   // a folded layer always writes its second output
   a.wscale = (ly.w8 || ly.dt == DT_FP8) ? ly.wscale : nullptr; a.w8 = ly.w8;
   if (c.sk_need) *c.sk_need = 0;
   if (c.gn_sum && c.gn_groups > 0 && !ly.tr_stride) {
@@ -436,7 +438,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     if (e != hipSuccess || launched) return e;
   }
   if (c.sk_need) return hipSuccess;   // dry run: the generic kernel never splits K
-  if (c.gn_part) return hipErrorInvalidValue;   // the fused GroupNorm apply exists only on the pipelined kernel (the planner checks bm_out)
+  if (c.gn_part || c.y2) return hipErrorInvalidValue;   // the fused GroupNorm apply exists only on the pipelined kernel (the planner checks bm_out)
   if (ly.dt == DT_FP8) return hipErrorInvalidValue;   // fp8 inputs exist only on the pipelined kernel (the planner checks eligibility)
   a.win_rows = std::min(span, c.B * c.L_in) + 1;
   int bn = ly.bn;

@@ -136,6 +136,7 @@ struct Codec {
 };
 
 struct ResnetW {
+  ConvLayer c1r;               // block1's conv with res_conv folded in (ConvLayer::wtaps; bf16 / f32 weights only)
   ConvLayer c1, c2, res;
   ConvLayer c2_f8;              // fp8-weight contexts: block2's conv with fp8 INPUTS too (w == null: not eligible)
   bool has_res = false;
@@ -277,6 +278,7 @@ struct ldc_ctx {
   int flow_depth = 8;           // LDC_FLOW_DEPTH (0 = unbounded look-ahead)
   int fuse_gn_stats = 1;
   int gn_epi_min_l = 0;         // LDC_GN_EPI_MINL: shortest level (positions per item) whose ResnetBlocks fuse the GroupNorm apply
+  int fold_res = 1;             // res_conv as a second accumulator set of block1's conv (LDC_NO_RES_FOLD / option "fold_res")
   int fuse_gn_epi = 1;          // GroupNorm APPLY in the producing conv's epilogue behind an in-launch per-item wait (LDC_NO_GN_EPI / option "fuse_gn_epi")
   // knobs read from the environment once, at ldc_create (per context, not process-global)
   ConvTune tune;
@@ -719,6 +721,21 @@ static int build_resnet(ldc_ctx* c, WeightReader& wr, const std::string& p, int 
     ConvSpec s3 = sp;
     s3.k = 1; s3.pad_left = 0;
     LDCCHK(make_conv(c, s3, wr_->data.data(), br_->data.data(), &r->res));
+    if (!c->w8) {
+      // res_conv folded into block1's conv (both read x, unet.py:171,189-192): a packed image with four slabs per channel
+      // chunk -- the three taps of the standardised block1 weight and the 1x1 res_conv weight (ConvLayer::wtaps)
+      const std::vector<float> w = fold_weight_std(*w1);
+      std::vector<float> w4((size_t)cout * cin * 4);
+      for (size_t oc = 0; oc < (size_t)cout * cin; ++oc) {
+        w4[oc * 4 + 0] = w[oc * 3 + 0]; w4[oc * 4 + 1] = w[oc * 3 + 1]; w4[oc * 4 + 2] = w[oc * 3 + 2];
+        w4[oc * 4 + 3] = wr_->data[oc];
+      }
+      ConvSpec s4 = sp;
+      s4.k = 4;
+      LDCCHK(make_conv(c, s4, w4.data(), b1->data.data(), &r->c1r));
+      r->c1r.taps = 3; r->c1r.wtaps = 4; r->c1r.bias2 = r->res.bias;
+      r->c1r.flops_per_row = r->c1.flops_per_row + r->res.flops_per_row;
+    }
   }
   LDCCHK(c->wmem.upload(&r->g1, g1->data));
   LDCCHK(c->wmem.upload(&r->b1, be1->data));
@@ -985,6 +1002,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
   c->gn_epi_min_l = env_int("LDC_GN_EPI_MINL", c->gn_epi_min_l);
+  c->fold_res = getenv("LDC_NO_RES_FOLD") ? 0 : 1;
   c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
   c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
   c->fuse_attn_tail = getenv("LDC_NO_TAIL_FUSE") ? 0 : 1;
@@ -1124,12 +1142,16 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->fuse_gn_epi) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fuse_gn_epi = value ? 1 : 0; }
     return LDC_OK;
   }
+  if (n == "fold_res") {
+    if ((value ? 1 : 0) != c->fold_res) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fold_res = value ? 1 : 0; }
+    return LDC_OK;
+  }
   if (n == "side_streams") {
     if (value && c->split_batch != 1) return fail(LDC_E_INVALID, "side streams need a single chain (split 1)");
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fold_res | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 extern "C" int ldc_reseed(ldc_ctx* c, uint64_t seed) {
@@ -1561,6 +1583,7 @@ struct PlanBuilder {
     pl->flops += flops;
   }
   std::string info;   // description of the next op added
+  void* y2_next = nullptr;   // second output of the next conv added (a layer with a folded 1x1 conv)
   // fused GroupNorm apply of a conv (see ConvCall::gn_cnt)
   struct GnEpi {
     void* part = nullptr;          // granule region of this conv
@@ -1569,14 +1592,14 @@ struct PlanBuilder {
     int out = 0;
   };
   // rows per tile the pipelined kernel would use for this conv (0: generic kernel) -- the fused apply needs L_out >= that
-  // (out[0] = rows per tile, out[1] = wave rows)
-  void conv_bm(const ConvLayer& ly, int L_in, int L_out, bool with_stats, int* out) {
+  // (out[0] = rows per tile, out[1] = wave rows, out[2] = split-K factor)
+  void conv_bm(const ConvLayer& ly, int L_in, int L_out, bool with_stats, int* out) {   // out: int[3]
     ConvCall d;
     d.B = B; d.L_in = L_in; d.L_rows = L_out; d.y_ld = ly.n; d.tune = &c->tune;
     d.sk_part = sk_part; d.sk_count = sk_count; d.sk_part_cap = sk_part_cap; d.sk_count_cap = sk_count_cap;
     if (with_stats) { d.gn_sum = stats_pool; d.gn_groups = c->unet.groups; }
     long long need = 0;
-    out[0] = out[1] = 0;
+    out[0] = out[1] = 0; out[2] = 1;
     d.sk_need = &need; d.bm_out = out;
     (void)launch_conv(ly, d, nullptr);
   }
@@ -1596,6 +1619,7 @@ struct PlanBuilder {
     ConvCall cc;
     cc.B = B; cc.L_in = L_in; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.residual = residual; cc.y_ld = ly.n;
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
+    cc.y2 = y2_next; y2_next = nullptr;
     if (ge && ge->part) {
       cc.gn_groups = c->unet.groups;
       cc.gn_part = ge->part; cc.gn_mslots = ge->mslots; cc.gn_gamma = ge->gamma; cc.gn_beta = ge->beta; cc.gn_ss = ge->ss; cc.gn_out = ge->out;
@@ -1614,11 +1638,11 @@ struct PlanBuilder {
     const ConvLayer* lp = &ly;
     {
       char buf[96];
-      snprintf(buf, sizeof(buf), "k%d_s%d_u%d_c%d+%d->%d_L%d%s%s", ly.taps, ly.stride, ly.ups, ly.cin1, ly.cin2, ly.n, L_out,
+      snprintf(buf, sizeof(buf), "k%d%s_s%d_u%d_c%d+%d->%d_L%d%s%s", ly.taps, ly.wtaps ? "+res" : "", ly.stride, ly.ups, ly.cin1, ly.cin2, ly.n, L_out,
                (ge && ge->part) ? (residual ? "_gnapply+res" : "_gnapply") : (gn_sum ? "_gn" : ""), colmax ? "_kmax" : "");
       info = buf;
     }
-    const double cbytes = ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n * ((ge && ge->part && residual) ? 2 : 1)) * es + (double)conv_packed_weight_bytes(ly);
+    const double cbytes = ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n * (((ge && ge->part && residual) ? 2 : 1) + (ly.wtaps ? 1 : 0))) * es + (double)conv_packed_weight_bytes(ly);
     pl->conv_bytes += cbytes;
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out, LDC_CLASS_CONV, cbytes);
   }
@@ -1649,7 +1673,7 @@ struct PlanBuilder {
     bool epi1 = false, epi2 = false;
     GnEpi ge1, ge2;
     if (epi_ok) {
-      int t1[2], t2[2];
+      int t1[3], t2[3];
       conv_bm(r.c1, L, L, false, t1);
       epi1 = !f8 && t1[0] > 0 && t1[0] <= 2 * L && take_part(&ge1, L, t1[0], t1[1], r.cout);
       conv_bm(f8 ? r.c2_f8 : r.c2, L, L, false, t2);
@@ -1657,22 +1681,32 @@ struct PlanBuilder {
     }
     void* a = epi1 ? nullptr : act(rows, r.cout);   // un-normalised conv outputs exist only on the unfused path
     void* d = epi2 ? nullptr : act(rows, r.cout);
-    // the 1x1 res_conv only feeds the final add: it runs on the side stream, off the conv->norm->conv chain
+    // res_conv: folded into block1's conv where that conv runs on the pipelined kernel with an unsplit K (one launch and one
+    // read of x less); otherwise its own launch (on the side stream when there is one: it only feeds the final add)
     const void* res = x1;
-    if (r.has_res) {
-      void* rr = act(rows, r.cout);
+    bool folded = false;
+    void* rr = r.has_res ? act(rows, r.cout) : nullptr;
+    if (r.has_res && c->fold_res && r.c1r.w) {
+      int t[3];
+      conv_bm(r.c1, L, L, false, t);
+      folded = t[0] > 0 && t[2] == 1;
+    }
+    if (r.has_res && !folded) {
       mark(2);
       where = 1;
       conv(r.res, x1, x2, rr, nullptr, L, L);
       where = 0;
-      res = rr;
     }
+    if (r.has_res) res = rr;
+    const ConvLayer& c1 = folded ? r.c1r : r.c1;
     const ResnetW* rp = &r;
     if (epi1) {   // block1: conv -> GroupNorm -> (scale + 1, shift) -> SiLU, one launch, one store
       ge1.gamma = r.g1; ge1.beta = r.b1; ge1.ss = cur_ss + r.ss_off;
-      conv(r.c1, x1, x2, b, nullptr, L, L, nullptr, nullptr, 0, 0, 0, &ge1);
+      if (folded) y2_next = rr;
+      conv(c1, x1, x2, b, nullptr, L, L, nullptr, nullptr, 0, 0, 0, &ge1);
     } else {
-      conv(r.c1, x1, x2, a, nullptr, L, L, fuse_stats ? st1 : nullptr);
+      if (folded) y2_next = rr;
+      conv(c1, x1, x2, a, nullptr, L, L, fuse_stats ? st1 : nullptr);
       if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, a, Bn, L, rp->cout, g, st1, s); });
       add([=](hipStream_t s) {
         return launch_gn_apply(dt, a, b, nullptr, Bn, L, rp->cout, g, st1, rp->g1, rp->b1, cur_ss + rp->ss_off,
@@ -1686,7 +1720,7 @@ struct PlanBuilder {
     }
     if (epi2) {   // block2: conv -> GroupNorm -> SiLU -> + res (-> tanh), one launch; the PreNorm LayerNorm of a following attention block reads `out`
       ge2.gamma = r.g2; ge2.beta = r.b2; ge2.ss = nullptr; ge2.out = out_mode & 4;
-      if (r.has_res) mark(3);
+      if (r.has_res && !folded) mark(3);
       conv(f8 ? r.c2_f8 : r.c2, b, nullptr, out, res, L, L, nullptr, nullptr, 0, 0, 0, &ge2);
       if (xn) {
         const int C = r.cout;
@@ -1697,7 +1731,7 @@ struct PlanBuilder {
     }
     conv(f8 ? r.c2_f8 : r.c2, b, nullptr, d, nullptr, L, L, fuse_stats ? st2 : nullptr);
     if (!fuse_stats) add([=](hipStream_t s) { return launch_gn_stats(dt, d, Bn, L, rp->cout, g, st2, s); });
-    if (r.has_res) mark(3);
+    if (r.has_res && !folded) mark(3);
     const int out8_ln = ((xn && xn_fp8) ? 2 : 0) | (gn_apply_fp8_ok(r.cout) ? out_mode : 0);
     add([=](hipStream_t s) {
       return launch_gn_apply(dt, d, out, res, Bn, L, rp->cout, g, st2, rp->g2, rp->b2, nullptr, 0, nullptr, ACT_SILU, s, xn, ln_g, out8_ln);

@@ -43,6 +43,11 @@ struct ConvLayer {
   int w8 = 0;                 // weights are OCP fp8 e4m3 (dt must be DT_BF16): value = fp8 * wscale[n]
   float* wscale = nullptr;    // [n] fp32 per-output-channel scale (w8)
   double flops_per_row = 0;   // 2*K*N, for accounting
+  // ResnetBlock.res_conv folded into block1's conv (unet.py:171,189-192: both read the same input): the packed image holds
+  // wtaps = taps + 1 slabs per channel chunk, the extra one being the 1x1 res_conv weight; the pipelined kernel multiplies it
+  // with the centre-tap window it has in LDS anyway into a second accumulator set and writes ConvCall::y2 (+ bias2).
+  int wtaps = 0;              // 0: no folded second conv
+  float* bias2 = nullptr;     // [n] bias of the folded 1x1 conv
 };
 
 // tuning knobs of the conv launchers; owned by the context (read from the environment once at ldc_create)
@@ -61,6 +66,7 @@ struct ConvCall {
   const void* x1 = nullptr;
   const void* x2 = nullptr;
   void* y = nullptr;
+  void* y2 = nullptr;              // output of the folded 1x1 conv (ConvLayer::wtaps), [rows][n]
   const void* residual = nullptr;  // [rows][n], same dtype, added before post_act (plain conv only)
   int B = 0;
   int L_in = 0;               // positions per item of the input
@@ -88,7 +94,7 @@ struct ConvCall {
   unsigned* fail_flag = nullptr;    // host-mapped word raised when the bounded in-launch wait gives up
   const ConvTune* tune = nullptr;   // null: defaults
   long long* sk_need = nullptr;     // dry run: no launch, *sk_need = split-K workspace floats this call would use
-  int* bm_out = nullptr;            // dry run (with sk_need): int[2] = rows per tile of the pipelined kernel (0 when the generic kernel would run), wave rows WM
+  int* bm_out = nullptr;            // dry run (with sk_need): int[2] = rows per tile of the pipelined kernel (0 when the generic kernel would run), wave rows WM, split-K factor
 };
 
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
