@@ -325,6 +325,11 @@ int ldc_profile_enable(ldc_ctx* ctx, int on);
  * (n_words 32-bit words; NULL: unmasked). */
 int ldc_xcc_census(ldc_ctx* ctx, const uint32_t* mask, int n_words, int wgs, int* hist16);
 
+/* Test hook: raises the context's device-side failure flag exactly as a kernel whose bounded spin gave up would (code 1: the
+ * cooperative LSTM's hidden-state exchange, 2: the in-launch GroupNorm exchange of a fused conv).  The next call on the context
+ * reports LDC_E_HIP with "device-side failure [coop_lstm]" / "[gn_wait]" in ldc_last_error and clears the flag. */
+int ldc_debug_raise_failure(ldc_ctx* ctx, int code);
+
 /* Host-side cost of the step-graph replays since the last reset: milliseconds spent inside hipGraphLaunch, milliseconds spent
  * waiting for the bounded look-ahead window (LDC_FLOW_DEPTH), number of replays. */
 int ldc_host_stats(ldc_ctx* ctx, int reset, double* graph_launch_ms, double* lookahead_wait_ms, int64_t* graph_launches);

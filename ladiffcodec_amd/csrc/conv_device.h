@@ -471,8 +471,9 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
         wait_vm0();
         if (__all(!mine || (v[0] == 1u && v[2] == 1u))) break;
         __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 50000000ull) {   // 0.5 s
+        if (wall_clock64() - t0 > 50000000ull) {   // 0.5 s: give up, raise the flag, poison the output
           if (lane == 0 && a.fail_flag) __hip_atomic_store(a.fail_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          s = __uint_as_float(0x7fc00000u);
           break;
         }
       }

@@ -323,10 +323,17 @@ static hipStream_t pick_stream(ldc_ctx* c, void* s) { return s ? reinterpret_cas
 // A kernel that gave up (bounded spin of the cooperative LSTM) raises a host-mapped flag; it is reported by the first
 // API call that sees it: synchronous calls (stream == NULL) see their own failures, asynchronous ones the previous call's.
 static int check_dev_flag(ldc_ctx* c) {
-  if (c->dev_flag_host && *reinterpret_cast<volatile unsigned*>(c->dev_flag_host)) {
+  const unsigned v = c->dev_flag_host ? *reinterpret_cast<volatile unsigned*>(c->dev_flag_host) : 0u;
+  if (v) {
     *reinterpret_cast<volatile unsigned*>(c->dev_flag_host) = 0u;
-    return fail(LDC_E_HIP, "cooperative LSTM: the hidden-state exchange timed out (its workgroups were not co-resident: is the "
-                           "GPU shared with another process?); the outputs of that call are NaN");
+    // the bracketed tag is what callers key their fallback on (sample.py: decode_with_retry)
+    if (v == 2)
+      return fail(LDC_E_HIP, "device-side failure [gn_wait]: the in-launch GroupNorm exchange of a fused conv timed out (its tiles were "
+                             "not all resident in time: is the GPU shared with another process?); the outputs of that call are NaN; "
+                             "ldc_set_option(ctx, \"fuse_gn_epi\", 0) restores the separate conv + gn_apply launches");
+    return fail(LDC_E_HIP, "device-side failure [coop_lstm]: cooperative LSTM: the hidden-state exchange timed out (its workgroups were "
+                           "not co-resident: is the GPU shared with another process?); the outputs of that call are NaN; "
+                           "ldc_set_option(ctx, \"lstm_stream\", 1) selects the streamed LSTM kernel");
   }
   return LDC_OK;
 }
@@ -1152,6 +1159,13 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     return LDC_OK;
   }
   return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fold_res | fp8_act | train_fp32_mfma | train_bf16)", name);
+}
+
+// debug hook: raise the device-side failure flag as a kernel that gave up would (1 = cooperative LSTM, 2 = fused GroupNorm wait)
+extern "C" int ldc_debug_raise_failure(ldc_ctx* c, int code) {
+  if (!c || !c->dev_flag_host || (code != 1 && code != 2)) return fail(LDC_E_INVALID, "bad arguments");
+  *reinterpret_cast<volatile unsigned*>(c->dev_flag_host) = (unsigned)code;
+  return LDC_OK;
 }
 
 extern "C" int ldc_reseed(ldc_ctx* c, uint64_t seed) {

@@ -76,6 +76,10 @@ class Engine:
         products in the training GEMMs, opt-in; process-wide)."""
         L.check(self.lib.ldc_set_option(self._ctx, name.encode(), int(value)))
 
+    def debug_raise_failure(self, code: int) -> None:
+        """test hook: raise the device-side failure flag (1 = cooperative LSTM gave up, 2 = fused GroupNorm wait gave up)"""
+        L.check(self.lib.ldc_debug_raise_failure(self._ctx, int(code)))
+
     def host_stats(self, reset: bool = True):
         """-> (ms inside hipGraphLaunch, ms waiting for the look-ahead window, graph replays) since the last reset"""
         a, b, n = C.c_double(), C.c_double(), C.c_int64()

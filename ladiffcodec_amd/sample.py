@@ -126,15 +126,42 @@ def read_wav_16k(path: str, eng=None) -> np.ndarray:
 
 
 def wav_header(path: str) -> Tuple[int, int, int]:
-    """(channels, samples at 16 kHz, sample rate) from the file header alone (memory-mapped read: no sample is touched); the length
-    after resampling is torchaudio's ceil(16000 * T / sr) (functional.resample)."""
-    from scipy.io import wavfile
-    sr, x = wavfile.read(path, mmap=True)
-    n = int(x.shape[0])
-    ch = 1 if x.ndim == 1 else int(x.shape[1])
-    del x
-    n16 = n if sr == 16000 else -(-16000 * n // int(sr))
-    return ch, n16, int(sr)
+    """(channels, samples at 16 kHz, sample rate) from the RIFF header alone: the 'fmt ' and 'data' chunk headers are parsed
+    directly, no sample is touched and every PCM / float container size works (scipy's memory-mapped read refuses the 3-byte
+    samples of 24-bit files: one such file used to abort the whole run on every rank).  The length after resampling is what
+    the resampler itself will produce (ldc_resample_out_len = torchaudio's ceil(16000 * T / sr)), so the batch plan and the
+    data agree."""
+    import struct
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] not in (b"RIFF", b"RF64") or head[8:12] != b"WAVE":
+            raise ValueError(f"{path}: not a RIFF/WAVE file")
+        ch = sr = block = None
+        n_bytes = None
+        while True:
+            hdr = f.read(8)
+            if len(hdr) < 8:
+                break
+            cid, size = hdr[:4], struct.unpack("<I", hdr[4:])[0]
+            if cid == b"fmt ":
+                fmt = f.read(size + (size & 1))
+                _, ch, sr, _, block, _ = struct.unpack("<HHIIHH", fmt[:16])
+            elif cid == b"data":
+                here = f.tell()
+                f.seek(0, 2)
+                n_bytes = min(size, f.tell() - here) if size not in (0, 0xFFFFFFFF) else f.tell() - here   # streamed files leave the size open
+                break
+            else:
+                f.seek(size + (size & 1), 1)
+    if not ch or not sr or not block or n_bytes is None:
+        raise ValueError(f"{path}: no 'fmt ' / 'data' chunk")
+    n = n_bytes // block
+    if sr == 16000:
+        n16 = n
+    else:
+        from . import lib as L
+        n16 = int(L.load().ldc_resample_out_len(n, int(sr), 16000))
+    return int(ch), int(n16), int(sr)
 
 
 class LazyWavs:
@@ -216,20 +243,31 @@ def synthesis(inp_args) -> List[str]:
     return written
 
 
-def decode_with_retry(eng, batch, n_steps: int, noise, per_item: bool):
-    """One engine call.  The cond codec's LSTM runs as co-resident workgroups exchanging h through memory (seanet.hip); when
-    other work on the device keeps them from being co-resident its bounded spin gives up, poisons the output and raises the
-    context's device-side failure flag (LDC_E_HIP).  That batch is then decoded again on the streamed LSTM kernel, which needs
-    no co-residency, and the engine stays on it."""
+def apply_device_fallback(eng, err) -> bool:
+    """A kernel whose bounded in-launch wait gave up poisons its output with NaN and raises the context's device-side failure
+    flag; the call that sees the flag fails with LDC_E_HIP and a tagged message (ldc_api.cpp: check_dev_flag).  Switch the engine
+    to the form that needs no co-residency: "[coop_lstm]" -> the streamed LSTM kernel, "[gn_wait]" -> separate conv + gn_apply
+    launches.  Returns False for any other error."""
     from . import lib as L
-    try:
-        out = eng.decode(batch, n_steps, noise=noise, per_item=per_item)
-        return out
-    except L.LdcError as e:
-        if "device-side failure" not in str(e):
-            raise
+    if getattr(err, "code", None) != L.E_HIP or "device-side failure" not in str(err):
+        return False
+    if "[gn_wait]" in str(err):
+        eng.set_option("fuse_gn_epi", 0)
+    else:
         eng.set_option("lstm_stream", 1)
-        return eng.decode(batch, n_steps, noise=noise, per_item=per_item)
+    return True
+
+
+def decode_with_retry(eng, batch, n_steps: int, noise, per_item: bool):
+    """One engine call; a batch hit by a device-side failure (or by the report of an earlier call's) is decoded again after
+    the matching fallback (apply_device_fallback), twice at most: the LSTM and the GroupNorm exchange can each give up once."""
+    from . import lib as L
+    for attempt in range(3):
+        try:
+            return eng.decode(batch, n_steps, noise=noise, per_item=per_item)
+        except L.LdcError as e:
+            if attempt == 2 or not apply_device_fallback(eng, e):
+                raise
 
 
 def plan_batches(lengths: List[int], channels: List[int], rank: int, world: int, batch_size: int) -> List[Tuple[List[int], bool]]:
@@ -358,9 +396,14 @@ def decode_files(eng, files: List[str], inp_args, rank: int, world: int, local_r
         if not bool(torch.isfinite(out).all()):
             # the device-side failure of this batch (cooperative LSTM timed out: its output is poisoned with NaN) is reported by
             # the engine's NEXT call; decode the batch again on the streamed LSTM instead of losing the run
+            # (that report -- LDC_E_HIP with the failure's tag -- may well arrive in the redo itself: decode_with_retry applies the
+            # matching fallback and decodes again; without a report the cooperative LSTM is the one that poisons silently)
             eng_k, batch_k, per_item_k, noise_k = redo
-            eng_k.set_option("lstm_stream", 1)
-            out = eng_k.decode(batch_k.to(dev), inp_args.midway_t, noise=noise_k, per_item=per_item_k).cpu()
+            out = decode_with_retry(eng_k, batch_k.to(dev), inp_args.midway_t, noise_k, per_item_k).cpu()
+            if not bool(torch.isfinite(out).all()):
+                eng_k.set_option("lstm_stream", 1)
+                eng_k.set_option("fuse_gn_epi", 0)
+                out = decode_with_retry(eng_k, batch_k.to(dev), inp_args.midway_t, noise_k, per_item_k).cpu()
             if not bool(torch.isfinite(out).all()):
                 raise RuntimeError(f"non-finite audio decoded for {[files[i] for i in idxs]}")
         out = out.numpy()

@@ -10,7 +10,9 @@ decoder frozen (the reference's `optim.Adam(model.diffusion.parameters())` branc
 discriminator, no EMA, the 1-D UNet.  The main model's frozen parts come from --finetune_model + '.amlt' (train.py:345-347; the
 reference can also start them from random initialisation, which has no use with a frozen codec), the condition model from
 --model_for_cond + '/model_best.amlt' (train.py:356).  Differences that are deliberate: --num_steps (the reference hard-codes 50 000
-outer steps), --max_files, a one-line log per evaluation on stdout instead of the reference's log file."""
+outer steps), --max_files, a one-line log per evaluation on stdout instead of the reference's log file, and the default of --model_type
+('unet' here; the reference's parser defaults to 'transformer', a backbone this repo does not build -- it is refused, like every other flag
+that would change the computation without being implemented: --unet_scale_x, a missing --cond_quantization)."""
 import argparse
 import time
 from typing import List, Optional
@@ -79,7 +81,13 @@ def _unsupported(a) -> None:
     if not a.freeze_ed: bad.append("--freeze_ed is required: only model.diffusion's parameters are optimised (train.py:361-365)")
     if a.use_disc: bad.append("--use_disc (GAN loss) is out of scope")
     if a.train_time_diff: bad.append("--train_time_diff (DiffAudioTime) is out of scope")
-    if a.model_type not in ("unet", "transformer"): bad.append(f"--model_type {a.model_type}: only the 1-D UNet of DiffAudioRep is implemented")
+    if a.model_type != "unet": bad.append(f"--model_type {a.model_type}: only the 1-D UNet of DiffAudioRep is implemented (the reference builds "
+                                          "TransformerDDPM for 'transformer', its own default; here the default is 'unet')")
+    if a.unet_scale_x: bad.append("--unet_scale_x is implemented on the decode path only (the training step has no per-item max scaling of cat(cond, x))")
+    if not a.cond_quantization: bad.append("--cond_quantization is required: the condition codec of the training row is the quantised one "
+                                           "(BASELINE configs[3]; without it the reference conditions on unquantised latents, train.py:355)")
+    from .lib import FINAL_ACTIVATIONS
+    if a.final_activation not in FINAL_ACTIVATIONS: bad.append(f"--final_activation {a.final_activation}: supported are {sorted(k for k in FINAL_ACTIVATIONS if k)}")
     if a.self_condition or a.qtz_condition: bad.append("--self_condition / --qtz_condition are not implemented")
     if a.run_vae or a.use_film or a.scaling_frame or a.scaling_feature or a.scaling_dim:
         bad.append("only --scaling_global is implemented among the scaling / VAE / FiLM options")
@@ -121,9 +129,10 @@ def run(a, log=print) -> dict:
     torch.manual_seed(rank)                                    # train.py:332 (crop positions and t / noise draws differ per rank)
     enc_ratios = tuple(a.enc_ratios) if a.enc_ratios else (8, 5, 4, 2)
     mc = CodecConfig(rep_dims=a.rep_dims, n_filters=a.n_filters, n_residual_layers=a.n_residual_layers, lstm=a.lstm, enc_ratios=enc_ratios,
-                     quantization=False)
+                     quantization=False, final_activation=a.final_activation)                  # train.py:340-343
     cc = CodecConfig(rep_dims=a.rep_dims, n_filters=a.n_filters, n_residual_layers=a.n_residual_layers, lstm=a.lstm,
-                     enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=a.cond_bandwidth)   # `ratios=` is ignored by the reference
+                     enc_ratios=(8, 5, 4, 2), quantization=bool(a.cond_quantization), bandwidth=a.cond_bandwidth,
+                     final_activation=a.final_activation)   # train.py:355; `ratios=` is ignored by the reference
     u = UnetConfig(dim=a.diff_dims, upsampling_ratios=tuple(a.upsampling_ratios) if a.upsampling_ratios else None,
                    unet_scale_cond=a.unet_scale_cond, unet_scale_x=a.unet_scale_x)
     sd_main = checkpoint.read_amlt(a.finetune_model + ".amlt")

@@ -256,3 +256,35 @@ def test_cli_batches_in_flight_round_robin(tmp_path, monkeypatch):
         y = wavfile.read(str(outd / n))[1]; x = wavfile.read(str(ind / n))[1]
         r = float(np.abs(y).max() / np.abs(x).max())
         assert abs(r - 1.0) < 1e-5 or abs(r - 2.0) < 1e-5
+
+
+def test_wav_header_reads_every_container_without_touching_samples(tmp_path):
+    """sample.wav_header parses the RIFF chunks itself (scipy's mmap read refuses 24-bit PCM and one such file aborted
+    the run on every rank): 16-bit, 24-bit, 32-bit float, stereo, an odd-sized extra chunk in front of 'data', and a 44.1 kHz
+    file whose 16 kHz length must be the resampler's own (ldc_resample_out_len = ceil(16000 T / sr))."""
+    import struct
+    from scipy.io import wavfile
+    from ladiffcodec_amd import sample as cli
+    rng = np.random.default_rng(0)
+    wavfile.write(tmp_path / "a16.wav", 16000, (rng.standard_normal(5000) * 3000).astype(np.int16))
+    assert cli.wav_header(str(tmp_path / "a16.wav")) == (1, 5000, 16000)
+    wavfile.write(tmp_path / "f32.wav", 16000, rng.standard_normal((4000, 2)).astype(np.float32))
+    assert cli.wav_header(str(tmp_path / "f32.wav")) == (2, 4000, 16000)
+    wavfile.write(tmp_path / "a44.wav", 44100, (rng.standard_normal(44100) * 3000).astype(np.int16))
+    assert cli.wav_header(str(tmp_path / "a44.wav")) == (1, 16000, 44100)
+    wavfile.write(tmp_path / "b44.wav", 44100, (rng.standard_normal(44101) * 3000).astype(np.int16))
+    assert cli.wav_header(str(tmp_path / "b44.wav")) == (1, -(-16000 * 44101 // 44100), 44100)
+    # 24-bit PCM, hand-written, with a 'LIST' chunk of odd size before 'data'
+    n, ch = 3001, 2
+    data = rng.integers(0, 256, n * ch * 3, dtype=np.uint8).tobytes()
+    extra = b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\0"
+    fmt = b"fmt " + struct.pack("<IHHIIHH", 16, 1, ch, 16000, 16000 * ch * 3, ch * 3, 24)
+    body = b"WAVE" + fmt + extra + b"data" + struct.pack("<I", len(data)) + data
+    (tmp_path / "p24.wav").write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+    assert cli.wav_header(str(tmp_path / "p24.wav")) == (ch, n, 16000)
+    x, sr = cli.read_wav(str(tmp_path / "p24.wav"))          # the full read decodes the same file
+    assert x.shape == (ch, n) and sr == 16000
+    import pytest
+    (tmp_path / "bad.wav").write_bytes(b"not a wave file at all")
+    with pytest.raises(ValueError):
+        cli.wav_header(str(tmp_path / "bad.wav"))

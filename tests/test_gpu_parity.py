@@ -230,6 +230,36 @@ def test_error_behaviour():
     bad.close()
 
 
+@pytest.mark.parametrize("code,tag,option", [(1, "[coop_lstm]", "lstm_stream"), (2, "[gn_wait]", "fuse_gn_epi")])
+def test_device_side_failure_fallback(code, tag, option):
+    """A kernel whose bounded in-launch wait gave up raises the host-mapped flag; the next call fails with LDC_E_HIP and a
+    tagged message, and the CLI's decode_with_retry applies the matching fallback and decodes the batch again (ADVICE r3:
+    the fallback keyed on a string the message did not contain).  The flag is raised through the debug hook."""
+    from ladiffcodec_amd import sample as cli
+    from ladiffcodec_amd.model import Engine
+    mc, u, _ = CASES["r84"]
+    e = Engine(mc, u, COND_CFG, dtype="f32")
+    e.load_state_dict(L.MODEL_MAIN, main_sd_np("r84"))
+    e.load_state_dict(L.MODEL_COND, cond_sd_np())
+    e.finalize(strict=True)
+    wav = torch.from_numpy(synth.synthetic_wav(2, 5120, seed=5)).cuda()
+    ref = e.decode(wav, 2, noise=None, per_item=True).cpu()
+    e.reseed(0)
+    e.debug_raise_failure(code)
+    with pytest.raises(L.LdcError, match="device-side failure") as ei:
+        e.decode(wav, 2, noise=None, per_item=True)
+    assert ei.value.code == L.E_HIP and tag in str(ei.value)
+    # the flag was consumed by that call; raise it again and let the CLI helper recover
+    e.debug_raise_failure(code)
+    calls = []
+    real = e.set_option
+    e.set_option = lambda n, v: (calls.append((n, v)), real(n, v))[1]
+    out = cli.decode_with_retry(e, wav, 2, None, True).cpu()
+    assert calls == [(option, 1 if option == "lstm_stream" else 0)]
+    assert bool(torch.isfinite(out).all()) and out.shape == ref.shape
+    e.close()
+
+
 def test_cli_synthesis_end_to_end(tmp_path):
     """`python -m srcs.sample`-equivalent run: .amlt checkpoints (one DDP-prefixed), wav files in a tree,
     batching by length; with --midway_t 1 the sampler draws no noise (t = 0), so the written audio must equal

@@ -440,7 +440,7 @@ def test_run_diff_training_loop_end_to_end(tmp_path):
     synth.save_amlt(cond_sd_np(), str(tmp_path / "cond" / "model_best.amlt"))
     lines = []
     a = train_loop.build_parser().parse_args([
-        "--run_diff", "--freeze_ed", "--scaling_global", "--unet_scale_cond", "--model_for_cond", str(tmp_path / "cond"),
+        "--run_diff", "--freeze_ed", "--scaling_global", "--unet_scale_cond", "--cond_quantization", "--model_for_cond", str(tmp_path / "cond"),
         "--finetune_model", str(tmp_path / "ladiff"), "--enc_ratios", "8", "4", "--upsampling_ratios", "5", "2", "--diff_dims", "32",
         "--cond_bandwidth", "3", "--data_folder_path", str(tmp_path / "libri"), "--seq_len_p_sec", "0.16", "--batch_size", "2", "--lr", "1e-3",
         "--output_dir", str(tmp_path / "out"), "--exp_name", "t", "--num_steps", "6"])

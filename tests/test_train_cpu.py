@@ -157,6 +157,14 @@ def test_train_loop_refuses_what_it_does_not_implement():
         train_loop._unsupported(p.parse_args(["--freeze_ed", "--scaling_global", "--model_for_cond", "c", "--finetune_model", "m"]))
     with pytest.raises(SystemExit, match="--use_disc"):
         train_loop._unsupported(p.parse_args(["--run_diff", "--freeze_ed", "--scaling_global", "--model_for_cond", "c", "--finetune_model", "m", "--use_disc"]))
-    train_loop._unsupported(p.parse_args(["--run_diff", "--freeze_ed", "--scaling_global", "--model_for_cond", "c", "--finetune_model", "m"]))
+    ok = ["--run_diff", "--freeze_ed", "--scaling_global", "--cond_quantization", "--model_for_cond", "c", "--finetune_model", "m"]
+    train_loop._unsupported(p.parse_args(ok))
+    # flags that change the computation and are not implemented must be refused, never ignored
+    for extra, msg in ((["--model_type", "transformer"], "--model_type transformer"), (["--unet_scale_x"], "--unet_scale_x"),
+                       (["--final_activation", "Softmax"], "--final_activation")):
+        with pytest.raises(SystemExit, match=msg):
+            train_loop._unsupported(p.parse_args(ok + extra))
+    with pytest.raises(SystemExit, match="--cond_quantization is required"):
+        train_loop._unsupported(p.parse_args([f for f in ok if f != "--cond_quantization"]))
     a = p.parse_args([])
     assert a.lr == 5e-4 and a.batch_size == 5 and a.seq_len_p_sec == 1.0 and a.diff_dims == 128 and a.output_dir == "saved_models"   # train.py:233-262
