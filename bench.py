@@ -186,13 +186,98 @@ def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, 
     os.close(result_fd)
 
 
+def seanet_flops(cc, T):
+    """algorithmic conv + LSTM-input-GEMM flops of one encode + one decode of a T-sample clip (spec.seanet_*_layers)"""
+    total, L = 0.0, T
+    for ly in spec.seanet_encoder_layers(cc):
+        if ly.kind == "conv":
+            L = L // ly.stride
+            total += 2.0 * L * ly.cin * ly.cout * ly.kernel
+        elif ly.kind == "res":
+            total += 2.0 * L * (ly.cin * ly.hidden * ly.kernel + ly.hidden * ly.cout + ly.cin * ly.cout)
+        elif ly.kind == "lstm":
+            total += 2.0 * L * ly.layers * 8 * ly.cin * ly.cin
+    for ly in spec.seanet_decoder_layers(cc):
+        if ly.kind == "conv":
+            total += 2.0 * L * ly.cin * ly.cout * ly.kernel
+        elif ly.kind == "convtr":
+            total += 2.0 * L * ly.cin * ly.cout * ly.kernel      # every input position meets every tap once
+            L = L * ly.stride
+        elif ly.kind == "res":
+            total += 2.0 * L * (ly.cin * ly.hidden * ly.kernel + ly.hidden * ly.cout + ly.cin * ly.cout)
+        elif ly.kind == "lstm":
+            total += 2.0 * L * ly.layers * 8 * ly.cin * ly.cin
+    return total
+
+
+def bench_c1(args, eng, cc, sd_cond, wav, T, rank, world, dev, result_fd):
+    """BASELINE configs[0]: EnCodec-style round trip without diffusion -- SEANet encode -> RVQ (3 kbps) -> cond-codec decode of
+    2.4 s clips (enc_ratios 8 5 4 2; model.py:223-231 + seanet.py:157-248), all exact fp32.  The reference's own case is ONE clip on
+    the CPU; B = 1 is the default here too (latency-bound: LSTM recurrences over 120 frames), --batch N gives the batched rate."""
+    B = wav.shape[0]
+
+    def step():
+        cond = eng.get_cond(wav)
+        out = eng.decode_latents(L.MODEL_COND, cond)
+        parallel.gather_results(out, world)
+        return out
+    for _ in range(max(1, args.warmup)):
+        step()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+    assert bool(torch.isfinite(out).all()) and out.shape[-1] == T
+    flops = seanet_flops(cc, T) * B
+    ach = flops * args.steps / elapsed / 1e12
+    result = {
+        "metric": "audio-sec round-tripped / wall-sec, 16kHz EnCodec encode -> RVQ 3kbps -> decode (no diffusion)",
+        "value": world * B * (T / 16000.0) * args.steps / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio)",
+        "config": {"workload": f"EnCodec 16kHz encode->RVQ->decode only (no diffusion), {B}x{T / 16000.0:.1f} s clip(s), enc_ratios 8 5 4 2, bandwidth=3",
+                   "name": "c1", "global_batch": world * B, "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                   "parallelism": f"dp{world} (utterance-sharded, no data-path collective)"},
+        "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<float> (SEANet convs, transposed convs and LSTM input GEMMs on the exact-fp32 MFMA) -- "
+                                                "whole round trip incl. the sequential LSTM recurrences and RVQ",
+                     "achieved": ach, "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS["f32"], "traffic": None,
+                     "algorithmic_gflop_per_clip": flops / B / 1e9,
+                     "note": "latency-bound at this size: four LSTM layers of 120 sequential steps and ~40 small launches per clip"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ldc_oracle as O
+        cores = host_threads()
+        torch.set_num_threads(cores)
+        a = synth.to_torch(sd_cond)
+        w = wav[:1].cpu()
+        times = []
+        with torch.no_grad():
+            for _ in range(3):
+                t1 = time.perf_counter()
+                q = O.get_cond(a, cc, w)[0]
+                O.seanet_decode(a, cc, q)
+                times.append(time.perf_counter() - t1)
+        result["cpu_baseline"] = {"value": (T / 16000.0) / min(times[1:]), "unit": "audio-s/wall-s", "cores": cores, "kind": "port",
+                                  "sample": f"1 x {T / 16000.0:.1f} s clip, fp32 oracle (encode, RVQ, decode), best of two after one warm-up ({min(times[1:]):.3f} s)"}
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
+    os.close(result_fd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c8", "c5", "c4"],
-                    help="c2 = BASELINE configs[1] (the metric's config: 3 kbps, enc_ratios 8 4, 50 steps); c3 = configs[2] per GPU "
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c8", "c5", "c4"],
+                    help="c1 = BASELINE configs[0]: EnCodec encode -> RVQ -> decode of one 2.4 s clip, no diffusion; c2 = BASELINE configs[1] (the metric's config: 3 kbps, enc_ratios 8 4, 50 steps); c3 = configs[2] per GPU "
                          "(1.5 kbps condition, 200 steps); c8 = the released checkpoints' layout (enc_ratios 8, latent L = 4800, "
                          "upsampling 5 4 2; README.md:30,35), 3 kbps, 50 steps; c5 = configs[4]: one 30 s recording as 13 chunks of "
                          "2.4 s (batch items), fp8 UNet weights; c4 = configs[3] per GPU: one optimisation step of the diffusion UNet per bench step (fp32 correctness path of the training row)")
@@ -210,9 +295,9 @@ def main():
                          "n > 1: n engines on n streams, every batch as ONE chain; steps are dealt round-robin and all K finish inside "
                          "the timed region (supplementary number, see DESIGN.md section 7)")
     args = ap.parse_args()
-    args.batch = args.batch or (13 if args.config == "c5" else 32)
+    args.batch = args.batch or (13 if args.config == "c5" else (1 if args.config == "c1" else 32))
     args.dtype = args.dtype or ("fp8" if args.config == "c5" else ("f32" if args.config == "c4" else "bf16"))
-    if args.config == "c4":
+    if args.config in ("c4", "c1"):
         args.in_flight, args.no_pipelined = 1, True
 
     # stdout carries exactly ONE line, the JSON result: RCCL prints a banner (version / hostname / library path) on
@@ -271,6 +356,12 @@ def main():
     B = args.batch
     wav = torch.from_numpy(synth.synthetic_wav(B, T, seed=1234 + rank)).to(dev)   # resident in HBM before timing
 
+    if args.config == "c1":
+        bench_c1(args, eng, cc, sd_cond, wav, T, rank, world, dev, result_fd)
+        eng.close()
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
     if args.config == "c4":
         bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, dev, result_fd)
         eng.close()

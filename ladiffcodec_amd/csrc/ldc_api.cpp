@@ -224,10 +224,13 @@ struct StepGraph {   // per batch part: hipGraph of {step_begin, unet step, p_sa
   hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr};
   hipGraphExec_t pexec[kMaxParts][2] = {};   // per-part single-stream graphs ([part][0] = K steps, [1] = one step)
   bool per_part = false;
+  std::vector<hipEvent_t> part_ev;            // per-part mode: look-ahead events [part][depth]
   uint64_t last_use = 0;
   bool any() const { return exec[0] != nullptr; }
   void destroy() {   // exec[0] aliases pexec[0][0] in per-part mode
     if (per_part) exec[0] = nullptr;
+    for (hipEvent_t e : part_ev) (void)hipEventDestroy(e);
+    part_ev.clear();
     for (auto& e : exec) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
     for (auto& pe : pexec) for (auto& e : pe) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
     per_part = false;
@@ -258,7 +261,8 @@ struct ldc_ctx {
   int split_batch = 2;
   int fp8_act = 1;              // LDC_FP8_ACT: in an fp8-weight context, tensors whose only consumer is a conv are produced in fp8 and
                                 // that conv runs fp8 x fp8 on the block-scaled MFMA (0: bf16 activations x fp8 weights everywhere)
-  int part_graphs = 0;          // LDC_PART_GRAPHS=1: one single-stream graph per batch part instead of one fork/join graph (host time 142 -> 76 ms per decode, decode 161 -> 163 ms: GPU-bound either way, so off)
+  int part_graphs = 1;          // one single-stream graph per batch part, replays interleaved behind a bounded look-ahead: recorded-AQL replay path,
+                                // 3 ms of host time inside hipGraphLaunch per decode instead of 145 (LDC_PART_GRAPHS=0: one fork/join graph, node-by-node path)
   double host_graph_ms = 0, host_wait_ms = 0;   // host time inside hipGraphLaunch / waiting for the look-ahead window (ldc_host_stats)
   long long host_graph_launches = 0;
   hipStream_t side_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
@@ -1032,7 +1036,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->coop_resident[0] = lstm_coop_resident(256) ? 1 : 0;
   c->coop_resident[1] = lstm_coop_resident(512) ? 1 : 0;
   c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
-  c->part_graphs = env_int("LDC_PART_GRAPHS", 0);
+  c->part_graphs = env_int("LDC_PART_GRAPHS", 1);
   c->fp8_act = env_int("LDC_FP8_ACT", 1);
   c->graph_steps = std::max(0, env_int("LDC_GRAPH_STEPS", 0));   // 0 = by chain count (denoise_loop)
   c->plan_bytes_cap = (size_t)std::max(1, env_int("LDC_PLAN_CACHE_GB", 48)) << 30;
@@ -2265,7 +2269,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   }
   const int K = std::min(k_want, std::max(1, n_steps - 1));
   int done = 0;
-  if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K + ((par && c->part_graphs) ? 100000 : 0)) {
+  if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K + ((par && c->part_graphs && h.n == 2) ? 100000 : 0)) {
     if (sg->any()) {
       // replays of the old executable graphs may still be in flight: drain before destroying (a re-capture is one of
       // the documented places where a call waits for the device)
@@ -2275,7 +2279,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
     // first step eagerly: loads code objects / sets function attributes outside of the capture
     LDCCHK(one_step(c, h, x, noise, stride, s));
     done = 1;
-    const bool per_part = par && c->part_graphs;
+    const bool per_part = par && c->part_graphs && h.n == 2;   // (three parts on per-part graphs measured 45 % slower than the fork/join graph)
     if (per_part) {
       // ONE SINGLE-STREAM graph per batch part, captured and replayed on the part's own stream.  ROCm 7.2 replays a
       // single-stream graph from AQL packets recorded at instantiation (~0.4 ms of host time for 1 500 kernel nodes); a graph
@@ -2350,20 +2354,34 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   };
   int i = done;
   if (sg->per_part) {
+    // One single-stream graph per part, replayed from recorded AQL packets.  The parts' replays are issued INTERLEAVED (graph j
+    // of every part before graph j + 1 of any) behind a bounded look-ahead per part: through round 3 all of part 0's replays
+    // were issued first, hipGraphLaunch blocked on the full hardware queue for most of the decode (76-105 ms "inside
+    // hipGraphLaunch") and part 1 started late.  Waiting happens on events of this context, outside hipGraphLaunch.
     LDCCHK(fork_parts(c, h, s));
-    for (int k = 0; k < h.n; ++k) {
-      hipStream_t sk = k == 0 ? s : c->aux_stream[k];
-      int j = done;
-      auto launch_k = [&](hipGraphExec_t ge) -> hipError_t {
+    const int depth = std::max(1, std::min(c->flow_depth > 0 ? c->flow_depth : 3, 3));
+    std::vector<hipEvent_t>& evs = sg->part_ev;
+    const int n_big = (n_steps - done) / K, n_rep = n_big + ((n_steps - done) - n_big * K);
+    while ((int)evs.size() < h.n * depth) {
+      hipEvent_t e = nullptr;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      evs.push_back(e);
+    }
+    for (int j = 0; j < n_rep; ++j)
+      for (int k = 0; k < h.n; ++k) {
+        hipStream_t sk = k == 0 ? s : c->aux_stream[k];
+        hipEvent_t ev = evs[(size_t)k * depth + j % depth];
+        if (j >= depth) {
+          const auto t0 = std::chrono::steady_clock::now();
+          HIPCHK(hipEventSynchronize(ev));   // replay j - depth of this part has finished
+          c->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
         const auto t0 = std::chrono::steady_clock::now();
-        const hipError_t e = hipGraphLaunch(ge, sk);
+        HIPCHK(hipGraphLaunch(sg->pexec[k][(j < n_big || K == 1) ? 0 : 1], sk));
         c->host_graph_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ++c->host_graph_launches;
-        return e;
-      };
-      for (; j + K <= n_steps; j += K) HIPCHK(launch_k(sg->pexec[k][0]));
-      for (; j < n_steps; ++j) HIPCHK(launch_k(sg->pexec[k][K == 1 ? 0 : 1]));
-    }
+        HIPCHK(hipEventRecord(ev, sk));
+      }
     LDCCHK(join_parts(c, h, s));
     return LDC_OK;
   }

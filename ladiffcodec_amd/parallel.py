@@ -98,20 +98,23 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
-def allreduce_gradients(flat, average: bool = True):
+def allreduce_gradients(flat, average: bool = True, force_collective: bool = False):
     """Data-parallel gradient reduction of the training step: ONE flat fp32 buffer per step
     (542 MB for the diff_dims = 256 model) instead of the reference's per-parameter all-reduce (srcs/encodec/distrib.py:
     sync_grad).  On RCCL the sum is a reduce-scatter followed by an all-gather: xGMI is point-to-point, and the two halves keep
     all seven links of every GPU busy with 1/world-sized shards (each rank can also run its optimiser step on its own shard
-    between the two); gloo (CPU tests) has no reduce-scatter and takes the plain all-reduce.  In place; returns `flat`."""
+    between the two); gloo (CPU tests) has no reduce-scatter and takes the plain all-reduce.  In place; returns `flat`.
+    The buffer is padded so that every rank's shard is a whole number of 16-byte pieces.  `force_collective` runs the collectives
+    in a one-rank group too (the GPU suite brings up a world-size-1 RCCL group so that this exact code path has executed on
+    the hardware before an 8-GPU node sees it)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return flat
     world = dist.get_world_size()
     if dist.get_backend() == "nccl":
         n = flat.numel()
-        pad = (-n) % world
+        pad = (-n) % (world * 4)
         buf = torch.cat([flat, flat.new_zeros(pad)]) if pad else flat
         shard = torch.empty(buf.numel() // world, dtype=buf.dtype, device=buf.device)
         dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM)

@@ -100,6 +100,29 @@ def test_codec_encode_rvq_decode_golden():
     assert rel(e.rvq_decode(cu(g["codes"])).cpu().numpy(), g["quantized"]) < 1e-6
 
 
+def test_codec_round_trip_full_size_c1():
+    """BASELINE configs[0] at its full size: encode -> RVQ -> cond-codec decode of one 2.4 s clip (F = 120 frames) against the
+    REFERENCE (tests/golden/codec_c1_full.npz, tools/gen_golden_c1.py; model.py:223-231, seanet.py:157-248).  The 0.4 s fixture
+    never ran the decoder's cooperative LSTM (H = 512) over 120 frames or the k16 s8 transposed conv at that length."""
+    g = load_golden("codec_c1_full")
+    e = engine("r84", "f32")
+    _, Tn, seed_in = (int(v) for v in g["meta"])
+    wav = (torch.from_numpy(synth.synthetic_wav(1, Tn, seed=seed_in)) * 0.5).cuda()
+    z = e.encode(L.MODEL_COND, wav)
+    assert rel(z.cpu().numpy(), g["z"]) < 1e-4
+    cond, codes = e.get_cond(wav, return_codes=True)
+    assert tuple(codes.shape) == g["codes"].shape and np.array_equal(codes.cpu().numpy(), g["codes"]), "RVQ codes must be bit-exact"
+    assert rel(cond.cpu().numpy(), g["quantized"]) < 1e-5
+    dec = e.decode_latents(L.MODEL_COND, cu(g["quantized"]))
+    assert dec.shape[-1] == Tn and rel(dec.cpu().numpy(), g["decoded"]) < 1e-4
+    # and the streamed LSTM kernel (the fallback of the cooperative one) at the same length
+    e.set_option("lstm_stream", 1)
+    try:
+        assert rel(e.decode_latents(L.MODEL_COND, cu(g["quantized"])).cpu().numpy(), g["decoded"]) < 1e-4
+    finally:
+        e.set_option("lstm_stream", 0)
+
+
 def test_rvq_ties_take_first_index():
     """Duplicate code vectors: the reference's argmax returns the first maximum (core_vq.py:181)."""
     e = engine("r84", "f32")
@@ -450,3 +473,43 @@ def test_conv_fp8_x_fp8_mfma_against_bf16_path_on_the_e4m3_grid():
             assert m.value > 0.1 and d.value <= m.value / 128, (Lx, c1, c2, co, k, B, d.value, m.value)
             # GroupNorm sums agree to 1e-4; a column MAXIMUM is one of the (bf16-rounded) outputs and may differ by their one ulp
             assert r.value < (1.0 / 128 if k == 1 else 1e-4), ("fused statistics", Lx, c1, c2, co, k, B, r.value)
+
+
+def test_rccl_world_size_one_group_runs_every_collective_path():
+    """The RCCL code paths of parallel.py -- flat checkpoint broadcast, result all_gather, and the training row's
+    reduce_scatter + all_gather of a flat gradient buffer whose length needs padding -- on a world-size-1 `nccl` group on the
+    GPU: no 8-GPU node has been available to any round, so this is the first time these exact calls run on the hardware
+    (the 2-rank semantics are covered under gloo in tests/test_cli_and_parallel_cpu.py).  Own process: a failed RCCL
+    bring-up must not take the suite's CUDA context with it."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        import numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, os.getcwd())
+        from ladiffcodec_amd import parallel
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+        rank, local_rank, world = parallel.init_process_group("nccl")
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        rng = np.random.default_rng(0)
+        layout = [("a.weight", (7, 5, 3)), ("a.bias", (7,)), ("scalar", ())]
+        sd = {k: rng.standard_normal(s).astype(np.float32) for k, s in layout}
+        out = parallel.broadcast_state_dict(sd, layout, device=dev)
+        assert all(np.array_equal(out[k], sd[k]) for k, _ in layout)
+        x = torch.randn(3, 1, 1000, device=dev)
+        got = parallel.gather_results(x, world)
+        assert len(got) == 1 and torch.equal(got[0], x)
+        g = torch.randn(1003, device=dev)                 # 1003 % 4 != 0: the padded reduce_scatter / all_gather path
+        ref = g.clone()
+        parallel.allreduce_gradients(g, average=True, force_collective=True)
+        assert torch.equal(g, ref), float((g - ref).abs().max())
+        assert abs(parallel.max_over_ranks(3.25, device=dev) - 3.25) < 1e-12
+        dist.barrier()
+        dist.destroy_process_group()
+        print("RCCL_OK")
+    """)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

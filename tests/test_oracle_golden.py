@@ -68,6 +68,21 @@ def test_codec_encode_rvq_decode():
     assert rel_err(dec.numpy(), g["decoded"]) < TOL
 
 
+def test_codec_round_trip_full_size_c1():
+    """BASELINE configs[0] at its full size (one 2.4 s clip, enc_ratios 8 5 4 2, bandwidth 3): the oracle against the REFERENCE's
+    encoder -> RVQ -> decoder (tests/golden/codec_c1_full.npz from tools/gen_golden_c1.py; model.py:223-231, seanet.py:66-248)."""
+    g = load_golden("codec_c1_full")
+    sd = synth.to_torch(cond_sd_np())
+    seed_w, Tn, seed_in = (int(v) for v in g["meta"])
+    wav = torch.from_numpy(synth.synthetic_wav(1, Tn, seed=seed_in)) * 0.5
+    q, codes, margins, z = O.get_cond(sd, COND_CFG, wav)
+    assert rel_err(z.numpy(), g["z"]) < TOL
+    safe = margins.numpy() > 1e-3
+    assert safe.mean() > 0.95 and np.array_equal(codes.numpy()[safe], g["codes"][safe])
+    dec = O.seanet_decode(sd, COND_CFG, T(g["quantized"]))
+    assert dec.shape[-1] == Tn and rel_err(dec.numpy(), g["decoded"]) < TOL
+
+
 @pytest.mark.parametrize("tag", ["r84", "r8"])
 def test_unet_step_and_chain(tag):
     g = load_golden("ladiff_" + tag)
