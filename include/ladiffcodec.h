@@ -338,6 +338,14 @@ int ldc_host_stats(ldc_ctx* ctx, int reset, double* graph_launch_ms, double* loo
  * clock at its first and last kernel.  ldc_timeline_read: ticks[2j], ticks[2j+1] = begin / end of step j of `part`. */
 int ldc_timeline_enable(ldc_ctx* ctx, int on);
 int ldc_timeline_read(ldc_ctx* ctx, int part, int n, uint64_t* ticks);
+/* Per-kernel durations of the TIMED mode (hipGraph replay, batch parts on their own streams): with stamps enabled every launch of
+ * the pipelined conv kernel records its earliest workgroup start and latest workgroup end (100 MHz clock) in a slot of its own per
+ * denoise step.  enable / disable rebuilds the plans; reset re-arms the buffers; read returns plan `idx` (creation order = batch
+ * part) as ticks[n_steps][n_ops][2] (0 where the op is not a pipelined conv) with the ops' descriptions and LDC_CLASS_* codes.
+ * ticks == NULL: only *n_ops is returned. */
+int ldc_kstamps_enable(ldc_ctx* ctx, int on);
+int ldc_kstamps_reset(ldc_ctx* ctx);
+int ldc_kstamps_read(ldc_ctx* ctx, int idx, int n_steps, int* n_ops, uint64_t* ticks, char* infos, int info_cap, int* classes);
 /* Tuning aid: times the GroupNorm-apply kernel on [B,L,C] (random data, fixed statistics). */
 int ldc_gn_microbench(ldc_ctx* ctx, int dtype, int B, int L, int C, int with_residual, int iters, double* ms_per_launch);
 /* Tuning aid: times `iters` launches of one conv-GEMM (random weights/inputs) of the given shape with

@@ -72,6 +72,12 @@ struct ConvKArgs {
   int io_sc1;              // bit 0: the output is read inside this launch (write-through stores); bit 1: the residual was
                            // produced inside this launch (agent-scope loads); bit 2: so was the input window (x1)
   unsigned* fail_flag;     // host-mapped word raised when a bounded spin gives up (the output is then wrong, never a hang)
+  // Timed-mode stamps (ldc_kstamps_enable): every launch records the earliest workgroup start and the latest workgroup end on
+  // the 100 MHz wall clock in its own slot kst[(step index & 2047) * kst_stride + {0, 1}] (atomicMin of t / of ~t), so that
+  // per-kernel durations exist for the graph-replayed, two-stream mode the bench times (rocprofv3 serialises the streams)
+  unsigned long long* kst;
+  const int* kst_step;     // the part's device step state: [1] = iteration index
+  int kst_stride;
   char* y2;                // folded 1x1 conv (ConvLayer::wtaps): second output [rows][n], or null
   const float* bias2;
   int wtaps;               // weight slabs per channel chunk in the packed image (taps, or taps + 1 with the folded conv)

@@ -401,6 +401,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   if (c.bm_out) { c.bm_out[0] = 0; c.bm_out[1] = 0; c.bm_out[2] = 1; }
   a.gn_part = (char*)c.gn_part; a.gn_mslots = c.gn_mslots; a.gn_gamma = c.gn_gamma; a.gn_beta = c.gn_beta; a.gn_ss = c.gn_ss; a.gn_out = c.gn_out; a.io_sc1 = c.io_sc1;
   a.fail_flag = c.fail_flag;
+  a.kst = c.kst; a.kst_step = c.kst_step; a.kst_stride = c.kst_stride;
   a.y2 = (char*)c.y2; a.bias2 = ly.bias2; a.wtaps = ly.wtaps ? ly.wtaps : ly.taps;
   if ((c.y2 != nullptr) != (ly.wtaps != 0)) return hipErrorInvalidValue;   // a folded layer always writes its second output
   a.wscale = (ly.w8 || ly.dt == DT_FP8) ? ly.wscale : nullptr; a.w8 = ly.w8;

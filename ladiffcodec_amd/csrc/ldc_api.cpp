@@ -180,6 +180,7 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
   uint64_t last_use = 0;        // LRU tick (ldc_ctx::use_tick)
   long long sk_floats = 0;      // split-K workspace this plan's convs need (sized by a dry run of the launchers)
   long long sk_need_max = 0;
+  unsigned long long* kst = nullptr;   // [2048 steps][kKstOps][2] timed-mode stamps of the step's conv launches (ldc_kstamps_enable)
   size_t part_bytes = 0;        // granule regions of the fused GroupNorm applies (sized by the same dry run)
   size_t part_need = 0;
   void* arena_base = nullptr;
@@ -215,6 +216,8 @@ struct Halves {                // (the name dates from the two-way split; n part
   Plan* p[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int b0[kMaxParts] = {0, 0, 0, 0};   // first item of each part
 };
+
+static constexpr int kKstOps = 256;   // stamp slots per step (one per op of the step list)
 
 struct StepGraph {   // per batch part: hipGraph of {step_begin, unet step, p_sample_update, step_advance}
   int B = 0, L = 0, F = 0, n = 0;
@@ -302,6 +305,7 @@ struct ldc_ctx {
   // device-side timeline of the timed mode (ldc_timeline_enable): [kMaxParts][2048][begin, end] in 100 MHz ticks
   unsigned long long* tl_buf = nullptr;
   bool timeline = false;
+  bool kstamps = false;         // ldc_kstamps_enable: per-launch device stamps of the pipelined conv kernel (plans carry the buffers)
   // scratch arena for codec stages and boundary buffers
   char* scratch = nullptr;
   size_t scratch_cap = 0;
@@ -1638,6 +1642,9 @@ struct PlanBuilder {
     cc.B = B; cc.L_in = L_in; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.residual = residual; cc.y_ld = ly.n;
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
     cc.y2 = y2_next; y2_next = nullptr;
+    if (pl->kst && pl->step_ops.size() < (size_t)kKstOps) {
+      cc.kst = pl->kst + pl->step_ops.size() * 2; cc.kst_stride = kKstOps * 2; cc.kst_step = pl->step_state;
+    }
     if (ge && ge->part) {
       cc.gn_groups = c->unet.groups;
       cc.gn_part = ge->part; cc.gn_mslots = ge->mslots; cc.gn_gamma = ge->gamma; cc.gn_beta = ge->beta; cc.gn_ss = ge->ss; cc.gn_out = ge->out;
@@ -1839,6 +1846,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   pb.sk_part = (float*)ar.alloc((size_t)std::max<long long>(pb.sk_part_cap, 4) * 4);
   pl->maxabs = (float*)ar.alloc((size_t)B * 4);
   pl->step_state = (int*)ar.alloc(64);
+  pl->kst = c->kstamps ? (unsigned long long*)ar.alloc((size_t)2048 * kKstOps * 2 * 8) : nullptr;
   pl->cur_ss = (float*)ar.alloc((size_t)std::max(1, u.ss_stride) * 4);
   pl->x_cl = ar.alloc((size_t)B * L * Cx * es);
   pl->eps_cl = ar.alloc((size_t)B * L * Cx * es);
@@ -3096,6 +3104,52 @@ extern "C" int ldc_timeline_enable(ldc_ctx* c, int on) {
   }
   if (on) HIPCHK(hipMemset(c->tl_buf, 0, (size_t)kMaxParts * 2048 * 2 * sizeof(unsigned long long)));
   c->timeline = on != 0;
+  return LDC_OK;
+}
+
+// Per-launch stamps of the pipelined conv kernel in the timed mode: plans are rebuilt with (or without) a stamp buffer.
+extern "C" int ldc_kstamps_enable(ldc_ctx* c, int on) {
+  if (!c) return fail(LDC_E_INVALID, "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  drop_plans(c);
+  c->kstamps = on != 0;
+  return LDC_OK;
+}
+// re-arm the stamp buffers of every cached plan (all-ones: both fields are kept as minima)
+extern "C" int ldc_kstamps_reset(ldc_ctx* c) {
+  if (!c) return fail(LDC_E_INVALID, "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipDeviceSynchronize());
+  for (auto& p : c->plans)
+    if (p->kst) HIPCHK(hipMemset(p->kst, 0xff, (size_t)2048 * kKstOps * 2 * 8));
+  return LDC_OK;
+}
+// Plan `idx` (in creation order: the batch parts of the last shape decoded).  ticks: [n_steps][n_ops][2] begin / end in 100 MHz ticks
+// (0 / 0 where the op is not a pipelined conv); infos: n_ops strings of `info_cap` bytes (the op descriptions of the profile dump);
+// classes: n_ops LDC_CLASS_* codes.  Returns the number of ops of a step through n_ops when ticks == NULL.
+extern "C" int ldc_kstamps_read(ldc_ctx* c, int idx, int n_steps, int* n_ops, uint64_t* ticks, char* infos, int info_cap, int* classes) {
+  if (!c || idx < 0 || idx >= (int)c->plans.size() || !n_ops) return fail(LDC_E_INVALID, "bad arguments");
+  Plan* pl = c->plans[idx].get();
+  if (!pl->kst) return fail(LDC_E_STATE, "ldc_kstamps_enable has not been called");
+  const int nops = (int)std::min<size_t>(pl->step_ops.size(), kKstOps);
+  *n_ops = nops;
+  if (!ticks) return LDC_OK;
+  if (n_steps < 1 || n_steps > 2048) return fail(LDC_E_INVALID, "n_steps must be in [1, 2048]");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<unsigned long long> h((size_t)n_steps * kKstOps * 2);
+  HIPCHK(hipMemcpy(h.data(), pl->kst, h.size() * 8, hipMemcpyDeviceToHost));
+  for (int j = 0; j < n_steps; ++j)
+    for (int o = 0; o < nops; ++o) {
+      const unsigned long long b = h[((size_t)j * kKstOps + o) * 2], e = h[((size_t)j * kKstOps + o) * 2 + 1];
+      const bool set = b != ~0ull && e != ~0ull && ~e >= b;
+      ticks[((size_t)j * nops + o) * 2] = set ? b : 0;
+      ticks[((size_t)j * nops + o) * 2 + 1] = set ? ~e : 0;
+    }
+  for (int o = 0; o < nops; ++o) {
+    if (infos && info_cap > 0) snprintf(infos + (size_t)o * info_cap, info_cap, "%s", pl->step_info[o].c_str());
+    if (classes) classes[o] = pl->step_class[o];
+  }
   return LDC_OK;
 }
 

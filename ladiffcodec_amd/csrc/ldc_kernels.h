@@ -92,6 +92,9 @@ struct ConvCall {
   int gn_out = 0;                   // bit 2: tanh after the residual add
   int io_sc1 = 0;                   // in-launch producer / consumer hints (ConvKArgs::io_sc1)
   unsigned* fail_flag = nullptr;    // host-mapped word raised when the bounded in-launch wait gives up
+  unsigned long long* kst = nullptr;   // timed-mode stamps of this launch (ConvKArgs::kst), pipelined kernel only
+  const int* kst_step = nullptr;
+  int kst_stride = 0;
   const ConvTune* tune = nullptr;   // null: defaults
   long long* sk_need = nullptr;     // dry run: no launch, *sk_need = split-K workspace floats this call would use
   int* bm_out = nullptr;            // dry run (with sk_need): int[2] = rows per tile of the pipelined kernel (0 when the generic kernel would run), wave rows WM, split-K factor

@@ -329,6 +329,26 @@ class Engine:
         t0 = min(float(a[a > 0].min()) for a in out if (a > 0).any())
         return [(a - t0) / 100.0 for a in out]      # 100 MHz ticks -> us
 
+    def kstamps_enable(self, on: bool):
+        L.check(self.lib.ldc_kstamps_enable(self._ctx, int(on)))
+
+    def kstamps_reset(self):
+        L.check(self.lib.ldc_kstamps_reset(self._ctx))
+
+    def kstamps(self, part: int, n_steps: int):
+        """Timed-mode stamps of batch part `part` after a decode with kstamps_enable(True): (ticks [n_steps, n_ops, 2] in
+        microseconds on the device's 100 MHz clock (0 where the op is not a pipelined conv), op descriptions, class codes)."""
+        n = C.c_int()
+        L.check(self.lib.ldc_kstamps_read(self._ctx, part, n_steps, C.byref(n), None, None, 0, None))
+        nops, cap = n.value, 96
+        ticks = (C.c_uint64 * (n_steps * nops * 2))()
+        infos = C.create_string_buffer(nops * cap)
+        classes = (C.c_int * nops)()
+        L.check(self.lib.ldc_kstamps_read(self._ctx, part, n_steps, C.byref(n), ticks, infos, cap, classes))
+        t = np.array(ticks, dtype=np.float64).reshape(n_steps, nops, 2) / 100.0
+        names = [infos.raw[o * cap:(o + 1) * cap].split(b"\0", 1)[0].decode() for o in range(nops)]
+        return t, names, list(classes)
+
     def timeline_enable(self, on: bool):
         L.check(self.lib.ldc_timeline_enable(self._ctx, int(on)))
 
