@@ -643,7 +643,11 @@ __device__ __forceinline__ void epilogue_rows_second(const ConvKArgs& a, f32x16 
     const int row = sw * RPS + rsub;
     const int m = m_wave0 + row;
     const uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * PITCH + chunk * 16);
-    if (m < M && col < a.n) *reinterpret_cast<uint4*>(a.y2 + ((size_t)m * a.n + col) * sizeof(T)) = v;
+    if (m < M && col < a.n) {
+      char* dst = a.y2 + ((size_t)m * a.n + col) * sizeof(T);
+      if (a.io_sc1 & 1) store16_wt(dst, v);   // read by the second conv of a chained pair: write-through (drained by the caller)
+      else *reinterpret_cast<uint4*>(dst) = v;
+    }
   }
 }
 
@@ -673,5 +677,8 @@ bool conv_fast_eligible(const ConvLayer& ly);
 hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, hipStream_t s, bool* launched);
 hipError_t launch_conv_fast_fp8(const ConvLayer& ly, const ConvKArgs& a_in, int M, int span_rows, hipStream_t s, bool* launched);
 hipError_t launch_conv_fast_bf16w8(const ConvLayer& ly, const ConvKArgs& a_in, int M, int span_rows, hipStream_t s, bool* launched);
+// two dependent ResnetBlock convs as one launch (conv_fast.inc: conv_fast_pair_kernel); bf16 / f32 weights only
+hipError_t launch_conv_fast_pair(const ConvLayer& ly0, const ConvKArgs& a0, int M0, int span0, const ConvLayer& ly1, const ConvKArgs& a1, int M1,
+                                 int span1, unsigned* pair_done, int pair_done_cap, hipStream_t s, bool* launched);
 
 }  // namespace ldc

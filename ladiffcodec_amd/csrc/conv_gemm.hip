@@ -382,8 +382,8 @@ static hipError_t launch_cfg(const ConvKArgs& a, int M, size_t lds, hipStream_t 
   return hipGetLastError();
 }
 
-hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
-  ConvKArgs a;
+// kernel arguments of one conv call; *M_out = GEMM rows (0: nothing to do), *span_out = input rows a 128-row tile can touch
+static hipError_t conv_kargs(const ConvLayer& ly, const ConvCall& c, ConvKArgs& a, int* M_out, int* span_out) {
   a.x1 = (const char*)c.x1; a.x2 = (const char*)c.x2; a.w = (const char*)ly.w; a.bias = ly.bias;
   a.y = (char*)c.y; a.residual = (const char*)c.residual;
   a.C1 = ly.cin1; a.C2 = ly.cin2; a.n = ly.n; a.n_pad = ly.n_pad;
@@ -415,6 +415,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   if (c.gn_part && c.gn_groups > 0) { a.gn_groups = c.gn_groups; a.gn_cpg = ly.n / c.gn_groups; }   // fused apply: no gn_sum
   const int BM = 128;
   const int M = c.B * c.L_rows;
+  *M_out = M; *span_out = 0;
   if (M <= 0) return hipSuccess;
   // reflect reach beyond the clamped window ends
   a.reflect_back = 0; a.reflect_fwd = 0;
@@ -433,6 +434,15 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     seam_slack = ((BM + c.L_rows - 1) / c.L_rows + 1) * leftover;
   }
   span += seam_slack;
+  *span_out = span;
+  return hipSuccess;
+}
+
+hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
+  ConvKArgs a;
+  int M = 0, span = 0;
+  hipError_t e0 = conv_kargs(ly, c, a, &M, &span);
+  if (e0 != hipSuccess || M <= 0) return e0;
   if (!(c.tune && c.tune->force_generic) && conv_fast_eligible(ly)) {
     bool launched = false;
     hipError_t e = launch_conv_fast(ly, a, M, span, s, &launched);
@@ -461,6 +471,27 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     if (bn == 64) return launch_cfg<__bf16, 2, 2, 2, 1>(a, M, lds, s);
     return launch_cfg<__bf16, 4, 1, 1, 1>(a, M, lds, s);
   }
+}
+
+// block1's conv [+ folded res_conv] and block2's conv of a ResnetBlock as ONE launch when both run on the pipelined kernel with the same
+// tile shape (conv_fast.inc: conv_fast_pair_kernel); otherwise one after the other
+hipError_t launch_conv_pair(const ConvLayer& ly0, const ConvCall& c0, const ConvLayer& ly1, const ConvCall& c1, unsigned* pair_done,
+                            int pair_done_cap, hipStream_t s) {
+  if (pair_done && !(c0.tune && c0.tune->force_generic) && !c0.sk_need && !c1.sk_need) {
+    ConvKArgs a0, a1;
+    int M0 = 0, M1 = 0, sp0 = 0, sp1 = 0;
+    hipError_t e = conv_kargs(ly0, c0, a0, &M0, &sp0);
+    if (e == hipSuccess) e = conv_kargs(ly1, c1, a1, &M1, &sp1);
+    if (e != hipSuccess) return e;
+    if (M0 > 0 && M1 > 0) {
+      bool launched = false;
+      e = launch_conv_fast_pair(ly0, a0, M0, sp0, ly1, a1, M1, sp1, pair_done, pair_done_cap, s, &launched);
+      if (e != hipSuccess || launched) return e;
+    }
+  }
+  hipError_t e = launch_conv(ly0, c0, s);
+  if (e != hipSuccess) return e;
+  return launch_conv(ly1, c1, s);
 }
 
 }  // namespace ldc

@@ -285,6 +285,8 @@ struct ldc_ctx {
   int flow_depth = 8;           // LDC_FLOW_DEPTH (0 = unbounded look-ahead)
   int fuse_gn_stats = 1;
   int gn_epi_min_l = 0;         // LDC_GN_EPI_MINL: shortest level (positions per item) whose ResnetBlocks fuse the GroupNorm apply
+  int chain_convs = 0;          // block1's and block2's convs of a ResnetBlock as ONE launch (conv_fast_pair_kernel; LDC_CHAIN=1 / option "chain_convs").
+                                // Off: measured 3 % slower than two launches (157.3 vs 152.2 ms per decode, profiles/r04_fusion_experiments.md)
   int fold_res = 1;             // res_conv as a second accumulator set of block1's conv (LDC_NO_RES_FOLD / option "fold_res")
   int fuse_gn_epi = 1;          // GroupNorm APPLY in the producing conv's epilogue behind an in-launch per-item wait (LDC_NO_GN_EPI / option "fuse_gn_epi")
   // knobs read from the environment once, at ldc_create (per context, not process-global)
@@ -1018,6 +1020,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
   c->gn_epi_min_l = env_int("LDC_GN_EPI_MINL", c->gn_epi_min_l);
   c->fold_res = getenv("LDC_NO_RES_FOLD") ? 0 : 1;
+  c->chain_convs = env_int("LDC_CHAIN", c->chain_convs);
   c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
   c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
   c->fuse_attn_tail = getenv("LDC_NO_TAIL_FUSE") ? 0 : 1;
@@ -1157,6 +1160,10 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->fuse_gn_epi) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fuse_gn_epi = value ? 1 : 0; }
     return LDC_OK;
   }
+  if (n == "chain_convs") {
+    if ((value ? 1 : 0) != c->chain_convs) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->chain_convs = value ? 1 : 0; }
+    return LDC_OK;
+  }
   if (n == "fold_res") {
     if ((value ? 1 : 0) != c->fold_res) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fold_res = value ? 1 : 0; }
     return LDC_OK;
@@ -1166,7 +1173,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fold_res | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fold_res | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // debug hook: raise the device-side failure flag as a kernel that gave up would (1 = cooperative LSTM, 2 = fused GroupNorm wait)
@@ -1606,6 +1613,8 @@ struct PlanBuilder {
   }
   std::string info;   // description of the next op added
   void* y2_next = nullptr;   // second output of the next conv added (a layer with a folded 1x1 conv)
+  struct Captured { const ConvLayer* ly = nullptr; ConvCall cc; double flops = 0, bytes = 0; std::string info; };
+  Captured* capture = nullptr;   // when set, conv() hands the call back instead of adding an op (chained pairs)
   // fused GroupNorm apply of a conv (see ConvCall::gn_cnt)
   struct GnEpi {
     void* part = nullptr;          // granule region of this conv
@@ -1669,7 +1678,21 @@ struct PlanBuilder {
     }
     const double cbytes = ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n * (((ge && ge->part && residual) ? 2 : 1) + (ly.wtaps ? 1 : 0))) * es + (double)conv_packed_weight_bytes(ly);
     pl->conv_bytes += cbytes;
+    if (capture) {
+      capture->ly = lp; capture->cc = cc; capture->flops = ly.flops_per_row * (double)B * L_out; capture->bytes = cbytes; capture->info = info;
+      info.clear();
+      return;
+    }
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out, LDC_CLASS_CONV, cbytes);
+  }
+  // zeroed-every-step bytes from the granule pool (nullptr while the pool is being sized)
+  void* take_raw(size_t bytes) {
+    bytes = (bytes + 63) / 64 * 64;
+    pl->part_need += bytes;
+    if (!part_pool || part_used + bytes > part_cap) return nullptr;
+    void* p = part_pool + part_used;
+    part_used += bytes;
+    return p;
   }
   float* next_stats() {
     const int g = c->unet.groups;
@@ -1725,6 +1748,41 @@ struct PlanBuilder {
     if (r.has_res) res = rr;
     const ConvLayer& c1 = folded ? r.c1r : r.c1;
     const ResnetW* rp = &r;
+    // both convs as ONE launch (conv_fast_pair_kernel): block2's tiles sit behind block1's in dispatch order and wait per M tile
+    unsigned* pair_done = nullptr;
+    const int pair_cap = rows / 64 + 2;
+    if (epi_ok && c->chain_convs && !f8 && !c->w8) {
+      unsigned* pd = (unsigned*)take_raw((size_t)pair_cap * 64);   // one 64-byte line per M-tile counter
+      if (epi1 && epi2) pair_done = pd;
+    }
+    if (pair_done) {
+      Captured k1, k2;
+      ge1.gamma = r.g1; ge1.beta = r.b1; ge1.ss = cur_ss + r.ss_off;
+      if (folded) y2_next = rr;
+      capture = &k1;
+      conv(c1, x1, x2, b, nullptr, L, L, nullptr, nullptr, 0, 0, 0, &ge1);
+      void* xn = nullptr;
+      if (ln_g && xn_out && c->fuse_ln && gn_apply_ln_fusable(r.cout)) {
+        xn = xn_fp8 ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
+        *xn_out = xn;
+      }
+      ge2.gamma = r.g2; ge2.beta = r.b2; ge2.ss = nullptr; ge2.out = out_mode & 4;
+      if (r.has_res && !folded) mark(3);
+      capture = &k2;
+      conv(r.c2, b, nullptr, out, res, L, L, nullptr, nullptr, 0, 0, 0, &ge2);
+      capture = nullptr;
+      info = k1.info + " >> " + k2.info;
+      const ConvLayer *l1 = k1.ly, *l2 = k2.ly;
+      const ConvCall cc1 = k1.cc, cc2 = k2.cc;
+      add([=](hipStream_t s) { return launch_conv_pair(*l1, cc1, *l2, cc2, pair_done, pair_cap, s); }, true, k1.flops + k2.flops, LDC_CLASS_CONV,
+          k1.bytes + k2.bytes);
+      if (xn) {
+        const int C = r.cout;
+        add([=](hipStream_t s) { return launch_ln_rows(dt, out, xn, nullptr, ln_g, rows, C, s, xn_fp8 ? 1 : 0); }, false, 0, LDC_CLASS_LAYERNORM,
+            (xn_fp8 ? 1.5 : 2.0) * rows * C * es);
+      }
+      return out;
+    }
     if (epi1) {   // block1: conv -> GroupNorm -> (scale + 1, shift) -> SiLU, one launch, one store
       ge1.gamma = r.g1; ge1.beta = r.b1; ge1.ss = cur_ss + r.ss_off;
       if (folded) y2_next = rr;

@@ -101,6 +101,11 @@ struct ConvCall {
 };
 
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
+// Two dependent convs (c1 reads c0.y as its input, optionally c0.y2 as its residual; both with the fused GroupNorm apply) as one
+// launch where the pipelined kernel allows it, else back to back.  pair_done: [pair_done_cap] counters on 64-byte lines (16 words each; one per 64 rows of c0's
+// output at least), zeroed before every launch (the step's first kernel does it).
+hipError_t launch_conv_pair(const ConvLayer& ly0, const ConvCall& c0, const ConvLayer& ly1, const ConvCall& c1, unsigned* pair_done,
+                            int pair_done_cap, hipStream_t s);
 size_t conv_packed_weight_bytes(const ConvLayer& ly);
 // host-side packers (fp32 [Cout][Cin][k] or, transposed, [Cin][Cout][k]) -> packed image in ly.dt
 void pack_conv_weights(const ConvLayer& ly, const float* w_oik, void* dst_host);
