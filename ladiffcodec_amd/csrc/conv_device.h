@@ -78,6 +78,7 @@ struct ConvKArgs {
   unsigned long long* kst;
   const int* kst_step;     // the part's device step state: [1] = iteration index
   int kst_stride;
+  const float* ln_s;       // folded PreNorm LayerNorm (ConvLayer::ln_s) or null
   char* y2;                // folded 1x1 conv (ConvLayer::wtaps): second output [rows][n], or null
   const float* bias2;
   int wtaps;               // weight slabs per channel chunk in the packed image (taps, or taps + 1 with the folded conv)

@@ -402,6 +402,7 @@ static hipError_t conv_kargs(const ConvLayer& ly, const ConvCall& c, ConvKArgs& 
   a.gn_part = (char*)c.gn_part; a.gn_mslots = c.gn_mslots; a.gn_gamma = c.gn_gamma; a.gn_beta = c.gn_beta; a.gn_ss = c.gn_ss; a.gn_out = c.gn_out; a.io_sc1 = c.io_sc1;
   a.fail_flag = c.fail_flag;
   a.kst = c.kst; a.kst_step = c.kst_step; a.kst_stride = c.kst_stride;
+  a.ln_s = ly.ln_s;
   a.y2 = (char*)c.y2; a.bias2 = ly.bias2; a.wtaps = ly.wtaps ? ly.wtaps : ly.taps;
   if ((c.y2 != nullptr) != (ly.wtaps != 0)) return hipErrorInvalidValue;   // a folded layer always writes its second output
   a.wscale = (ly.w8 || ly.dt == DT_FP8) ? ly.wscale : nullptr; a.w8 = ly.w8;
@@ -449,7 +450,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     if (e != hipSuccess || launched) return e;
   }
   if (c.sk_need) return hipSuccess;   // dry run: the generic kernel never splits K
-  if (c.gn_part || c.y2) return hipErrorInvalidValue;   // the fused GroupNorm apply exists only on the pipelined kernel (the planner checks bm_out)
+  if (c.gn_part || c.y2 || ly.ln_s) return hipErrorInvalidValue;   // (the planner asks bm_out first)   // the fused GroupNorm apply exists only on the pipelined kernel (the planner checks bm_out)
   if (ly.dt == DT_FP8) return hipErrorInvalidValue;   // fp8 inputs exist only on the pipelined kernel (the planner checks eligibility)
   a.win_rows = std::min(span, c.B * c.L_in) + 1;
   int bn = ly.bn;

@@ -148,6 +148,7 @@ struct LinAttnW {
   float* norm_g = nullptr;
   ConvLayer qkv, out;
   ConvLayer qkv_f8;             // to_qkv with fp8 inputs (see ResnetW::c2_f8)
+  ConvLayer qkv_ln;             // to_qkv with the PreNorm LayerNorm folded in (ConvLayer::ln_s; bf16 / f32 weights only)
   float* out_g = nullptr;       // null for the bottleneck Attention
   int dim = 0;
 };
@@ -285,6 +286,7 @@ struct ldc_ctx {
   int flow_depth = 8;           // LDC_FLOW_DEPTH (0 = unbounded look-ahead)
   int fuse_gn_stats = 1;
   int gn_epi_min_l = 0;         // LDC_GN_EPI_MINL: shortest level (positions per item) whose ResnetBlocks fuse the GroupNorm apply
+  int fold_ln = 1;              // PreNorm LayerNorm of the attention blocks folded into to_qkv (LDC_NO_LN_FOLD / option "fold_ln")
   int chain_convs = 0;          // block1's and block2's convs of a ResnetBlock as ONE launch (conv_fast_pair_kernel; LDC_CHAIN=1 / option "chain_convs").
                                 // Off: measured 3 % slower than two launches (157.3 vs 152.2 ms per decode, profiles/r04_fusion_experiments.md)
   int fold_res = 1;             // res_conv as a second accumulator set of block1's conv (LDC_NO_RES_FOLD / option "fold_res")
@@ -779,6 +781,33 @@ static int build_attn(ldc_ctx* c, WeightReader& wr, const std::string& p, int di
     LDCCHK(make_conv(c, sq, wq->data.data(), nullptr, &a->qkv_f8));
     sq.dt = c->dt; sq.act8 = 0;
   }
+  if (!c->w8) {
+    // PreNorm folded into to_qkv: W' = W diag(g); ln_s[n] = sum_c W'[n][c] of the weight AS THE MFMA SEES IT (bf16-rounded in the
+    // bf16 engine), so that rstd * (W' x - mean * ln_s) equals W' ((x - mean) * rstd) up to fp32 rounding
+    const int N3 = 3 * hidden;
+    std::vector<float> w2((size_t)N3 * dim), sn((size_t)N3);
+    auto as_packed = [&](float v) {
+      if (c->dt != DT_BF16) return v;
+      uint32_t u;
+      memcpy(&u, &v, 4);
+      u += 0x7fffu + ((u >> 16) & 1u);       // round to nearest even (finite weights)
+      u &= 0xffff0000u;
+      float r;
+      memcpy(&r, &u, 4);
+      return r;
+    };
+    for (int n = 0; n < N3; ++n) {
+      double acc = 0;
+      for (int k = 0; k < dim; ++k) {
+        const float v = wq->data[(size_t)n * dim + k] * ng->data[k];
+        w2[(size_t)n * dim + k] = v;
+        acc += (double)as_packed(v);
+      }
+      sn[n] = (float)acc;
+    }
+    LDCCHK(make_conv(c, sq, w2.data(), nullptr, &a->qkv_ln));
+    LDCCHK(c->wmem.upload(&a->qkv_ln.ln_s, sn));
+  }
   ConvSpec so;
   so.dt = c->dt; so.cin1 = hidden; so.cout = dim; so.k = 1;
   LDCCHK(make_conv(c, so, wo->data.data(), bo->data.data(), &a->out));
@@ -1021,6 +1050,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->gn_epi_min_l = env_int("LDC_GN_EPI_MINL", c->gn_epi_min_l);
   c->fold_res = getenv("LDC_NO_RES_FOLD") ? 0 : 1;
   c->chain_convs = env_int("LDC_CHAIN", c->chain_convs);
+  c->fold_ln = getenv("LDC_NO_LN_FOLD") ? 0 : 1;
   c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
   c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
   c->fuse_attn_tail = getenv("LDC_NO_TAIL_FUSE") ? 0 : 1;
@@ -1160,6 +1190,10 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->fuse_gn_epi) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fuse_gn_epi = value ? 1 : 0; }
     return LDC_OK;
   }
+  if (n == "fold_ln") {
+    if ((value ? 1 : 0) != c->fold_ln) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fold_ln = value ? 1 : 0; }
+    return LDC_OK;
+  }
   if (n == "chain_convs") {
     if ((value ? 1 : 0) != c->chain_convs) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->chain_convs = value ? 1 : 0; }
     return LDC_OK;
@@ -1173,7 +1207,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fold_res | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // debug hook: raise the device-side failure flag as a kernel that gave up would (1 = cooperative LSTM, 2 = fused GroupNorm wait)
@@ -1822,13 +1856,22 @@ struct PlanBuilder {
     return out;
   }
   bool qkv_fp8(const LinAttnW& a) const { return c->w8 && c->fp8_act && a.qkv_f8.w != nullptr; }
+  // the attention block's PreNorm can ride inside to_qkv: the folded layer exists, runs on the pipelined kernel, and the ResnetBlock
+  // in front fuses its GroupNorm apply (else its gn_apply launch writes the LayerNorm output on the way at no extra launch)
+  bool ln_foldable(const LinAttnW& a, int L) {
+    if (!c->fold_ln || !c->fuse_gn_epi || c->w8 || !a.qkv_ln.w || L < c->gn_epi_min_l) return false;
+    int t[3];
+    conv_bm(a.qkv_ln, L, L, false, t);
+    return t[0] > 0;
+  }
   // Residual(PreNorm(LinearAttention)) (unet.py:208-222) / Residual(PreNorm(Attention)) (:234-246)
   void* attention(const LinAttnW& a, const void* x, int L, bool linear, void* xn_pre = nullptr) {
     const int rows = B * L, dt = c->dt, Bn = B;
     const int H = c->unet.heads, Dh = c->unet.dim_head, hid = H * Dh;
     const bool f8 = qkv_fp8(a);
-    void* xn = xn_pre ? xn_pre : (f8 ? ar->alloc((size_t)rows * a.dim) : act(rows, a.dim));
-    const ConvLayer& qkv_ly = f8 ? a.qkv_f8 : a.qkv;
+    const bool lnf = !xn_pre && ln_foldable(a, L);     // LayerNorm inside to_qkv: the conv reads x itself
+    void* xn = lnf ? const_cast<void*>(x) : (xn_pre ? xn_pre : (f8 ? ar->alloc((size_t)rows * a.dim) : act(rows, a.dim)));
+    const ConvLayer& qkv_ly = lnf ? a.qkv_ln : (f8 ? a.qkv_f8 : a.qkv);
     void* qkv = act(rows, 3 * hid);
     void* o = act(rows, hid);
     void* out = act(rows, a.dim);
@@ -1836,7 +1879,7 @@ struct PlanBuilder {
     // one workspace per LinearAttention layer when the k column-max is fused: all of them are zeroed by the
     // step's single memset (they sit behind the GroupNorm statistics)
     float* ws = (linear && c->fuse_kmax) ? linattn_ws + (size_t)(linattn_used++) * B * linattn_ws_floats_per_item(H, Dh) : linattn_ws;
-    if (!xn_pre)
+    if (!xn_pre && !lnf)
       add([=](hipStream_t s) { return launch_ln_rows(dt, x, xn, nullptr, ap->norm_g, rows, ap->dim, s, f8 ? 1 : 0); }, false, 0, LDC_CLASS_LAYERNORM,
           2.0 * rows * a.dim * es);
     if (linear) {
@@ -1971,7 +2014,8 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     const LevelW& lv = u.downs[i];
     x = pb.resnet(lv.b1, x, nullptr, Lc); hs.push_back({x, Lc});
     void* xn = nullptr;
-    x = pb.resnet(lv.b2, x, nullptr, Lc, lv.attn.norm_g, &xn, pb.qkv_fp8(lv.attn));
+    if (pb.ln_foldable(lv.attn, Lc)) x = pb.resnet(lv.b2, x, nullptr, Lc);
+    else x = pb.resnet(lv.b2, x, nullptr, Lc, lv.attn.norm_g, &xn, pb.qkv_fp8(lv.attn));
     x = pb.attention(lv.attn, x, Lc, true, xn); hs.push_back({x, Lc});
     int Ln = Lc;
     if (lv.kind == 0) Ln = (Lc + 2 - 4) / 2 + 1;
@@ -1982,7 +2026,8 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   }
   {
     void* xn = nullptr;
-    x = pb.resnet(u.mid1, x, nullptr, Lc, u.mid_attn.norm_g, &xn, pb.qkv_fp8(u.mid_attn));
+    if (pb.ln_foldable(u.mid_attn, Lc)) x = pb.resnet(u.mid1, x, nullptr, Lc);
+    else x = pb.resnet(u.mid1, x, nullptr, Lc, u.mid_attn.norm_g, &xn, pb.qkv_fp8(u.mid_attn));
     x = pb.attention(u.mid_attn, x, Lc, false, xn);
   }
   x = pb.resnet(u.mid2, x, nullptr, Lc);
@@ -1992,7 +2037,9 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     if (hs.back().second != Lc) return fail(LDC_E_INVALID, "latent length %d is not divisible by 2^%zu", L, u.downs.size() - 1);
     x = pb.resnet(lv.b1, x, hs.back().first, Lc); hs.pop_back();
     void* xn = nullptr;
-    x = pb.resnet(lv.b2, x, hs.back().first, Lc, lv.attn.norm_g, &xn, pb.qkv_fp8(lv.attn)); hs.pop_back();
+    if (pb.ln_foldable(lv.attn, Lc)) x = pb.resnet(lv.b2, x, hs.back().first, Lc);
+    else x = pb.resnet(lv.b2, x, hs.back().first, Lc, lv.attn.norm_g, &xn, pb.qkv_fp8(lv.attn));
+    hs.pop_back();
     x = pb.attention(lv.attn, x, Lc, true, xn);
     const int Ln = lv.kind == 1 ? 2 * Lc : Lc;
     void* y = pb.act(B * Ln, lv.cout);

@@ -46,6 +46,11 @@ struct ConvLayer {
   // ResnetBlock.res_conv folded into block1's conv (unet.py:171,189-192: both read the same input): the packed image holds
   // wtaps = taps + 1 slabs per channel chunk, the extra one being the 1x1 res_conv weight; the pipelined kernel multiplies it
   // with the centre-tap window it has in LDS anyway into a second accumulator set and writes ConvCall::y2 (+ bias2).
+  // PreNorm LayerNorm folded into a 1x1 conv (Residual(PreNorm(attention)).to_qkv, unet.py:82-101,208-246): the weight is packed
+  // as W diag(g) and  conv(LN(x))[r][n] = rstd_r * (acc[r][n] - mean_r * ln_s[n]),  ln_s[n] = sum_c (W diag(g))[n][c] of the ROUNDED
+  // packed weight; the pipelined kernel computes (mean_r, rstd_r) of its rows in its prologue and applies the identity to the
+  // accumulators (one launch and one write + read of the normalised tensor less)
+  float* ln_s = nullptr;
   int wtaps = 0;              // 0: no folded second conv
   float* bias2 = nullptr;     // [n] bias of the folded 1x1 conv
 };

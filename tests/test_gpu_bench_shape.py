@@ -393,8 +393,8 @@ def test_fused_gn_epilogue_equals_the_separate_gn_apply(dtype):
             err = rel(got, ref)
             assert err < (2e-5 if dtype == "f32" else TOL[dtype]["eps_bench"]), (dtype, rep, err)
         # the chained form (block1's and block2's convs in one launch, per-M-tile hand-off inside the launch; off by default) and
-        # the unfolded res_conv give the same tensor again
-        for opt, val in (("chain_convs", 1), ("fold_res", 0)):
+        # the unfolded res_conv / PreNorm LayerNorm give the same tensor again
+        for opt, val in (("chain_convs", 1), ("fold_res", 0), ("fold_ln", 0)):
             e.set_option(opt, val)
             got = e.unet_forward(x, 211, cond).cpu().numpy()
             e.set_option(opt, 1 - val)
@@ -403,3 +403,4 @@ def test_fused_gn_epilogue_equals_the_separate_gn_apply(dtype):
         e.set_option("fuse_gn_epi", 1)
         e.set_option("chain_convs", 0)
         e.set_option("fold_res", 1)
+        e.set_option("fold_ln", 1)
