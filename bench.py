@@ -447,7 +447,7 @@ def main():
         traffic, traffic_src = None, None
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from pmc_traffic import csrc_hash            # the figure is reported only while it was measured on THESE kernel sources
-        for name in ("r03_conv_traffic.json",):
+        for name in ("r04_conv_traffic.json",):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and args.dtype == "bf16" and B == 32 and N == 50 and args.config == "c2":
                 rec = json.load(open(tpath))

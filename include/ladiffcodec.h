@@ -329,6 +329,9 @@ int ldc_xcc_census(ldc_ctx* ctx, const uint32_t* mask, int n_words, int wgs, int
  * cooperative LSTM's hidden-state exchange, 2: the in-launch GroupNorm exchange of a fused conv).  The next call on the context
  * reports LDC_E_HIP with "device-side failure [coop_lstm]" / "[gn_wait]" in ldc_last_error and clears the flag. */
 int ldc_debug_raise_failure(ldc_ctx* ctx, int code);
+/* Test hook: number of device-wide synchronisations (hipDeviceSynchronize) this library has issued in this process.  Steady-state
+ * stage calls issue none: the count does not move across warm ldc_decode calls. */
+long long ldc_debug_sync_count(void);
 
 /* Host-side cost of the step-graph replays since the last reset: milliseconds spent inside hipGraphLaunch, milliseconds spent
  * waiting for the bounded look-ahead window (LDC_FLOW_DEPTH), number of replays. */

@@ -25,6 +25,14 @@
 
 #include "ldc_kernels.h"
 
+// Every device-wide synchronisation of the library goes through this counter (ldc_debug_sync_count): the steady state of the
+// decode path -- plans built, graphs captured -- must issue none (tests/test_gpu_parity.py: test_warm_decode_never_waits_for_the_device)
+static long long g_device_syncs = 0;
+static inline hipError_t counted_device_sync() {
+  ++g_device_syncs;
+  return hipDeviceSynchronize();
+}
+
 using namespace ldc;
 
 // ------------------------------------------------------------------------------------------------
@@ -1105,7 +1113,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
 }
 
 static void drop_plans(ldc_ctx* c) {
-  (void)hipDeviceSynchronize();   // nothing captured or planned may still be running when it is destroyed
+  (void)counted_device_sync();   // nothing captured or planned may still be running when it is destroyed
   for (auto& g : c->graphs) g.destroy();
   c->graphs.clear();
   for (auto& pl : c->plans) {
@@ -1120,7 +1128,7 @@ static void drop_plans(ldc_ctx* c) {
 extern "C" int ldc_destroy(ldc_ctx* c) {
   if (!c) return LDC_OK;
   (void)hipSetDevice(c->device);
-  (void)hipDeviceSynchronize();
+  (void)counted_device_sync();
   drop_plans(c);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->outnorm_ws) (void)hipFree(c->outnorm_ws);
@@ -1210,6 +1218,10 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
   return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
+// device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
+// option changes, profiling / tuning reads)
+extern "C" long long ldc_debug_sync_count(void) { return g_device_syncs; }
+
 // debug hook: raise the device-side failure flag as a kernel that gave up would (1 = cooperative LSTM, 2 = fused GroupNorm wait)
 extern "C" int ldc_debug_raise_failure(ldc_ctx* c, int code) {
   if (!c || !c->dev_flag_host || (code != 1 && code != 2)) return fail(LDC_E_INVALID, "bad arguments");
@@ -1280,7 +1292,7 @@ extern "C" int ldc_finalize_weights(ldc_ctx* c, int strict) {
 static int ensure_scratch(ldc_ctx* c, size_t bytes, hipStream_t s) {
   if (bytes <= c->scratch_cap) return LDC_OK;
   HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(counted_device_sync());
   if (c->scratch) HIPCHK(hipFree(c->scratch));
   c->scratch = nullptr;
   c->scratch_cap = 0;
@@ -2071,7 +2083,7 @@ static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
 
 // Drop plan `idx` (and every captured graph of its (L, F)): waits for the device first, nothing of it may be running.
 static void evict_plan(ldc_ctx* c, size_t idx) {
-  (void)hipDeviceSynchronize();
+  (void)counted_device_sync();
   Plan* pl = c->plans[idx].get();
   for (size_t g = 0; g < c->graphs.size();) {
     if (c->graphs[g].L == pl->L && c->graphs[g].F == pl->F) {
@@ -2356,7 +2368,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
       size_t victim = 0;
       for (size_t i = 1; i < c->graphs.size(); ++i)
         if (c->graphs[i].last_use < c->graphs[victim].last_use) victim = i;
-      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(counted_device_sync());
       c->graphs[victim].destroy();
       c->graphs.erase(c->graphs.begin() + victim);
     }
@@ -2386,7 +2398,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
     if (sg->any()) {
       // replays of the old executable graphs may still be in flight: drain before destroying (a re-capture is one of
       // the documented places where a call waits for the device)
-      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(counted_device_sync());
       sg->destroy();
     }
     // first step eagerly: loads code objects / sets function attributes outside of the capture
@@ -2505,7 +2517,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
 
 static int ensure_state(ldc_ctx* c, size_t bytes) {
   if (bytes <= c->state_bytes) return LDC_OK;
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(counted_device_sync());
   if (c->state_buf) HIPCHK(hipFree(c->state_buf));
   c->state_buf = nullptr; c->state_bytes = 0;
   void* p = nullptr;
@@ -2593,7 +2605,7 @@ extern "C" int ldc_infilling(ldc_ctx* c, float* img, float* infill_img, const fl
 static int ensure_outnorm(ldc_ctx* c, int B) {
   const size_t need = output_normalise_ws_bytes(B);
   if (need <= c->outnorm_ws_bytes) return LDC_OK;
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(counted_device_sync());
   if (c->outnorm_ws) HIPCHK(hipFree(c->outnorm_ws));
   c->outnorm_ws = nullptr;
   HIPCHK(hipMalloc(&c->outnorm_ws, need * 2));
@@ -3199,7 +3211,7 @@ extern "C" int ldc_host_stats(ldc_ctx* c, int reset, double* graph_launch_ms, do
 extern "C" int ldc_timeline_enable(ldc_ctx* c, int on) {
   if (!c) return fail(LDC_E_INVALID, "null ctx");
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(counted_device_sync());
   for (auto& g : c->graphs) g.destroy();
   c->graphs.clear();
   if (on && !c->tl_buf) {
@@ -3224,7 +3236,7 @@ extern "C" int ldc_kstamps_enable(ldc_ctx* c, int on) {
 extern "C" int ldc_kstamps_reset(ldc_ctx* c) {
   if (!c) return fail(LDC_E_INVALID, "null ctx");
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(counted_device_sync());
   for (auto& p : c->plans)
     if (p->kst) HIPCHK(hipMemset(p->kst, 0xff, (size_t)2048 * kKstOps * 2 * 8));
   return LDC_OK;
@@ -3241,7 +3253,7 @@ extern "C" int ldc_kstamps_read(ldc_ctx* c, int idx, int n_steps, int* n_ops, ui
   if (!ticks) return LDC_OK;
   if (n_steps < 1 || n_steps > 2048) return fail(LDC_E_INVALID, "n_steps must be in [1, 2048]");
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(counted_device_sync());
   std::vector<unsigned long long> h((size_t)n_steps * kKstOps * 2);
   HIPCHK(hipMemcpy(h.data(), pl->kst, h.size() * 8, hipMemcpyDeviceToHost));
   for (int j = 0; j < n_steps; ++j)
@@ -3264,7 +3276,7 @@ extern "C" int ldc_timeline_read(ldc_ctx* c, int part, int n, uint64_t* ticks) {
   if (!c || !ticks || part < 0 || part >= kMaxParts || n < 1 || n > 2048) return fail(LDC_E_INVALID, "bad arguments");
   if (!c->tl_buf) return fail(LDC_E_STATE, "ldc_timeline_enable has not been called");
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(counted_device_sync());
   HIPCHK(hipMemcpy(ticks, c->tl_buf + (size_t)part * 2048 * 2, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return LDC_OK;
 }
@@ -3284,7 +3296,7 @@ extern "C" int ldc_profile_enable(ldc_ctx* c, int on) {
 
 static int profile_collect(ldc_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(counted_device_sync());
   FILE* dump = getenv("LDC_PROFILE_DUMP") && !c->prof_events.empty() ? fopen(getenv("LDC_PROFILE_DUMP"), "a") : nullptr;
   for (size_t i = 0; i < c->prof_events.size(); ++i) {
     float ms = 0.f;

@@ -513,3 +513,27 @@ def test_rccl_world_size_one_group_runs_every_collective_path():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_warm_decode_never_waits_for_the_device():
+    """include/ladiffcodec.h: asynchronous stage calls on a caller's stream issue no device-wide synchronisation once the plans of a
+    shape are built and its step graphs captured (eleven hipDeviceSynchronize sites in ldc_api.cpp, all claimed to be
+    cold paths, nothing tested it).  Every such call goes through a counter: it must not move across warm decodes -- single UNet
+    calls, sampler calls and whole decodes, on both graph arrangements' default."""
+    e = engine("r84", "bf16")
+    lib = L.load()
+    wav = torch.from_numpy(synth.synthetic_wav(4, 5120, seed=9)).cuda()
+    g = load_golden("ladiff_r84")
+    x, cond = cu(g["x"]), cu(g["cond"])
+    for _ in range(2):                                   # cold: plans, graphs, scratch
+        e.decode(wav, 7, noise=None, per_item=True)
+        e.unet_forward(x, 5, cond)
+        e.denoise(cu(g["img0"]), cond, 6)
+    torch.cuda.synchronize()
+    before = lib.ldc_debug_sync_count()
+    for _ in range(3):
+        e.decode(wav, 7, noise=None, per_item=True)
+        e.unet_forward(x, 5, cond)
+        e.denoise(cu(g["img0"]), cond, 6)
+    torch.cuda.synchronize()
+    assert lib.ldc_debug_sync_count() == before, (before, lib.ldc_debug_sync_count())
