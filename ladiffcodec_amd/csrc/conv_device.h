@@ -68,7 +68,8 @@ struct ConvKArgs {
   const float* gn_gamma;   // [n]
   const float* gn_beta;    // [n]
   const float* gn_ss;      // [2 n]: (scale | shift) of the current timestep, or null
-  int gn_out;              // bit 2: tanh after the residual add (the final ResnetBlock feeds torch.tanh alone, unet.py:467)
+  int gn_out;              // bit 2: tanh after the residual add (the final ResnetBlock feeds torch.tanh alone, unet.py:467); bit 0: the output
+                           // is written as OCP fp8 e4m3 (its only consumer is an fp8 x fp8 conv; bf16 kernels only)
   int io_sc1;              // bit 0: the output is read inside this launch (write-through stores); bit 1: the residual was
                            // produced inside this launch (agent-scope loads); bit 2: so was the input window (x1)
   unsigned* fail_flag;     // host-mapped word raised when a bounded spin gives up (the output is then wrong, never a hang)
@@ -565,15 +566,20 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
     constexpr int NSW = TM * 32 / RPS;
     u32x4_t rres[NSW];
     const bool res_sc1 = (a.io_sc1 & 2) != 0;
+    const bool has_res = a.residual != nullptr;   // (this staged-fp32 form also serves the fp8 output of a conv without residual)
+    const bool out8 = (a.gn_out & 1) != 0;
 #pragma unroll
     for (int sw = 0; sw < NSW; ++sw) {
       const int m = m_wave0 + sw * RPS + rsub;
       const bool ok = m < M && col < a.n;
-      const char* src = a.residual + ((size_t)(ok ? m : 0) * a.n + (ok ? col : 0)) * sizeof(T);
-      if (res_sc1) load16_sc1_issue(rres[sw], src);
-      else { const uint4 t = *reinterpret_cast<const uint4*>(src); rres[sw] = u32x4_t{t.x, t.y, t.z, t.w}; }
+      rres[sw] = u32x4_t{0u, 0u, 0u, 0u};
+      if (has_res) {
+        const char* src = a.residual + ((size_t)(ok ? m : 0) * a.n + (ok ? col : 0)) * sizeof(T);
+        if (res_sc1) load16_sc1_issue(rres[sw], src);
+        else { const uint4 t = *reinterpret_cast<const uint4*>(src); rres[sw] = u32x4_t{t.x, t.y, t.z, t.w}; }
+      }
     }
-    if (res_sc1) wait_vm0();
+    if (res_sc1 && has_res) wait_vm0();
 #pragma unroll
     for (int sw = 0; sw < NSW; ++sw) {
       const int row = sw * RPS + rsub;
@@ -605,6 +611,20 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
         v = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
       } else {
         v = make_uint4(hw_bf16x2(f[0], f[1]), hw_bf16x2(f[2], f[3]), hw_bf16x2(f[4], f[5]), hw_bf16x2(f[6], f[7]));
+      }
+      if constexpr (sizeof(T) == 2) {
+        if (out8) {   // OCP e4m3, saturating, from the un-rounded value (as gn_apply's fp8 output: the consumer is an fp8 x fp8 conv)
+          float c8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) c8[e] = fminf(fmaxf(f[e], -448.0f), 448.0f);
+          int lo = 0, hi = 0;
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(c8[0], c8[1], lo, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(c8[2], c8[3], lo, true);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(c8[4], c8[5], hi, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(c8[6], c8[7], hi, true);
+          if (m < M && col < a.n) *reinterpret_cast<int2*>(a.y + (size_t)m * a.y_ld + col) = make_int2(lo, hi);
+          continue;
+        }
       }
       if (m < M && col < a.n) {
         char* dst = a.y + ((size_t)m * a.y_ld + col) * sizeof(T);
@@ -657,7 +677,7 @@ __device__ __forceinline__ void epilogue_rows_dispatch(const ConvKArgs& a, f32x1
                                                        int col_wave0, int M, int m0, int BM, int WM = 1, int wm = 0) {
   const int lane = threadIdx.x & 63;
   if (a.gn_part) {   // fused GroupNorm apply (uniform over the launch)
-    if (a.residual) epilogue_gn_fused<T, TM, TN, true>(a, acc, wave_lds, m_wave0, col_wave0, M, m0, BM, WM, wm);
+    if (a.residual || (a.gn_out & 1)) epilogue_gn_fused<T, TM, TN, true>(a, acc, wave_lds, m_wave0, col_wave0, M, m0, BM, WM, wm);
     else epilogue_gn_fused<T, TM, TN, false>(a, acc, wave_lds, m_wave0, col_wave0, M, m0, BM, WM, wm);
     return;
   }

@@ -1769,9 +1769,9 @@ struct PlanBuilder {
     if (epi_ok) {
       int t1[3], t2[3];
       conv_bm(r.c1, L, L, false, t1);
-      epi1 = !f8 && t1[0] > 0 && t1[0] <= 2 * L && take_part(&ge1, L, t1[0], t1[1], r.cout);
+      epi1 = (!f8 || dt == DT_BF16) && t1[0] > 0 && t1[0] <= 2 * L && take_part(&ge1, L, t1[0], t1[1], r.cout);   // f8: block1's output in fp8
       conv_bm(f8 ? r.c2_f8 : r.c2, L, L, false, t2);
-      epi2 = !(out_mode & 1) && t2[0] > 0 && t2[0] <= 2 * L && take_part(&ge2, L, t2[0], t2[1], r.cout);
+      epi2 = (!(out_mode & 1) || dt == DT_BF16) && t2[0] > 0 && t2[0] <= 2 * L && take_part(&ge2, L, t2[0], t2[1], r.cout);
     }
     void* a = epi1 ? nullptr : act(rows, r.cout);   // un-normalised conv outputs exist only on the unfused path
     void* d = epi2 ? nullptr : act(rows, r.cout);
@@ -1830,7 +1830,7 @@ struct PlanBuilder {
       return out;
     }
     if (epi1) {   // block1: conv -> GroupNorm -> (scale + 1, shift) -> SiLU, one launch, one store
-      ge1.gamma = r.g1; ge1.beta = r.b1; ge1.ss = cur_ss + r.ss_off;
+      ge1.gamma = r.g1; ge1.beta = r.b1; ge1.ss = cur_ss + r.ss_off; ge1.out = f8 ? 1 : 0;
       if (folded) y2_next = rr;
       conv(c1, x1, x2, b, nullptr, L, L, nullptr, nullptr, 0, 0, 0, &ge1);
     } else {
@@ -1848,7 +1848,7 @@ struct PlanBuilder {
       *xn_out = xn;
     }
     if (epi2) {   // block2: conv -> GroupNorm -> SiLU -> + res (-> tanh), one launch; the PreNorm LayerNorm of a following attention block reads `out`
-      ge2.gamma = r.g2; ge2.beta = r.b2; ge2.ss = nullptr; ge2.out = out_mode & 4;
+      ge2.gamma = r.g2; ge2.beta = r.b2; ge2.ss = nullptr; ge2.out = out_mode & 5;
       if (r.has_res && !folded) mark(3);
       conv(f8 ? r.c2_f8 : r.c2, b, nullptr, out, res, L, L, nullptr, nullptr, 0, 0, 0, &ge2);
       if (xn) {
