@@ -6,394 +6,29 @@
 //   Ctx::unet        <- DiffAudioRep.diff_model = Unet1D                  (srcs/model.py:74, modules/unet.py:250-469)
 //   Ctx::sched       <- GaussianDiffusion1D registered buffers            (srcs/losses/ddpm_loss.py:138-168)
 //   ldc_denoise      <- GaussianDiffusion1D.halfway_sampling              (srcs/losses/ddpm_loss.py:370-385)
-#include "../../include/ladiffcodec.h"
+#include "ldc_internal.h"
 
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <string.h>
-
-#include <algorithm>
-#include <chrono>
-#include <functional>
-#include <map>
-#include <memory>
-#include <set>
-#include <string>
-#include <vector>
-
-#include "ldc_kernels.h"
-
-// Every device-wide synchronisation of the library goes through this counter (ldc_debug_sync_count): the steady state of the
-// decode path -- plans built, graphs captured -- must issue none (tests/test_gpu_parity.py: test_warm_decode_never_waits_for_the_device)
-static long long g_device_syncs = 0;
-static inline hipError_t counted_device_sync() {
-  ++g_device_syncs;
-  return hipDeviceSynchronize();
-}
-
-using namespace ldc;
+long long g_device_syncs = 0;
 
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
-static int fail(int code, const char* fmt, ...) {
+int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
 }
-#define HIPCHK(expr)                                                                                   \
-  do {                                                                                                 \
-    hipError_t _e = (expr);                                                                            \
-    if (_e != hipSuccess) return fail(LDC_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-  } while (0)
-#define LDCCHK(expr)          \
-  do {                        \
-    int _r = (expr);          \
-    if (_r != LDC_OK) return _r; \
-  } while (0)
 
 extern "C" const char* ldc_last_error(void) { return g_err; }
 extern "C" const char* ldc_version(void) { return "ladiffcodec-amd 0.1 (gfx950)"; }
 
-// ------------------------------------------------------------------------------------------------
-// small utilities
-// ------------------------------------------------------------------------------------------------
-struct HostTensor {
-  std::vector<int64_t> shape;
-  std::vector<float> data;
-  bool used = false;
-  size_t numel() const {
-    size_t n = 1;
-    for (auto s : shape) n *= (size_t)s;
-    return n;
-  }
-};
-
-struct Arena {   // bump allocator over one device buffer; base == nullptr measures only
-  char* base = nullptr;
-  size_t cap = 0, off = 0;
-  void* alloc(size_t bytes) {
-    off = (off + 255) & ~(size_t)255;
-    void* p = base ? base + off : nullptr;
-    off += bytes;
-    return p;
-  }
-};
-
-struct DevMem {
-  std::vector<void*> ptrs;
-  ~DevMem() {
-    for (void* p : ptrs) (void)hipFree(p);
-  }
-  int alloc(void** out, size_t bytes) {
-    void* p = nullptr;
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return fail(LDC_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    ptrs.push_back(p);
-    *out = p;
-    return LDC_OK;
-  }
-  template <typename T>
-  int upload(T** out, const std::vector<T>& v) {
-    void* p = nullptr;
-    LDCCHK(alloc(&p, v.size() * sizeof(T)));
-    if (!v.empty()) {
-      hipError_t e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-      if (e != hipSuccess) return fail(LDC_E_HIP, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
-    }
-    *out = reinterpret_cast<T*>(p);
-    return LDC_OK;
-  }
-};
-
-// ------------------------------------------------------------------------------------------------
-// model descriptions
-// ------------------------------------------------------------------------------------------------
-struct LstmLayer {
-  ConvLayer in_proj;          // k1 GEMM H -> 4H with bias b_ih + b_hh
-  float* w_hh = nullptr;      // layout depends on H (see launch_lstm_layer)
-  float* w_rm = nullptr;      // row-major copy for the cooperative kernel (H = 256 / 512)
-};
-
-struct SeaOp {
-  enum Kind { CONV_CIN1, CONV, CONVTR, RES, LSTM } kind = CONV;
-  ConvLayer conv;             // CONV / CONVTR / RES first conv (k3, pre-ELU)
-  ConvLayer conv2;            // RES second conv (k1, pre-ELU, + shortcut residual)
-  ConvLayer shortcut;         // RES shortcut (k1)
-  std::vector<LstmLayer> lstm;
-  float* w1 = nullptr;        // CONV_CIN1 [Cout][k]
-  float* b1 = nullptr;
-  int cin = 0, cout = 0, k = 1, stride = 1, hidden = 0;
-};
-
-struct Codec {
-  std::vector<int> ratios;
-  int hop = 1;
-  std::vector<SeaOp> enc, dec;
-  // RVQ
-  int n_q_layers = 0, bins = 1024;
-  float* codebooks = nullptr;   // [n_q][bins][D]
-  float* cb_sqnorm = nullptr;   // [n_q][bins]
-  bool present = false;
-};
-
-struct ResnetW {
-  ConvLayer c1r;               // block1's conv with res_conv folded in (ConvLayer::wtaps; bf16 / f32 weights only)
-  ConvLayer c1, c2, res;
-  ConvLayer c2_f8;              // fp8-weight contexts: block2's conv with fp8 INPUTS too (w == null: not eligible)
-  bool has_res = false;
-  float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
-  int cin1 = 0, cin2 = 0, cout = 0;
-  int ss_off = 0;               // offset of this block's (scale|shift) in a table row
-};
-struct LinAttnW {
-  float* norm_g = nullptr;
-  ConvLayer qkv, out;
-  ConvLayer qkv_f8;             // to_qkv with fp8 inputs (see ResnetW::c2_f8)
-  ConvLayer qkv_ln;             // to_qkv with the PreNorm LayerNorm folded in (ConvLayer::ln_s; bf16 / f32 weights only)
-  float* out_g = nullptr;       // null for the bottleneck Attention
-  int dim = 0;
-};
-struct LevelW {
-  ResnetW b1, b2;
-  LinAttnW attn;
-  ConvLayer resample;
-  int kind = 0;                 // 0 down (k4 s2 p1), 1 up (nearest x2 + k3 p1), 2 same (k3 p1)
-  int cin = 0, cout = 0;
-};
-struct UnetW {
-  int dim = 0, time_dim = 0, groups = 8, heads = 4, dim_head = 32, channels = 128, cond_channels = 128;
-  std::vector<int> dims;
-  ConvLayer init, final_conv;
-  ConvLayer final_conv_f8;      // final_conv with fp8 inputs
-  std::vector<LevelW> downs, ups;
-  ResnetW mid1, mid2, fin;
-  LinAttnW mid_attn;
-  std::vector<ConvLayer> upsamplers;
-  std::vector<int> up_ratios;
-  float* ss_table = nullptr;    // [T][ss_stride] fp32
-  float* cur_ss = nullptr;      // [ss_stride]: the row of the step being executed (launch_step_begin)
-  int ss_stride = 0;
-  int timesteps = 1000;
-  double weight_elems = 0;
-};
-
-struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells the two halves of a batch apart
-  int B = 0, L = 0, F = 0, slot = 0;
-  uint64_t last_use = 0;        // LRU tick (ldc_ctx::use_tick)
-  long long sk_floats = 0;      // split-K workspace this plan's convs need (sized by a dry run of the launchers)
-  long long sk_need_max = 0;
-  unsigned long long* kst = nullptr;   // [2048 steps][kKstOps][2] timed-mode stamps of the step's conv launches (ldc_kstamps_enable)
-  size_t part_bytes = 0;        // granule regions of the fused GroupNorm applies (sized by the same dry run)
-  size_t part_need = 0;
-  void* arena_base = nullptr;
-  size_t arena_bytes = 0;
-  void* zero_ptr = nullptr;     // the step's accumulators (GroupNorm sums, split-K counters, k-max keys, scale_x maxima): cleared by
-  size_t zero_bytes = 0;        // launch_step_begin
-  void* x_cl = nullptr;         // [B*L][channels]
-  void* cond_in_cl = nullptr;   // [B*F][cond_channels]   (raw cond, channels-last)
-  void* cond_cl = nullptr;      // [B*L][cond_channels]   (processed)
-  void* eps_cl = nullptr;       // [B*L][channels]
-  float* maxabs = nullptr;      // [B]
-  int* step_state = nullptr;    // device int[2] {t, j} of THIS part: the parts of a batch advance independently
-  float* cur_ss = nullptr;      // [ss_stride] timestep-MLP row of the step this part is executing
-  std::vector<std::function<hipError_t(hipStream_t)>> cond_ops;   // process_cond (once per denoise)
-  std::vector<std::function<hipError_t(hipStream_t)>> step_ops;   // Unet1D.forward after process_cond
-  std::vector<int> step_is_conv;                                   // 1 where step_ops[i] is a conv-GEMM launch
-  std::vector<int> step_where;                                     // 0 main stream, 1 side stream, 2 fork, 3 join
-  std::vector<hipEvent_t> marker_events;                           // one event per fork/join marker (no re-use inside a capture)
-  std::vector<double> step_flops;
-  std::vector<int> step_class;                                     // LDC_CLASS_* of each op (profiling)
-  std::vector<double> step_bytes;                                  // algorithmic HBM bytes of each op
-  std::vector<std::string> step_info;                              // human-readable shape (profile dump)
-  struct Tap { void* p; int C; int L; };
-  std::map<std::string, Tap> taps;
-  double flops = 0, act_bytes = 0, conv_bytes = 0;   // conv_bytes: inputs + outputs + packed weights of every conv-GEMM
-};
-
-// A batch is decoded as (up to) two independent halves on two streams: utterances do not interact inside
-// the UNet, so the halves' kernels overlap and fill each other's tails and launch gaps.
-static constexpr int kMaxParts = 4;
-struct Halves {                // (the name dates from the two-way split; n parts, n <= kMaxParts)
-  int n = 0;
-  Plan* p[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
-  int b0[kMaxParts] = {0, 0, 0, 0};   // first item of each part
-};
-
-static constexpr int kKstOps = 256;   // stamp slots per step (one per op of the step list)
-
-struct StepGraph {   // per batch part: hipGraph of {step_begin, unet step, p_sample_update, step_advance}
-  int B = 0, L = 0, F = 0, n = 0;
-  const float* noise = nullptr;
-  float* x = nullptr;
-  hipStream_t stream = nullptr;
-  hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipGraphExec_t pexec[kMaxParts][2] = {};   // per-part single-stream graphs ([part][0] = K steps, [1] = one step)
-  bool per_part = false;
-  std::vector<hipEvent_t> part_ev;            // per-part mode: look-ahead events [part][depth]
-  uint64_t last_use = 0;
-  bool any() const { return exec[0] != nullptr; }
-  void destroy() {   // exec[0] aliases pexec[0][0] in per-part mode
-    if (per_part) exec[0] = nullptr;
-    for (hipEvent_t e : part_ev) (void)hipEventDestroy(e);
-    part_ev.clear();
-    for (auto& e : exec) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
-    for (auto& pe : pexec) for (auto& e : pe) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
-    per_part = false;
-  }
-};
-
-struct ldc_ctx {
-  ldc_config cfg;
-  int device = 0;
-  int dt = DT_F32;              // UNet compute dtype; the codec (SEANet/LSTM/RVQ/upsampler) is always fp32
-  bool w8 = false;              // LDC_BF16_W8: UNet conv weights stored as fp8 e4m3 + per-channel scale (activations bf16)
-  bool finalized = false;
-  std::map<std::string, HostTensor> raw[2];
-  DevMem wmem;                  // weights, tables
-  Codec codec[2];
-  UnetW unet;
-  StepTables sched{};
-  // training-side schedule buffers (q_sample, loss weights; ddpm_loss.py:150-168)
-  const float* sqrt_alphas_cumprod = nullptr;
-  const float* sqrt_one_minus_alphas_cumprod = nullptr;
-  const float* p2_loss_weight = nullptr;
-  int* step_state = nullptr;    // device int[2]: t, j
-  std::vector<std::unique_ptr<Plan>> plans;
-  std::vector<StepGraph> graphs;
-  Halves last_halves;
-  hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
-  int split_batch = 2;
-  int fp8_act = 1;              // LDC_FP8_ACT: in an fp8-weight context, tensors whose only consumer is a conv are produced in fp8 and
-                                // that conv runs fp8 x fp8 on the block-scaled MFMA (0: bf16 activations x fp8 weights everywhere)
-  int part_graphs = 1;          // one single-stream graph per batch part, replays interleaved behind a bounded look-ahead: recorded-AQL replay path,
-                                // 3 ms of host time inside hipGraphLaunch per decode instead of 145 (LDC_PART_GRAPHS=0: one fork/join graph, node-by-node path)
-  double host_graph_ms = 0, host_wait_ms = 0;   // host time inside hipGraphLaunch / waiting for the look-ahead window (ldc_host_stats)
-  long long host_graph_launches = 0;
-  hipStream_t side_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_side_fork[kMaxParts] = {nullptr, nullptr, nullptr, nullptr}, ev_side_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
-  int side_streams = 0;
-  int fuse_kmax = 1;
-  int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
-  int coop_launch = 0;          // LDC_COOP_LAUNCH: hipLaunchCooperativeKernel for the cooperative LSTM (see seanet.hip)
-  int coop_resident[2] = {0, 0};   // [H == 512]: the cooperative LSTM's H/4 workgroups fit the device together (asked at ldc_create)
-  int fuse_attn_tail = 1;       // LinearAttention out + to_out conv + LayerNorm + residual in one launch (bf16 engine)
-  // Flow control of the step-graph replays: with more than ~10-20 multi-thousand-node graph launches outstanding the ROCm 7.2
-  // runtime's enqueue path degrades (a decode queued behind a running one took 247 instead of 157 ms), so a replay waits on
-  // the host until the replay `flow_depth` launches before it has finished (an event of this context, never a device sync)
-  static constexpr int kFlowRing = 32;
-  hipEvent_t flow_ev[kFlowRing] = {};
-  unsigned long long flow_n = 0;
-  int flow_depth = 8;           // LDC_FLOW_DEPTH (0 = unbounded look-ahead)
-  int fuse_gn_stats = 1;
-  int gn_epi_min_l = 0;         // LDC_GN_EPI_MINL: shortest level (positions per item) whose ResnetBlocks fuse the GroupNorm apply
-  int fold_ln = 1;              // PreNorm LayerNorm of the attention blocks folded into to_qkv (LDC_NO_LN_FOLD / option "fold_ln")
-  int chain_convs = 0;          // block1's and block2's convs of a ResnetBlock as ONE launch (conv_fast_pair_kernel; LDC_CHAIN=1 / option "chain_convs").
-                                // Off: measured 3 % slower than two launches (157.3 vs 152.2 ms per decode, profiles/r04_fusion_experiments.md)
-  int fold_res = 1;             // res_conv as a second accumulator set of block1's conv (LDC_NO_RES_FOLD / option "fold_res")
-  int fuse_gn_epi = 1;          // GroupNorm APPLY in the producing conv's epilogue behind an in-launch per-item wait (LDC_NO_GN_EPI / option "fuse_gn_epi")
-  // knobs read from the environment once, at ldc_create (per context, not process-global)
-  ConvTune tune;
-  int lstm_stream_only = 0;     // LDC_LSTM_STREAM: never use the cooperative LSTM
-  int serial_parts = 0;         // LDC_SERIAL: batch parts back to back, eager (diagnostics)
-  int graph_steps = 5;          // LDC_GRAPH_STEPS: denoise steps per replayed graph
-  // plan / graph cache (LRU): a corpus with many distinct lengths must not grow device memory without bound
-  uint64_t use_tick = 0, call_tick = 0;
-  size_t plan_bytes = 0, plan_bytes_cap = (size_t)48 << 30;   // LDC_PLAN_CACHE_GB
-  int plan_count_cap = 24;                                     // LDC_PLAN_CACHE_N
-  // device-drawn noise: every sampler call that draws advances the epoch, so no two calls share a realisation
-  uint64_t noise_epoch = 0, cur_key = 0;
-  // asynchronous device-side failure flag (cooperative LSTM timeout), host-mapped
-  unsigned* dev_flag_host = nullptr;
-  unsigned* dev_flag_dev = nullptr;
-  int enc_final_act = ACT_NONE;
-  // device-side timeline of the timed mode (ldc_timeline_enable): [kMaxParts][2048][begin, end] in 100 MHz ticks
-  unsigned long long* tl_buf = nullptr;
-  bool timeline = false;
-  bool kstamps = false;         // ldc_kstamps_enable: per-launch device stamps of the pipelined conv kernel (plans carry the buffers)
-  // scratch arena for codec stages and boundary buffers
-  char* scratch = nullptr;
-  size_t scratch_cap = 0;
-  void* outnorm_ws = nullptr;
-  size_t outnorm_ws_bytes = 0;
-  float* state_buf = nullptr;   // diffusion state of ldc_denoise / ldc_p_sample_loop: a stable address keeps the step graphs valid
-  size_t state_bytes = 0;
-  hipStream_t own_stream = nullptr;
-  // profiling
-  bool profile = false;
-  double prof_ms = 0, prof_flops = 0;
-  int64_t prof_launches = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-  std::vector<double> prof_event_flops;
-  std::vector<int> prof_event_class;
-  std::vector<double> prof_event_bytes;
-  std::vector<std::string> prof_event_info;
-  double cls_ms[LDC_N_CLASSES] = {}, cls_flops[LDC_N_CLASSES] = {}, cls_bytes[LDC_N_CLASSES] = {};
-  int64_t cls_launches[LDC_N_CLASSES] = {};
-};
-
-static hipStream_t pick_stream(ldc_ctx* c, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : c->own_stream; }
-// A kernel that gave up (bounded spin of the cooperative LSTM) raises a host-mapped flag; it is reported by the first
-// API call that sees it: synchronous calls (stream == NULL) see their own failures, asynchronous ones the previous call's.
-static int check_dev_flag(ldc_ctx* c) {
-  const unsigned v = c->dev_flag_host ? *reinterpret_cast<volatile unsigned*>(c->dev_flag_host) : 0u;
-  if (v) {
-    *reinterpret_cast<volatile unsigned*>(c->dev_flag_host) = 0u;
-    // the bracketed tag is what callers key their fallback on (sample.py: decode_with_retry)
-    if (v == 2)
-      return fail(LDC_E_HIP, "device-side failure [gn_wait]: the in-launch GroupNorm exchange of a fused conv timed out (its tiles were "
-                             "not all resident in time: is the GPU shared with another process?); the outputs of that call are NaN; "
-                             "ldc_set_option(ctx, \"fuse_gn_epi\", 0) restores the separate conv + gn_apply launches");
-    return fail(LDC_E_HIP, "device-side failure [coop_lstm]: cooperative LSTM: the hidden-state exchange timed out (its workgroups were "
-                           "not co-resident: is the GPU shared with another process?); the outputs of that call are NaN; "
-                           "ldc_set_option(ctx, \"lstm_stream\", 1) selects the streamed LSTM kernel");
-  }
-  return LDC_OK;
-}
-static int finish_stream(ldc_ctx* c, void* s) {
-  if (!s) {   // NULL stream => synchronous call on the context's own stream
-    HIPCHK(hipStreamSynchronize(c->own_stream));
-    return check_dev_flag(c);
-  }
-  return LDC_OK;
-}
-static uint64_t next_noise_key(ldc_ctx* c, bool draws) {
-  c->cur_key = c->cfg.noise_seed ^ (c->noise_epoch * 0x9E3779B97F4A7C15ull);
-  if (draws) ++c->noise_epoch;
-  return c->cur_key;
-}
 
 // ------------------------------------------------------------------------------------------------
 // weight access + folding
 // ------------------------------------------------------------------------------------------------
-struct WeightReader {
-  ldc_ctx* c;
-  int which;
-  std::string missing;
-  HostTensor* get(const std::string& key, std::initializer_list<int64_t> shape) {
-    auto& m = c->raw[which];
-    auto it = m.find(key);
-    if (it == m.end() && key.rfind("diff_model.", 0) == 0) it = m.find("diffusion.model." + key.substr(11));
-    if (it == m.end()) {
-      if (missing.size() < 600) missing += key + " ";
-      return nullptr;
-    }
-    HostTensor& t = it->second;
-    if (t.shape != std::vector<int64_t>(shape)) {
-      if (missing.size() < 600) missing += key + "(shape) ";
-      return nullptr;
-    }
-    t.used = true;
-    return &t;
-  }
-};
 
 // w = g * v / ||v||  per dim-0 slice  (torch weight_norm, dim=0; reference conv.py:27-30)
 static std::vector<float> fold_weight_norm(const HostTensor& g, const HostTensor& v) {
@@ -429,18 +64,11 @@ static std::vector<float> fold_weight_std(const HostTensor& wt) {
   return w;
 }
 
-struct ConvSpec {
-  int dt = DT_F32;
-  int cin1 = 0, cin2 = 0, cout = 0, k = 1, stride = 1, dil = 1, pad_left = 0, ups = 0, pad_mode = PAD_ZERO;
-  int pre_act = ACT_NONE, post_act = ACT_NONE;
-  int no_w8 = 0;               // keep this layer's weights in bf16 even in an fp8-weight context
-  int act8 = 0;                // fp8 inputs as well (dt is then DT_FP8): the fp8 x fp8 MFMA path
-};
 
 // the column form of gn_apply (norm_act.hip) is the one that can write fp8
 static bool gn_apply_fp8_ok(int C) { return C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 && C <= 2048; }
 
-static int make_conv(ldc_ctx* c, const ConvSpec& sp, const float* w_oik, const float* bias, ConvLayer* out) {
+int make_conv(ldc_ctx* c, const ConvSpec& sp, const float* w_oik, const float* bias, ConvLayer* out) {
   ConvLayer ly;
   ly.dt = sp.dt;
   ly.cin1 = sp.cin1; ly.cin2 = sp.cin2;
@@ -479,7 +107,7 @@ static int make_conv(ldc_ctx* c, const ConvSpec& sp, const float* w_oik, const f
 }
 
 // ConvTranspose1d(k = 2*stride) as a 2-tap conv over q with N = stride*Cout (see conv_gemm.hip)
-static int make_convtr(ldc_ctx* c, int dt, int cin, int cout, int stride, int trim_left, int pre_act, const float* w_iok,
+int make_convtr(ldc_ctx* c, int dt, int cin, int cout, int stride, int trim_left, int pre_act, const float* w_iok,
                        const float* bias, ConvLayer* out) {
   ConvLayer ly;
   ly.dt = dt;
@@ -525,7 +153,7 @@ static int build_wn_conv(ldc_ctx* c, WeightReader& wr, const std::string& p, int
   return make_conv(c, sp, w.data(), b->data.data(), out);
 }
 
-static int build_lstm(ldc_ctx* c, WeightReader& wr, const std::string& p, int H, int layers, std::vector<LstmLayer>* out) {
+int build_lstm(ldc_ctx* c, WeightReader& wr, const std::string& p, int H, int layers, std::vector<LstmLayer>* out) {
   for (int n = 0; n < layers; ++n) {
     const std::string s = std::to_string(n);
     HostTensor* wih = wr.get(p + ".lstm.weight_ih_l" + s, {4 * H, H});
@@ -1112,7 +740,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   return LDC_OK;
 }
 
-static void drop_plans(ldc_ctx* c) {
+void drop_plans(ldc_ctx* c) {
   (void)counted_device_sync();   // nothing captured or planned may still be running when it is destroyed
   for (auto& g : c->graphs) g.destroy();
   c->graphs.clear();
@@ -1289,7 +917,7 @@ extern "C" int ldc_finalize_weights(ldc_ctx* c, int strict) {
 // ------------------------------------------------------------------------------------------------
 // Growth of a context-owned workspace is the one place a stage call waits for the device (the old buffer may still be
 // in use by earlier asynchronous calls); steady-state calls never do (include/ladiffcodec.h documents this).
-static int ensure_scratch(ldc_ctx* c, size_t bytes, hipStream_t s) {
+int ensure_scratch(ldc_ctx* c, size_t bytes, hipStream_t s) {
   if (bytes <= c->scratch_cap) return LDC_OK;
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(counted_device_sync());
@@ -1308,7 +936,7 @@ static int ensure_scratch(ldc_ctx* c, size_t bytes, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // SEANet execution (codec dtype = fp32, channels-last)
 // ------------------------------------------------------------------------------------------------
-static int conv_out_len(const ConvLayer& ly, int L) {
+int conv_out_len(const ConvLayer& ly, int L) {
   // SConv1d output length with the reference's extra right padding (conv.py:56-63): ceil(L / stride)
   const int eff_k = (ly.taps - 1) * ly.dil + 1;
   const int padding_total = eff_k - ly.stride;
@@ -1316,13 +944,6 @@ static int conv_out_len(const ConvLayer& ly, int L) {
   return (int)ceil(n_frames);
 }
 
-struct SeaRun {   // measures or runs a SEANet stack
-  ldc_ctx* c;
-  Arena* ar;
-  hipStream_t s;
-  bool dry;
-  int B;
-};
 
 static int sea_conv(SeaRun& R, const ConvLayer& ly, const void* x, const void* residual, int L_in, void** y, int* L_out,
                     int cout) {
@@ -1344,7 +965,7 @@ static int sea_conv(SeaRun& R, const ConvLayer& ly, const void* x, const void* r
   return LDC_OK;
 }
 
-static int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in, int L, void** out, int* L_out, int* C_out) {
+int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in, int L, void** out, int* L_out, int* C_out) {
   const void* x = x_in;
   int C = 0;
   for (const SeaOp& op : ops) {
@@ -1410,19 +1031,8 @@ static int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in
   return LDC_OK;
 }
 
-// runs `body` twice: once against a measuring arena, then (after sizing the scratch) for real
-template <typename F>
-static int with_scratch(ldc_ctx* c, hipStream_t s, F body) {
-  Arena measure;
-  LDCCHK(body(measure, true));
-  LDCCHK(ensure_scratch(c, measure.off + 4096, s));
-  Arena real;
-  real.base = c->scratch;
-  real.cap = c->scratch_cap;
-  return body(real, false);
-}
 
-static int check_ready(ldc_ctx* c, int which, bool need_cond_codec = false) {
+int check_ready(ldc_ctx* c, int which, bool need_cond_codec) {
   if (!c) return fail(LDC_E_INVALID, "null ctx");
   if (!c->finalized) return fail(LDC_E_STATE, "ldc_finalize_weights has not been called");
   if (which != LDC_MODEL_MAIN && which != LDC_MODEL_COND) return fail(LDC_E_INVALID, "bad model selector");
@@ -1579,7 +1189,7 @@ static int upsample_rows(ldc_ctx* c, const void* rows_in, int B, int F, Arena& a
   return LDC_OK;
 }
 
-static int upsample_factor(const ldc_ctx* c) {
+int upsample_factor(const ldc_ctx* c) {
   int f = 1;
   for (int r : c->unet.up_ratios) f *= r;
   return f;
@@ -1929,7 +1539,7 @@ struct PlanBuilder {
   }
 };
 
-static int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
+int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const UnetW& u = c->unet;
   pl->B = B; pl->L = L; pl->F = F;
   pl->cond_ops.clear(); pl->step_ops.clear(); pl->step_is_conv.clear(); pl->step_where.clear(); pl->step_flops.clear(); pl->step_class.clear(); pl->step_bytes.clear(); pl->step_info.clear(); pl->taps.clear();
@@ -2237,7 +1847,7 @@ static int load_x(ldc_ctx* c, const Halves& h, const float* x, hipStream_t s) {
   return LDC_OK;
 }
 
-static int check_unet_args(ldc_ctx* c, int B, int L, int F) {
+int check_unet_args(ldc_ctx* c, int B, int L, int F) {
   if (B <= 0 || L <= 0 || F <= 0) return fail(LDC_E_INVALID, "bad sizes");
   // upsampling_ratios=None (unet.py:411): process_cond only scales, so the condition must already have the latent length
   if (F * upsample_factor(c) != L) return fail(LDC_E_INVALID, "L (%d) must equal F (%d) x prod(upsampling_ratios) (%d)", L, F, upsample_factor(c));
@@ -2680,1037 +2290,11 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
   return finish_stream(c, stream);
 }
 
-// ------------------------------------------------------------------------------------------------
-// bit-stream layer.  These calls need no weights: any context of the device will do.
-// ------------------------------------------------------------------------------------------------
-static int check_dev(ldc_ctx* c) {
+
+// calls that need no weights (bit-stream layer, resampler, tuning aids): any context of the device will do
+int check_dev(ldc_ctx* c) {
   if (!c) return fail(LDC_E_INVALID, "null ctx");
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail(LDC_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
-  return LDC_OK;
-}
-
-extern "C" int64_t ldc_packed_bytes(int n_q, int F, int bits) { return ((int64_t)n_q * F * bits + 7) / 8; }
-
-extern "C" int ldc_pack_codes(ldc_ctx* c, const int64_t* codes, int n_q, int B, int F, int bits, uint8_t* out, int64_t out_stride,
-                              void* stream) {
-  LDCCHK(check_dev(c));
-  if (!codes || !out || n_q < 1 || B < 1 || F < 0 || bits < 1 || bits > 24) return fail(LDC_E_INVALID, "bad arguments (bits must be in [1,24])");
-  if (out_stride < ldc_packed_bytes(n_q, F, bits)) return fail(LDC_E_INVALID, "out_stride %lld < %lld packed bytes per item", (long long)out_stride, (long long)ldc_packed_bytes(n_q, F, bits));
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_pack_codes(codes, n_q, B, F, bits, out, out_stride, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_unpack_codes(ldc_ctx* c, const uint8_t* in, int64_t in_stride, int n_q, int B, int F, int bits, int64_t* codes_out,
-                                void* stream) {
-  LDCCHK(check_dev(c));
-  if (!in || !codes_out || n_q < 1 || B < 1 || F < 0 || bits < 1 || bits > 24) return fail(LDC_E_INVALID, "bad arguments (bits must be in [1,24])");
-  if (in_stride < ldc_packed_bytes(n_q, F, bits)) return fail(LDC_E_INVALID, "in_stride smaller than the packed size: the stream ended sooner than expected");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_unpack_codes(in, in_stride, n_q, B, F, bits, codes_out, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_ac_build_cdf(ldc_ctx* c, const float* pdf, int rows, int card, int total_range_bits, float roundoff, int min_range,
-                                int32_t* cdf_out, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!pdf || !cdf_out || rows < 1 || card < 1) return fail(LDC_E_INVALID, "bad arguments");
-  if (total_range_bits < 2 || total_range_bits > 30) return fail(LDC_E_INVALID, "total_range_bits must be <= 30 (ac.py:98)");
-  if (min_range < 2) return fail(LDC_E_INVALID, "min_range must be at least 2. (ac.py:47-48)");
-  if ((double)min_range * card > (double)(1ll << total_range_bits)) return fail(LDC_E_INVALID, "you must reduce min_range (ac.py:43)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_build_cdf(pdf, rows, card, total_range_bits, roundoff, min_range, cdf_out, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_ac_encode(ldc_ctx* c, const int32_t* symbols, const int32_t* cdf, int B, int S, int card, int n_static,
-                             int total_range_bits, uint8_t* out, int64_t out_stride, int64_t* nbytes_out, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!symbols || !cdf || !out || !nbytes_out || B < 1 || S < 0 || card < 1 || n_static < 0 || out_stride < 1) return fail(LDC_E_INVALID, "bad arguments");
-  if (total_range_bits < 2 || total_range_bits > 30) return fail(LDC_E_INVALID, "total_range_bits must be <= 30 (ac.py:98)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_ac_encode(symbols, cdf, B, S, card, n_static ? 1 : 0, std::max(1, n_static), total_range_bits, out, out_stride, out_stride,
-                          nbytes_out, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_ac_decode(ldc_ctx* c, const uint8_t* in, int64_t in_stride, const int64_t* nbytes, const int32_t* cdf, int B, int S,
-                             int card, int n_static, int total_range_bits, int32_t* symbols_out, int32_t* status_out, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!in || !nbytes || !cdf || !symbols_out || !status_out || B < 1 || S < 0 || card < 1 || n_static < 0) return fail(LDC_E_INVALID, "bad arguments");
-  if (total_range_bits < 2 || total_range_bits > 30) return fail(LDC_E_INVALID, "total_range_bits must be <= 30 (ac.py:98)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_ac_decode(in, in_stride, nbytes, cdf, B, S, card, n_static ? 1 : 0, std::max(1, n_static), total_range_bits, symbols_out,
-                          status_out, s));
-  return finish_stream(c, stream);
-}
-
-// ------------------------------------------------------------------------------------------------
-// audio front end: torchaudio.functional.resample as srcs/sample.py:84 calls it
-// ------------------------------------------------------------------------------------------------
-static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
-
-extern "C" int64_t ldc_resample_out_len(int64_t T, int orig_freq, int new_freq) {
-  if (orig_freq <= 0 || new_freq <= 0 || T < 0) return -1;
-  const int g = gcd_i(orig_freq, new_freq);
-  const int64_t orig = orig_freq / g, nnew = new_freq / g;
-  return (nnew * T + orig - 1) / orig;       // ceil(new * T / orig), torchaudio's target_length
-}
-
-extern "C" int ldc_resample(ldc_ctx* c, const float* wav, int C, int64_t T, int orig_freq, int new_freq, float* out, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!wav || !out || C < 1 || T < 1 || orig_freq <= 0 || new_freq <= 0) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  if (orig_freq == new_freq) {
-    HIPCHK(hipMemcpyAsync(out, wav, (size_t)C * T * 4, hipMemcpyDeviceToDevice, s));
-    return finish_stream(c, stream);
-  }
-  const int g = gcd_i(orig_freq, new_freq);
-  const int orig = orig_freq / g, nnew = new_freq / g;
-  // torchaudio 0.13 _get_sinc_resample_kernel: lowpass_filter_width 6, rolloff 0.99, Hann window, built in float64
-  const double lpw = 6.0, rolloff = 0.99, pi = 3.14159265358979323846;
-  const double base_freq = std::min(orig, nnew) * rolloff;
-  const int width = (int)ceil(lpw * orig / base_freq);
-  const int K = 2 * width + orig;
-  if ((double)nnew * K > 64e6) return fail(LDC_E_INVALID, "resampling %d -> %d needs a %d x %d filter bank: rates too incommensurate", orig_freq, new_freq, nnew, K);
-  std::vector<float> bank((size_t)nnew * K);
-  const double scale = base_freq / orig;
-  for (int p = 0; p < nnew; ++p)
-    for (int k = 0; k < K; ++k) {
-      double t = ((double)(-p) / nnew + (double)(k - width) / orig) * base_freq;
-      t = std::max(-lpw, std::min(lpw, t));
-      const double win = cos(t * pi / lpw / 2.0);
-      const double tp = t * pi;
-      const double sinc = tp == 0.0 ? 1.0 : sin(tp) / tp;
-      bank[(size_t)p * K + k] = (float)(sinc * win * win * scale);
-    }
-  const int64_t target = ldc_resample_out_len(T, orig_freq, new_freq);
-  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
-    float* dbank = (float*)ar.alloc(bank.size() * 4);
-    if (!dry) {
-      // (pageable host memory: the copy is staged before the call returns, `bank` may go out of scope)
-      HIPCHK(hipMemcpyAsync(dbank, bank.data(), bank.size() * 4, hipMemcpyHostToDevice, s));
-      HIPCHK(hipStreamSynchronize(s));
-      HIPCHK(launch_resample(wav, C, T, dbank, orig, nnew, width, target, out, s));
-    }
-    return LDC_OK;
-  }));
-  return finish_stream(c, stream);
-}
-
-// ------------------------------------------------------------------------------------------------
-// training step, first slice
-// ------------------------------------------------------------------------------------------------
-extern "C" int ldc_train_q_sample(ldc_ctx* c, const float* x0, const int64_t* t, const float* noise, int B, int C, int L, float* x_t,
-                                  void* stream) {
-  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
-  if (!x0 || !t || !noise || !x_t || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_q_sample(x0, noise, t, c->sqrt_alphas_cumprod, c->sqrt_one_minus_alphas_cumprod, B, (int64_t)C * L, x_t, c->unet.timesteps, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_num_timesteps(ldc_ctx* c) { return c ? c->unet.timesteps : 0; }
-
-extern "C" int ldc_train_predict_x_start(ldc_ctx* c, const float* x_t, const float* eps, const int64_t* t, int B, int C, int L, float* x0_out,
-                                         void* stream) {
-  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
-  if (!x_t || !eps || !t || !x0_out || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_predict_x_start(x_t, eps, t, c->sched.sqrt_recip_alphas_cumprod, c->sched.sqrt_recipm1_alphas_cumprod, B, (int64_t)C * L, x0_out,
-                                c->unet.timesteps, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_neg_sdsdr(ldc_ctx* c, const float* est, const float* tgt, int B, int64_t n_per_item, float clip_min, float* per_item_out,
-                                   void* stream) {
-  LDCCHK(check_dev(c));
-  if (!est || !tgt || !per_item_out || B < 1 || n_per_item < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_neg_sdsdr(est, tgt, B, n_per_item, clip_min, per_item_out, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_l1_loss(ldc_ctx* c, const float* model_out, const float* target, const int64_t* t, int B, int C, int L,
-                                 float* loss_out, float* grad_out, void* stream) {
-  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
-  if (!model_out || !target || !t || !loss_out || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
-    void* ws = ar.alloc(l1_loss_ws_bytes(B));
-    if (!dry) HIPCHK(launch_l1_loss(model_out, target, t, c->p2_loss_weight, B, (int64_t)C * L, loss_out, grad_out, ws, c->unet.timesteps, s));
-    return LDC_OK;
-  }));
-  return finish_stream(c, stream);
-}
-
-extern "C" int64_t ldc_train_block_ws_floats(int B, int Cin, int Cout, int L, int groups) {
-  return (int64_t)train_block_ws_floats(B, Cin, Cout, L, groups);
-}
-
-extern "C" int ldc_train_block_forward(ldc_ctx* c, const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
-                                       const float* scale_shift, int B, int Cin, int Cout, int L, int groups, float* y, float* ws,
-                                       void* stream) {
-  LDCCHK(check_dev(c));
-  if (!x || !w || !gamma || !beta || !y || !ws || B < 1 || Cin < 1 || Cout < 1 || L < 1 || groups < 1 || Cout % groups)
-    return fail(LDC_E_INVALID, "bad arguments (Cout must be a multiple of groups)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_block_forward(x, w, bias, gamma, beta, scale_shift, B, Cin, Cout, L, groups, y, ws, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_block_backward(ldc_ctx* c, const float* dy, const float* x, const float* gamma, const float* beta,
-                                        const float* scale_shift, int B, int Cin, int Cout, int L, int groups, float* ws, float* dx,
-                                        float* dw, float* db, float* dgamma, float* dbeta, float* dscale_shift, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!dy || !x || !gamma || !beta || !ws || !dw || !db || !dgamma || !dbeta || B < 1 || Cout % groups) return fail(LDC_E_INVALID, "bad arguments");
-  if (scale_shift && !dscale_shift) return fail(LDC_E_INVALID, "dscale_shift is required when scale_shift was given");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_block_backward(dy, x, gamma, beta, scale_shift, B, Cin, Cout, L, groups, ws, dx, dw, db, dgamma, dbeta,
-                                     scale_shift ? dscale_shift : nullptr, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_pointwise_forward(ldc_ctx* c, const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L,
-                                           int pre_silu, float* y, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!x || !w || !y || B < 1 || Cin < 1 || Cout < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_pw_forward(x, w, bias, B, Cin, Cout, L, pre_silu ? 1 : 0, y, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_pointwise_backward(ldc_ctx* c, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L,
-                                            int pre_silu, float* dx, float* dw, float* db, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!dy || !x || !w || !dw || B < 1 || Cin < 1 || Cout < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_pw_backward(dy, x, w, B, Cin, Cout, L, pre_silu ? 1 : 0, dx, dw, db, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int64_t ldc_train_linattn_ws_floats(int B, int heads, int dim_head, int N) {
-  return (int64_t)train_linattn_ws_floats(B, heads, dim_head, N);
-}
-
-extern "C" int ldc_train_linattn_forward(ldc_ctx* c, const float* qkv, int B, int heads, int dim_head, int N, float* out, float* ws, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!qkv || !out || !ws || B < 1 || heads < 1 || N < 1 || dim_head < 1 || dim_head > 64 || 256 % dim_head)
-    return fail(LDC_E_INVALID, "bad arguments (dim_head must divide 256 and be <= 64)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_linattn_forward(qkv, B, heads, dim_head, N, out, ws, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_linattn_backward(ldc_ctx* c, const float* dout, const float* qkv, int B, int heads, int dim_head, int N, float* ws,
-                                          float* dqkv, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!dout || !qkv || !ws || !dqkv || B < 1 || heads < 1 || N < 1 || dim_head < 1 || dim_head > 64 || 256 % dim_head)
-    return fail(LDC_E_INVALID, "bad arguments (dim_head must divide 256 and be <= 64)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_linattn_backward(dout, qkv, B, heads, dim_head, N, ws, dqkv, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_conv_forward(ldc_ctx* c, const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int Lin, int K,
-                                      int stride, int pad, float* y, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!x || !w || !y || B < 1 || Cin < 1 || Cout < 1 || Lin < 1 || K < 1 || stride < 1 || pad < 0 || (Lin + 2 * pad - K) / stride + 1 < 1)
-    return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_conv_forward(x, w, bias, B, Cin, Cout, Lin, K, stride, pad, y, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_conv_backward(ldc_ctx* c, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int Lin, int K,
-                                       int stride, int pad, float* dx, float* dw, float* db, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!dy || !x || !w || !dw || B < 1 || Cin < 1 || Cout < 1 || Lin < 1 || K < 1 || stride < 1 || pad < 0 || (Lin + 2 * pad - K) / stride + 1 < 1)
-    return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_conv_backward(dy, x, w, B, Cin, Cout, Lin, K, stride, pad, dx, dw, db, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_upsample2(ldc_ctx* c, const float* in, int64_t rows, int L, int backward, float* out, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!in || !out || rows < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_upsample2(in, rows, L, backward ? 1 : 0, out, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_activation(ldc_ctx* c, const float* x, const float* dy, int64_t n, int kind, float* out, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!x || !out || n < 1 || kind < 0 || kind > 2) return fail(LDC_E_INVALID, "bad arguments (kind: 0 tanh, 1 GELU, 2 SiLU)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_act(x, dy, n, kind, out, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int64_t ldc_train_attn_ws_floats(int B, int heads, int N) { return (int64_t)train_attn_ws_floats(B, heads, N); }
-
-extern "C" int ldc_train_attn_forward(ldc_ctx* c, const float* qkv, int B, int heads, int dim_head, int N, float* out, float* ws, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!qkv || !out || !ws || B < 1 || heads < 1 || N < 1 || dim_head < 1 || dim_head > 64 || 256 % dim_head)
-    return fail(LDC_E_INVALID, "bad arguments (dim_head must divide 256 and be <= 64)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_attn_forward(qkv, B, heads, dim_head, N, out, ws, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_attn_backward(ldc_ctx* c, const float* dout, const float* qkv, int B, int heads, int dim_head, int N, float* ws,
-                                       float* dqkv, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!dout || !qkv || !ws || !dqkv || B < 1 || heads < 1 || N < 1 || dim_head < 1 || dim_head > 64 || 256 % dim_head)
-    return fail(LDC_E_INVALID, "bad arguments (dim_head must divide 256 and be <= 64)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_attn_backward(dout, qkv, B, heads, dim_head, N, ws, dqkv, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_convtr_forward(ldc_ctx* c, const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int L, int ratio,
-                                        float* y, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!x || !w || !y || B < 1 || Cin < 1 || Cout < 1 || L < 1 || ratio < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_convtr_forward(x, w, bias, B, Cin, Cout, L, ratio, y, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_convtr_backward(ldc_ctx* c, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int L, int ratio,
-                                         float* dx, float* dw, float* db, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!dy || !x || !w || !dw || B < 1 || Cin < 1 || Cout < 1 || L < 1 || ratio < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_convtr_backward(dy, x, w, B, Cin, Cout, L, ratio, dx, dw, db, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_maxscale(ldc_ctx* c, const float* x, const float* dy, int B, int64_t n_per_item, float* out, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!x || !out || B < 1 || n_per_item < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_maxscale(x, dy, B, n_per_item, out, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_adam_step(ldc_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
-                                   float lr, float beta1, float beta2, float eps, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
-    return fail(LDC_E_INVALID, "bad arguments (step counts from 1)");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_adam(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_layernorm_forward(ldc_ctx* c, const float* x, const float* g, int B, int C, int L, float* y, float* stats, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!x || !g || !y || !stats || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_ln_forward(x, g, B, C, L, y, stats, s));
-  return finish_stream(c, stream);
-}
-
-extern "C" int ldc_train_layernorm_backward(ldc_ctx* c, const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L,
-                                            float* dx, float* dg, void* stream) {
-  LDCCHK(check_dev(c));
-  if (!dy || !x || !g || !stats || !dx || !dg || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");
-  hipStream_t s = pick_stream(c, stream);
-  HIPCHK(launch_train_ln_backward(dy, x, g, stats, B, C, L, dx, dg, s));
-  return finish_stream(c, stream);
-}
-
-// ------------------------------------------------------------------------------------------------
-// L1 primitives for the parity tests
-// ------------------------------------------------------------------------------------------------
-static int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-extern "C" int ldc_sconv1d(ldc_ctx* c, const float* x, int B, int Cin, int L, const float* w_host, const float* b_host,
-                           int Cout, int k, int stride, int dilation, int causal, int pre_elu, float* y, void* stream) {
-  if (!c || !x || !w_host || !y) return fail(LDC_E_INVALID, "null argument");
-  if (B <= 0 || Cin <= 0 || L <= 0 || Cout <= 0 || k <= 0 || stride <= 0 || dilation <= 0) return fail(LDC_E_INVALID, "bad sizes");
-  HIPCHK(hipSetDevice(c->device));
-  hipStream_t s = pick_stream(c, stream);
-  const int cp = round_up(Cin, 16);
-  std::vector<float> wp((size_t)Cout * cp * k, 0.f);
-  for (int o = 0; o < Cout; ++o)
-    for (int i = 0; i < Cin; ++i)
-      for (int t = 0; t < k; ++t) wp[((size_t)o * cp + i) * k + t] = w_host[((size_t)o * Cin + i) * k + t];
-  DevMem keep;
-  std::swap(keep.ptrs, c->wmem.ptrs);   // make_conv allocates from c->wmem; give it a temporary pool
-  ConvLayer ly;
-  ConvSpec sp;
-  sp.dt = DT_F32; sp.cin1 = cp; sp.cout = Cout; sp.k = k; sp.stride = stride; sp.dil = dilation;
-  const int padding_total = (k - 1) * dilation - (stride - 1);
-  sp.pad_left = causal ? padding_total : padding_total - padding_total / 2;
-  sp.pad_mode = PAD_REFLECT; sp.pre_act = pre_elu ? ACT_ELU : ACT_NONE;
-  int rc = make_conv(c, sp, wp.data(), b_host, &ly);
-  std::swap(keep.ptrs, c->wmem.ptrs);   // `keep` now owns the temporaries and frees them on return
-  LDCCHK(rc);
-  const int Lout = conv_out_len(ly, L);
-  if (L <= sp.pad_left) return fail(LDC_E_INVALID, "input shorter than the reflect padding is not supported (L=%d pad=%d)", L, sp.pad_left);
-  void *xc = nullptr, *yc = nullptr;
-  LDCCHK(keep.alloc(&xc, (size_t)B * L * cp * 4));
-  LDCCHK(keep.alloc(&yc, (size_t)B * Lout * Cout * 4));
-  HIPCHK(hipMemsetAsync(xc, 0, (size_t)B * L * cp * 4, s));
-  // [B][Cin][L] -> rows [B*L][cp]: transpose into the first Cin columns
-  {
-    void* tmp = nullptr;
-    LDCCHK(keep.alloc(&tmp, (size_t)B * L * Cin * 4));
-    HIPCHK(launch_to_cl(DT_F32, x, tmp, B, Cin, L, nullptr, 0, 0.f, s));
-    HIPCHK(hipMemcpy2DAsync(xc, (size_t)cp * 4, tmp, (size_t)Cin * 4, (size_t)Cin * 4, (size_t)B * L, hipMemcpyDeviceToDevice, s));
-  }
-  ConvCall cc;
-  cc.B = B; cc.L_in = L; cc.L_rows = Lout; cc.x1 = xc; cc.y = yc; cc.y_ld = Cout;
-  HIPCHK(launch_conv(ly, cc, s));
-  HIPCHK(launch_from_cl(DT_F32, yc, y, B, Cout, Lout, nullptr, 0, 0.f, s));
-  HIPCHK(hipStreamSynchronize(s));
-  return LDC_OK;
-}
-
-extern "C" int ldc_sconvtr1d(ldc_ctx* c, const float* x, int B, int Cin, int L, const float* w_host, const float* b_host,
-                             int Cout, int k, int stride, int causal, float* y, void* stream) {
-  if (!c || !x || !w_host || !y) return fail(LDC_E_INVALID, "null argument");
-  if (k != 2 * stride) return fail(LDC_E_INVALID, "only kernel_size == 2*stride transposed convs exist on the decode path");
-  HIPCHK(hipSetDevice(c->device));
-  hipStream_t s = pick_stream(c, stream);
-  const int cp = round_up(Cin, 16);
-  std::vector<float> wp((size_t)cp * Cout * k, 0.f);
-  memcpy(wp.data(), w_host, (size_t)Cin * Cout * k * 4);
-  DevMem keep;
-  std::swap(keep.ptrs, c->wmem.ptrs);
-  ConvLayer ly;
-  const int padding_total = k - stride;
-  const int trim_left = causal ? 0 : padding_total - padding_total / 2;
-  int rc = make_convtr(c, DT_F32, cp, Cout, stride, trim_left, ACT_NONE, wp.data(), b_host, &ly);
-  std::swap(keep.ptrs, c->wmem.ptrs);
-  LDCCHK(rc);
-  const int Lout = L * stride;
-  void *xc = nullptr, *yc = nullptr, *tmp = nullptr;
-  LDCCHK(keep.alloc(&xc, (size_t)B * L * cp * 4));
-  LDCCHK(keep.alloc(&yc, (size_t)B * Lout * Cout * 4));
-  LDCCHK(keep.alloc(&tmp, (size_t)B * L * Cin * 4));
-  HIPCHK(hipMemsetAsync(xc, 0, (size_t)B * L * cp * 4, s));
-  HIPCHK(launch_to_cl(DT_F32, x, tmp, B, Cin, L, nullptr, 0, 0.f, s));
-  HIPCHK(hipMemcpy2DAsync(xc, (size_t)cp * 4, tmp, (size_t)Cin * 4, (size_t)Cin * 4, (size_t)B * L, hipMemcpyDeviceToDevice, s));
-  ConvCall cc;
-  cc.B = B; cc.L_in = L; cc.L_rows = L + 1; cc.L_final = Lout; cc.x1 = xc; cc.y = yc; cc.y_ld = Cout;
-  HIPCHK(launch_conv(ly, cc, s));
-  HIPCHK(launch_from_cl(DT_F32, yc, y, B, Cout, Lout, nullptr, 0, 0.f, s));
-  HIPCHK(hipStreamSynchronize(s));
-  return LDC_OK;
-}
-
-extern "C" int ldc_slstm(ldc_ctx* c, const float* x, int B, int H, int T, const float* const* weights_host, int layers,
-                         float* y, void* stream) {
-  if (!c || !x || !weights_host || !y) return fail(LDC_E_INVALID, "null argument");
-  if (H % 16) return fail(LDC_E_INVALID, "H must be a multiple of 16");
-  HIPCHK(hipSetDevice(c->device));
-  hipStream_t s = pick_stream(c, stream);
-  // stage the weights as a throw-away state dict so that build_lstm can be reused
-  ldc_ctx tmpc;
-  tmpc.cfg = c->cfg;
-  tmpc.device = c->device;
-  tmpc.own_stream = c->own_stream;
-  for (int n = 0; n < layers; ++n) {
-    const char* names[4] = {"weight_ih_l", "weight_hh_l", "bias_ih_l", "bias_hh_l"};
-    for (int j = 0; j < 4; ++j) {
-      HostTensor t;
-      if (j < 2) t.shape = {4 * H, H};
-      else t.shape = {4 * H};
-      t.data.assign(weights_host[4 * n + j], weights_host[4 * n + j] + t.numel());
-      tmpc.raw[0][std::string("p.lstm.") + names[j] + std::to_string(n)] = std::move(t);
-    }
-  }
-  WeightReader wr{&tmpc, 0, ""};
-  SeaOp op;
-  op.kind = SeaOp::LSTM; op.cin = op.cout = H;
-  int rc = build_lstm(&tmpc, wr, "p", H, layers, &op.lstm);
-  tmpc.own_stream = nullptr;
-  LDCCHK(rc);
-  if (!wr.missing.empty()) return fail(LDC_E_INVALID, "internal: %s", wr.missing.c_str());
-  std::vector<SeaOp> ops{op};
-  int ret = with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
-    SeaRun R{c, &ar, s, dry, B};
-    void* xc = ar.alloc((size_t)B * T * H * 4);
-    if (!dry) HIPCHK(launch_to_cl(DT_F32, x, xc, B, H, T, nullptr, 0, 0.f, s));
-    void* o = nullptr;
-    int Lo = 0, C = 0;
-    LDCCHK(run_seanet(R, ops, xc, T, &o, &Lo, &C));
-    if (!dry) HIPCHK(launch_from_cl(DT_F32, o, y, B, H, T, nullptr, 0, 0.f, s));
-    return LDC_OK;
-  });
-  hipError_t e = hipStreamSynchronize(s);
-  if (ret != LDC_OK) return ret;
-  if (e != hipSuccess) return fail(LDC_E_HIP, "sync failed: %s", hipGetErrorString(e));
-  return LDC_OK;   // tmpc.wmem frees the temporaries
-}
-
-// ------------------------------------------------------------------------------------------------
-// accounting / profiling
-// ------------------------------------------------------------------------------------------------
-extern "C" int ldc_unet_step_cost(ldc_ctx* c, int B, int L, double* flops, double* bytes) {
-  LDCCHK(check_ready(c, LDC_MODEL_MAIN));
-  const int F = L / std::max(1, upsample_factor(c));
-  LDCCHK(check_unet_args(c, B, L, F));
-  Plan tmp;
-  Arena measure;
-  LDCCHK(build_plan(c, &tmp, measure, B, L, F));
-  if (flops) *flops = tmp.flops;
-  // algorithmic bytes with perfect intra-block fusion: every conv-boundary activation
-  // read + written once, the weights once per step
-  // algorithmic bytes of the conv-GEMM launches of one step: every conv reads its input(s) and packed weights once
-  // and writes its output once
-  if (bytes) *bytes = tmp.conv_bytes;
-  return LDC_OK;
-}
-
-// Timeline of the TIMED mode.  rocprofv3's kernel trace serialises the batch parts' streams (measured: overlap factor
-// 1.01 under the tracer against 1.5 untraced), so the evidence is taken on the device: the first and last kernel of every
-// step of every batch part stamp a constant-rate clock.  Toggling drops the captured graphs (the stamp pointer is a
-// kernel argument).
-// Tuning aid: which XCCs (dies) the workgroups of a launch land on when its stream is created with a CU mask
-// (hipExtStreamCreateWithCUMask): `wgs` workgroups each record HW_REG_XCC_ID; hist[x] = workgroups seen on XCC x.  mask == NULL: no mask.
-__global__ void xcc_census_kernel(int* out, int spin) {
-  if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 0xf);
-  for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(8);   // keep workgroups resident so that the launch spreads
-}
-extern "C" int ldc_xcc_census(ldc_ctx* c, const uint32_t* mask, int n_words, int wgs, int* hist16) {
-  if (!c || !hist16 || wgs < 1 || wgs > (1 << 16)) return fail(LDC_E_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(c->device));
-  hipStream_t st = nullptr;
-  if (mask && n_words > 0) HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask));
-  else HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  int* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, (size_t)wgs * sizeof(int)));
-  HIPCHK(hipMemsetAsync(d, 0xff, (size_t)wgs * sizeof(int), st));
-  hipLaunchKernelGGL(xcc_census_kernel, dim3(wgs), dim3(64), 0, st, d, 64);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(st));
-  std::vector<int> h((size_t)wgs);
-  HIPCHK(hipMemcpy(h.data(), d, h.size() * sizeof(int), hipMemcpyDeviceToHost));
-  for (int i = 0; i < 16; ++i) hist16[i] = 0;
-  for (int v : h) if (v >= 0 && v < 16) ++hist16[v];
-  (void)hipFree(d);
-  (void)hipStreamDestroy(st);
-  return LDC_OK;
-}
-
-extern "C" int ldc_host_stats(ldc_ctx* c, int reset, double* graph_launch_ms, double* lookahead_wait_ms, int64_t* graph_launches) {
-  if (!c) return fail(LDC_E_INVALID, "null context");
-  if (graph_launch_ms) *graph_launch_ms = c->host_graph_ms;
-  if (lookahead_wait_ms) *lookahead_wait_ms = c->host_wait_ms;
-  if (graph_launches) *graph_launches = c->host_graph_launches;
-  if (reset) { c->host_graph_ms = 0; c->host_wait_ms = 0; c->host_graph_launches = 0; }
-  return LDC_OK;
-}
-
-extern "C" int ldc_timeline_enable(ldc_ctx* c, int on) {
-  if (!c) return fail(LDC_E_INVALID, "null ctx");
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(counted_device_sync());
-  for (auto& g : c->graphs) g.destroy();
-  c->graphs.clear();
-  if (on && !c->tl_buf) {
-    void* p = nullptr;
-    HIPCHK(hipMalloc(&p, (size_t)kMaxParts * 2048 * 2 * sizeof(unsigned long long)));
-    c->tl_buf = (unsigned long long*)p;
-  }
-  if (on) HIPCHK(hipMemset(c->tl_buf, 0, (size_t)kMaxParts * 2048 * 2 * sizeof(unsigned long long)));
-  c->timeline = on != 0;
-  return LDC_OK;
-}
-
-// Per-launch stamps of the pipelined conv kernel in the timed mode: plans are rebuilt with (or without) a stamp buffer.
-extern "C" int ldc_kstamps_enable(ldc_ctx* c, int on) {
-  if (!c) return fail(LDC_E_INVALID, "null ctx");
-  HIPCHK(hipSetDevice(c->device));
-  drop_plans(c);
-  c->kstamps = on != 0;
-  return LDC_OK;
-}
-// re-arm the stamp buffers of every cached plan (all-ones: both fields are kept as minima)
-extern "C" int ldc_kstamps_reset(ldc_ctx* c) {
-  if (!c) return fail(LDC_E_INVALID, "null ctx");
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(counted_device_sync());
-  for (auto& p : c->plans)
-    if (p->kst) HIPCHK(hipMemset(p->kst, 0xff, (size_t)2048 * kKstOps * 2 * 8));
-  return LDC_OK;
-}
-// Plan `idx` (in creation order: the batch parts of the last shape decoded).  ticks: [n_steps][n_ops][2] begin / end in 100 MHz ticks
-// (0 / 0 where the op is not a pipelined conv); infos: n_ops strings of `info_cap` bytes (the op descriptions of the profile dump);
-// classes: n_ops LDC_CLASS_* codes.  Returns the number of ops of a step through n_ops when ticks == NULL.
-extern "C" int ldc_kstamps_read(ldc_ctx* c, int idx, int n_steps, int* n_ops, uint64_t* ticks, char* infos, int info_cap, int* classes) {
-  if (!c || idx < 0 || idx >= (int)c->plans.size() || !n_ops) return fail(LDC_E_INVALID, "bad arguments");
-  Plan* pl = c->plans[idx].get();
-  if (!pl->kst) return fail(LDC_E_STATE, "ldc_kstamps_enable has not been called");
-  const int nops = (int)std::min<size_t>(pl->step_ops.size(), kKstOps);
-  *n_ops = nops;
-  if (!ticks) return LDC_OK;
-  if (n_steps < 1 || n_steps > 2048) return fail(LDC_E_INVALID, "n_steps must be in [1, 2048]");
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(counted_device_sync());
-  std::vector<unsigned long long> h((size_t)n_steps * kKstOps * 2);
-  HIPCHK(hipMemcpy(h.data(), pl->kst, h.size() * 8, hipMemcpyDeviceToHost));
-  for (int j = 0; j < n_steps; ++j)
-    for (int o = 0; o < nops; ++o) {
-      const unsigned long long b = h[((size_t)j * kKstOps + o) * 2], e = h[((size_t)j * kKstOps + o) * 2 + 1];
-      const bool set = b != ~0ull && e != ~0ull && ~e >= b;
-      ticks[((size_t)j * nops + o) * 2] = set ? b : 0;
-      ticks[((size_t)j * nops + o) * 2 + 1] = set ? ~e : 0;
-    }
-  for (int o = 0; o < nops; ++o) {
-    if (infos && info_cap > 0) snprintf(infos + (size_t)o * info_cap, info_cap, "%s", pl->step_info[o].c_str());
-    if (classes) classes[o] = pl->step_class[o];
-  }
-  return LDC_OK;
-}
-
-// ticks[2 * j] / ticks[2 * j + 1]: begin / end of step j (iteration index of the last sampler call) of batch part `part`,
-// in 100 MHz ticks; n <= 2048 steps
-extern "C" int ldc_timeline_read(ldc_ctx* c, int part, int n, uint64_t* ticks) {
-  if (!c || !ticks || part < 0 || part >= kMaxParts || n < 1 || n > 2048) return fail(LDC_E_INVALID, "bad arguments");
-  if (!c->tl_buf) return fail(LDC_E_STATE, "ldc_timeline_enable has not been called");
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(counted_device_sync());
-  HIPCHK(hipMemcpy(ticks, c->tl_buf + (size_t)part * 2048 * 2, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  return LDC_OK;
-}
-
-extern "C" int ldc_profile_enable(ldc_ctx* c, int on) {
-  if (!c) return fail(LDC_E_INVALID, "null ctx");
-  c->profile = on != 0;
-  if (on) {
-    for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    c->prof_events.clear();
-    c->prof_event_flops.clear(); c->prof_event_class.clear(); c->prof_event_bytes.clear(); c->prof_event_info.clear();
-    c->prof_ms = 0; c->prof_flops = 0; c->prof_launches = 0;
-    for (int k = 0; k < LDC_N_CLASSES; ++k) { c->cls_ms[k] = c->cls_flops[k] = c->cls_bytes[k] = 0; c->cls_launches[k] = 0; }
-  }
-  return LDC_OK;
-}
-
-static int profile_collect(ldc_ctx* c) {
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(counted_device_sync());
-  FILE* dump = getenv("LDC_PROFILE_DUMP") && !c->prof_events.empty() ? fopen(getenv("LDC_PROFILE_DUMP"), "a") : nullptr;
-  for (size_t i = 0; i < c->prof_events.size(); ++i) {
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
-    const int k = c->prof_event_class[i];
-    if (dump) fprintf(dump, "%d %.0f %.0f %.3f %s\n", k, c->prof_event_flops[i], c->prof_event_bytes[i], ms * 1e3, c->prof_event_info[i].c_str());
-    c->cls_ms[k] += ms; c->cls_flops[k] += c->prof_event_flops[i]; c->cls_bytes[k] += c->prof_event_bytes[i]; c->cls_launches[k] += 1;
-    if (k == LDC_CLASS_CONV) {
-      c->prof_ms += ms;
-      c->prof_flops += c->prof_event_flops[i];
-      c->prof_launches += 1;
-    }
-    (void)hipEventDestroy(c->prof_events[i].first);
-    (void)hipEventDestroy(c->prof_events[i].second);
-  }
-  if (dump) fclose(dump);
-  c->prof_events.clear();
-  c->prof_event_flops.clear(); c->prof_event_class.clear(); c->prof_event_bytes.clear(); c->prof_event_info.clear();
-  return LDC_OK;
-}
-
-extern "C" int ldc_profile_read_classes(ldc_ctx* c, int n, double* ms, int64_t* launches, double* flops, double* bytes) {
-  if (!c || n < 1) return fail(LDC_E_INVALID, "bad arguments");
-  LDCCHK(profile_collect(c));
-  for (int k = 0; k < n && k < LDC_N_CLASSES; ++k) {
-    if (ms) ms[k] = c->cls_ms[k];
-    if (launches) launches[k] = c->cls_launches[k];
-    if (flops) flops[k] = c->cls_flops[k];
-    if (bytes) bytes[k] = c->cls_bytes[k];
-  }
-  return LDC_OK;
-}
-
-extern "C" int ldc_profile_read(ldc_ctx* c, double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total) {
-  if (!c) return fail(LDC_E_INVALID, "null ctx");
-  LDCCHK(profile_collect(c));
-  if (conv_ms_total) *conv_ms_total = c->prof_ms;
-  if (conv_launches) *conv_launches = c->prof_launches;
-  if (conv_flops_total) *conv_flops_total = c->prof_flops;
-  return LDC_OK;
-}
-
-namespace ldc { extern unsigned long long* g_conv_stamps; }
-
-// uniform [-1, 1) values of the given dtype (host LCG, uploaded)
-static int fill_random(void* dev, size_t n, int dt, unsigned seed) {
-  const size_t es = dt_size(dt);
-  std::vector<char> h(n * es);
-  for (size_t i = 0; i < n; ++i) {
-    seed = seed * 1664525u + 1013904223u;
-    const float v = ((seed >> 8) * (1.0f / 8388608.0f)) - 1.0f;
-    if (dt == DT_F32) {
-      reinterpret_cast<float*>(h.data())[i] = v;
-    } else {
-      uint32_t u;
-      memcpy(&u, &v, 4);
-      reinterpret_cast<uint16_t*>(h.data())[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-    }
-  }
-  HIPCHK(hipMemcpy(dev, h.data(), h.size(), hipMemcpyHostToDevice));
-  return LDC_OK;
-}
-
-
-extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride,
-                                   int ups, int iters, double* ms_per_launch) {
-  if (!c || !ms_per_launch || iters < 1) return fail(LDC_E_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(c->device));
-  const int dt = dtype == LDC_F32 ? DT_F32 : DT_BF16;
-  const bool saved_w8 = c->w8;
-  c->w8 = dtype == LDC_BF16_W8;
-  const int cin = cin1 + cin2;
-  std::vector<float> w((size_t)cout * cin * k), bias(cout, 0.1f);
-  unsigned seed = 12345u;
-  for (auto& v : w) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f; }
-  DevMem keep;
-  std::swap(keep.ptrs, c->wmem.ptrs);
-  ConvLayer ly;
-  ConvSpec sp;
-  sp.dt = dt; sp.cin1 = cin1; sp.cin2 = cin2; sp.cout = cout; sp.k = k; sp.stride = stride; sp.ups = ups;
-  sp.pad_left = (k == 4 && stride == 2) ? 1 : (k - 1) / 2;
-  int rc = make_conv(c, sp, w.data(), bias.data(), &ly);
-  std::swap(keep.ptrs, c->wmem.ptrs);
-  c->w8 = saved_w8;
-  LDCCHK(rc);
-  const int L_out = ups ? 2 * L : (stride == 2 ? (L + 2 * sp.pad_left - k) / 2 + 1 : L);
-  const size_t es = dt_size(dt);
-  void *x1 = nullptr, *x2 = nullptr, *y = nullptr;
-  LDCCHK(keep.alloc(&x1, (size_t)B * L * cin1 * es));
-  if (cin2) LDCCHK(keep.alloc(&x2, (size_t)B * L * cin2 * es));
-  LDCCHK(keep.alloc(&y, (size_t)B * L_out * cout * es));
-  // full-range pseudo-random operands: constant or zero fills let the chip clock ~15-20 % higher than real data does
-  LDCCHK(fill_random(x1, (size_t)B * L * cin1, dt, 777u));
-  if (cin2) LDCCHK(fill_random(x2, (size_t)B * L * cin2, dt, 778u));
-  ConvCall cc;
-  cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.y_ld = cout;
-  {   // split-K workspace as the plan builder provides it
-    void *part = nullptr, *cnt = nullptr;
-    LDCCHK(keep.alloc(&part, (size_t)(8 << 20) * 4));
-    LDCCHK(keep.alloc(&cnt, 1024 * 4));
-    HIPCHK(hipMemset(cnt, 0, 1024 * 4));
-    cc.sk_part = (float*)part; cc.sk_part_cap = (long long)8 << 20; cc.sk_count = (unsigned*)cnt; cc.sk_count_cap = 1024;
-    cc.tune = &c->tune;
-  }
-  if (getenv("LDC_MB_GN")) {   // tuning aid: the fused GroupNorm statistics of the UNet's block convs (8 groups) ride along
-    void* gs = nullptr;
-    LDCCHK(keep.alloc(&gs, (size_t)B * 8 * kGnPad * 4));
-    HIPCHK(hipMemset(gs, 0, (size_t)B * 8 * kGnPad * 4));
-    cc.gn_sum = (float*)gs; cc.gn_groups = 8;
-  }
-  hipStream_t s = c->own_stream;
-  for (int i = 0; i < 3; ++i) HIPCHK(launch_conv(ly, cc, s));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) HIPCHK(launch_conv(ly, cc, s));
-  HIPCHK(hipEventRecord(e1, s));
-  HIPCHK(hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *ms_per_launch = ms / iters;
-  if (getenv("LDC_CONV_STAMPS")) {
-    const int nblk = 1 << 16;
-    void* st = nullptr;
-    LDCCHK(keep.alloc(&st, (size_t)nblk * 8 * 8));
-    HIPCHK(hipMemset(st, 0, (size_t)nblk * 8 * 8));
-    ldc::g_conv_stamps = (unsigned long long*)st;
-    hipError_t le = launch_conv(ly, cc, s);
-    ldc::g_conv_stamps = nullptr;
-    HIPCHK(le);
-    HIPCHK(hipStreamSynchronize(s));
-    std::vector<unsigned long long> h((size_t)nblk * 8);
-    HIPCHK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
-    double pro = 0, loop = 0, epi = 0, tab = 0, dma = 0; int n = 0;
-    unsigned long long t_first = ~0ull, t_last = 0;
-    int xcc_match = 0, xcc_hist[16] = {0}, xcc_of_class[8][16] = {};
-    for (int b = 0; b < nblk; ++b) {
-      if (!h[8 * b + 3]) continue;
-      xcc_match += ((int)h[8 * b + 6] == (b & 7));
-      ++xcc_hist[h[8 * b + 6] & 15];
-      ++xcc_of_class[b & 7][h[8 * b + 6] & 15];
-      t_first = std::min(t_first, h[8 * b]); t_last = std::max(t_last, h[8 * b + 3]);
-      pro += (double)(h[8 * b + 1] - h[8 * b]); loop += (double)(h[8 * b + 2] - h[8 * b + 1]); epi += (double)(h[8 * b + 3] - h[8 * b + 2]);
-      tab += (double)(h[8 * b + 4] - h[8 * b]); dma += (double)(h[8 * b + 5] - h[8 * b + 4]);
-      ++n;
-    }
-    if (n) fprintf(stderr, "  XCC id == workgroup %% 8 for %d of %d workgroups; per-XCC counts %d %d %d %d %d %d %d %d\n", xcc_match, n, xcc_hist[0], xcc_hist[1],
-                   xcc_hist[2], xcc_hist[3], xcc_hist[4], xcc_hist[5], xcc_hist[6], xcc_hist[7]);
-    if (n) {
-      fprintf(stderr, "  workgroup %% 8 -> XCC ids seen (count):");
-      for (int cl = 0; cl < 8; ++cl) {
-        fprintf(stderr, "  %d:", cl);
-        for (int x = 0; x < 16; ++x) if (xcc_of_class[cl][x]) fprintf(stderr, " %d(%d)", x, xcc_of_class[cl][x]);
-      }
-      fprintf(stderr, "\n");
-    }
-    if (n) fprintf(stderr, "  stamps (s_memtime ticks per workgroup): blocks=%d prologue=%.1f (tile+copy tables %.1f, first copies issued %.1f, fragment tables %.1f) loop=%.1f epilogue=%.1f | first start -> last end %.0f\n",
-                   n, pro / n, tab / n, dma / n, (pro - tab - dma) / n, loop / n, epi / n, (double)(t_last - t_first));
-  }
-  return LDC_OK;
-}
-
-// Self-check of the pipelined conv-GEMM: the same layer and pseudo-random operands through conv_fast.inc with tile shape
-// `tile_cfg` forced (-1: the launcher's own choice) and through the generic kernel (conv_gemm.hip, itself pinned to the
-// reference's SConv1d vectors); reports the largest output difference, the largest |reference output|, and the largest relative
-// difference of the fused GroupNorm statistics (with_gn) / the fused column maxima (with_colmax).
-extern "C" int ldc_conv_compare(ldc_ctx* c, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups,
-                                int tile_cfg, int with_gn, int with_colmax, int with_residual, double* max_abs_diff, double* max_abs_ref,
-                                double* max_rel_stat) {
-  if (!c || !max_abs_diff || !max_abs_ref || !max_rel_stat) return fail(LDC_E_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(c->device));
-  const int dt = dtype == LDC_F32 ? DT_F32 : DT_BF16;
-  const bool saved_w8 = c->w8;
-  c->w8 = dtype == LDC_BF16_W8;
-  const int cin = cin1 + cin2;
-  std::vector<float> w((size_t)cout * cin * k), bias(cout);
-  unsigned seed = 4242u;
-  for (auto& v : w) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.2f; }
-  for (auto& v : bias) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f); }
-  DevMem keep;
-  std::swap(keep.ptrs, c->wmem.ptrs);
-  ConvLayer ly;
-  ConvSpec sp;
-  sp.dt = dt; sp.cin1 = cin1; sp.cin2 = cin2; sp.cout = cout; sp.k = k; sp.stride = stride; sp.ups = ups;
-  sp.pad_left = (k == 4 && stride == 2) ? 1 : (k - 1) / 2;
-  int rc = make_conv(c, sp, w.data(), bias.data(), &ly);
-  std::swap(keep.ptrs, c->wmem.ptrs);
-  c->w8 = saved_w8;
-  LDCCHK(rc);
-  const int L_out = ups ? 2 * L : (stride == 2 ? (L + 2 * sp.pad_left - k) / 2 + 1 : L);
-  const size_t es = dt_size(dt);
-  const int groups = 8;
-  const size_t n_out = (size_t)B * L_out * cout, stat_n = (size_t)B * groups * kGnPad, cm_n = (size_t)B * cout;
-  void *x1 = nullptr, *x2 = nullptr, *res = nullptr, *y[2] = {nullptr, nullptr}, *st[2] = {nullptr, nullptr}, *cm[2] = {nullptr, nullptr};
-  LDCCHK(keep.alloc(&x1, (size_t)B * L * cin1 * es));
-  LDCCHK(fill_random(x1, (size_t)B * L * cin1, dt, 901u));
-  if (cin2) {
-    LDCCHK(keep.alloc(&x2, (size_t)B * L * cin2 * es));
-    LDCCHK(fill_random(x2, (size_t)B * L * cin2, dt, 902u));
-  }
-  if (with_residual) {
-    LDCCHK(keep.alloc(&res, n_out * es));
-    LDCCHK(fill_random(res, n_out, dt, 903u));
-  }
-  void *part = nullptr, *cnt = nullptr;
-  LDCCHK(keep.alloc(&part, (size_t)(8 << 20) * 4));
-  LDCCHK(keep.alloc(&cnt, 1024 * 4));
-  HIPCHK(hipMemset(cnt, 0, 1024 * 4));
-  hipStream_t s = c->own_stream;
-  ConvTune tune = c->tune;
-  for (int v = 0; v < 2; ++v) {
-    LDCCHK(keep.alloc(&y[v], n_out * es));
-    LDCCHK(keep.alloc(&st[v], stat_n * 4));
-    LDCCHK(keep.alloc(&cm[v], cm_n * 4));
-    HIPCHK(hipMemset(y[v], 0, n_out * es));
-    HIPCHK(hipMemset(st[v], 0, stat_n * 4));
-    HIPCHK(hipMemset(cm[v], 0, cm_n * 4));
-    tune.force_generic = v == 0 ? 1 : 0;
-    tune.force_tile = tile_cfg;
-    ConvCall cc;
-    cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y[v]; cc.y_ld = cout; cc.residual = res;
-    if (with_gn) { cc.gn_sum = (float*)st[v]; cc.gn_groups = groups; }
-    if (with_colmax) { cc.colmax = (unsigned*)cm[v]; cc.colmax_lo = 0; cc.colmax_hi = cout; cc.colmax_stride = cout; }
-    cc.sk_part = (float*)part; cc.sk_part_cap = (long long)8 << 20; cc.sk_count = (unsigned*)cnt; cc.sk_count_cap = 1024;
-    cc.tune = &tune;
-    HIPCHK(launch_conv(ly, cc, s));
-  }
-  HIPCHK(hipStreamSynchronize(s));
-  std::vector<char> h0(n_out * es), h1(n_out * es);
-  HIPCHK(hipMemcpy(h0.data(), y[0], h0.size(), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(h1.data(), y[1], h1.size(), hipMemcpyDeviceToHost));
-  auto val = [&](const std::vector<char>& h, size_t i) {
-    if (dt == DT_F32) return (double)reinterpret_cast<const float*>(h.data())[i];
-    const uint32_t u = (uint32_t)reinterpret_cast<const uint16_t*>(h.data())[i] << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return (double)f;
-  };
-  double d = 0, m = 0;
-  for (size_t i = 0; i < n_out; ++i) {
-    const double a = val(h0, i), b = val(h1, i);
-    if (!(b == b)) { d = 1e30; break; }
-    d = std::max(d, fabs(a - b));
-    m = std::max(m, fabs(a));
-  }
-  *max_abs_diff = d;
-  *max_abs_ref = m;
-  double rs = 0;
-  if (with_gn) {
-    std::vector<float> s0(stat_n), s1(stat_n);
-    HIPCHK(hipMemcpy(s0.data(), st[0], stat_n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(s1.data(), st[1], stat_n * 4, hipMemcpyDeviceToHost));
-    double smax = 0;
-    for (size_t i = 0; i < stat_n; ++i) smax = std::max(smax, (double)fabsf(s0[i]));
-    for (size_t i = 0; i < stat_n; ++i) rs = std::max(rs, fabs((double)s0[i] - s1[i]) / (smax + 1e-30));
-  }
-  if (with_colmax) {
-    std::vector<unsigned> c0(cm_n), c1(cm_n);
-    HIPCHK(hipMemcpy(c0.data(), cm[0], cm_n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(c1.data(), cm[1], cm_n * 4, hipMemcpyDeviceToHost));
-    auto unkey = [](unsigned kx) { const unsigned b = (kx & 0x80000000u) ? (kx & 0x7fffffffu) : ~kx; float f; memcpy(&f, &b, 4); return (double)f; };
-    for (size_t i = 0; i < cm_n; ++i) rs = std::max(rs, fabs(unkey(c0[i]) - unkey(c1[i])) / (m + 1e-30));
-  }
-  *max_rel_stat = rs;
-  return LDC_OK;
-}
-
-// Self-check of the fp8 x fp8 conv (conv_fast_fp8.hip): operands drawn ON the e4m3 grid, so the bf16-activation x fp8-weight
-// kernel (same quantised weights, expanded to bf16 in registers, bf16 MFMA) computes exactly the same products; the two results
-// may differ by the fp32 summation order only (one bf16 ulp of the output at most).  Reports max |diff| and max |output|.
-extern "C" int ldc_conv_compare_fp8(ldc_ctx* c, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups, int with_gn,
-                                    int with_colmax, double* max_abs_diff, double* max_abs_ref, double* max_rel_stat) {
-  if (!c || !max_abs_diff || !max_abs_ref || !max_rel_stat) return fail(LDC_E_INVALID, "bad arguments");
-  if ((cin1 % 64) || (cin2 % 64)) return fail(LDC_E_INVALID, "fp8 inputs need channel counts that are multiples of 64");
-  HIPCHK(hipSetDevice(c->device));
-  const int cin = cin1 + cin2;
-  std::vector<float> w((size_t)cout * cin * k), bias(cout);
-  unsigned seed = 777u;
-  for (auto& v : w) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.2f; }
-  for (auto& v : bias) { seed = seed * 1664525u + 1013904223u; v = ((seed >> 8) * (1.0f / 16777216.0f) - 0.5f); }
-  DevMem keep;
-  const bool saved_w8 = c->w8;
-  c->w8 = true;
-  std::swap(keep.ptrs, c->wmem.ptrs);
-  ConvLayer ly[2];
-  ConvSpec sp;
-  sp.cin1 = cin1; sp.cin2 = cin2; sp.cout = cout; sp.k = k; sp.stride = stride; sp.ups = ups;
-  sp.pad_left = (k == 4 && stride == 2) ? 1 : (k - 1) / 2;
-  sp.dt = DT_BF16;
-  int rc = make_conv(c, sp, w.data(), bias.data(), &ly[0]);            // bf16 activations x fp8 weights
-  sp.dt = DT_FP8; sp.act8 = 1;
-  if (rc == LDC_OK) rc = make_conv(c, sp, w.data(), bias.data(), &ly[1]);   // fp8 x fp8
-  std::swap(keep.ptrs, c->wmem.ptrs);
-  c->w8 = saved_w8;
-  LDCCHK(rc);
-  const int L_out = ups ? 2 * L : (stride == 2 ? (L + 2 * sp.pad_left - k) / 2 + 1 : L);
-  const int groups = 8;
-  const size_t n_out = (size_t)B * L_out * cout, stat_n = (size_t)B * groups * kGnPad, cm_n = (size_t)B * cout;
-  // inputs: e4m3 codes with |value| <= 3.5 (exponent field <= 8), never the NaN code; the same values as bf16
-  auto make_input = [&](size_t n, unsigned sd, void** d8, void** d16) -> int {
-    std::vector<uint8_t> h8(n);
-    std::vector<uint16_t> h16(n);
-    for (size_t i = 0; i < n; ++i) {
-      sd = sd * 1664525u + 1013904223u;
-      uint8_t code = (uint8_t)(sd >> 13);
-      if (((code >> 3) & 0xf) > 8) code = (uint8_t)((code & 0x87) | (8 << 3));
-      h8[i] = code;
-      const float f = host_e4m3_to_f32(code);
-      uint32_t u;
-      memcpy(&u, &f, 4);
-      h16[i] = (uint16_t)(u >> 16);                       // every e4m3 value is exact in bf16
-    }
-    LDCCHK(keep.alloc(d8, n));
-    LDCCHK(keep.alloc(d16, n * 2));
-    HIPCHK(hipMemcpy(*d8, h8.data(), n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(*d16, h16.data(), n * 2, hipMemcpyHostToDevice));
-    return LDC_OK;
-  };
-  void *x1[2] = {nullptr, nullptr}, *x2[2] = {nullptr, nullptr};
-  LDCCHK(make_input((size_t)B * L * cin1, 31u, &x1[1], &x1[0]));
-  if (cin2) LDCCHK(make_input((size_t)B * L * cin2, 32u, &x2[1], &x2[0]));
-  void *part = nullptr, *cnt = nullptr;
-  LDCCHK(keep.alloc(&part, (size_t)(8 << 20) * 4));
-  LDCCHK(keep.alloc(&cnt, 1024 * 4));
-  HIPCHK(hipMemset(cnt, 0, 1024 * 4));
-  hipStream_t s = c->own_stream;
-  void *y[2], *st[2], *cm[2];
-  for (int v = 0; v < 2; ++v) {
-    LDCCHK(keep.alloc(&y[v], n_out * 2));
-    LDCCHK(keep.alloc(&st[v], stat_n * 4));
-    LDCCHK(keep.alloc(&cm[v], cm_n * 4));
-    HIPCHK(hipMemset(y[v], 0, n_out * 2));
-    HIPCHK(hipMemset(st[v], 0, stat_n * 4));
-    HIPCHK(hipMemset(cm[v], 0, cm_n * 4));
-    ConvCall cc;
-    cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1[v]; cc.x2 = x2[v]; cc.y = y[v]; cc.y_ld = cout;
-    if (with_gn) { cc.gn_sum = (float*)st[v]; cc.gn_groups = groups; }
-    if (with_colmax) { cc.colmax = (unsigned*)cm[v]; cc.colmax_lo = 0; cc.colmax_hi = cout; cc.colmax_stride = cout; }
-    cc.sk_part = (float*)part; cc.sk_part_cap = (long long)8 << 20; cc.sk_count = (unsigned*)cnt; cc.sk_count_cap = 1024;
-    cc.tune = &c->tune;
-    HIPCHK(launch_conv(ly[v], cc, s));
-  }
-  HIPCHK(hipStreamSynchronize(s));
-  std::vector<uint16_t> h0(n_out), h1(n_out);
-  HIPCHK(hipMemcpy(h0.data(), y[0], n_out * 2, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(h1.data(), y[1], n_out * 2, hipMemcpyDeviceToHost));
-  auto val = [](uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return (double)f; };
-  double d = 0, m = 0;
-  for (size_t i = 0; i < n_out; ++i) {
-    const double a = val(h0[i]), b = val(h1[i]);
-    if (!(b == b)) { d = 1e30; break; }
-    d = std::max(d, fabs(a - b));
-    m = std::max(m, fabs(a));
-  }
-  *max_abs_diff = d;
-  *max_abs_ref = m;
-  double rs = 0;
-  if (with_gn) {
-    std::vector<float> s0(stat_n), s1(stat_n);
-    HIPCHK(hipMemcpy(s0.data(), st[0], stat_n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(s1.data(), st[1], stat_n * 4, hipMemcpyDeviceToHost));
-    double smax = 0;
-    for (size_t i = 0; i < stat_n; ++i) smax = std::max(smax, (double)fabsf(s0[i]));
-    for (size_t i = 0; i < stat_n; ++i) rs = std::max(rs, fabs((double)s0[i] - s1[i]) / (smax + 1e-30));
-  }
-  if (with_colmax) {
-    std::vector<unsigned> c0(cm_n), c1(cm_n);
-    HIPCHK(hipMemcpy(c0.data(), cm[0], cm_n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(c1.data(), cm[1], cm_n * 4, hipMemcpyDeviceToHost));
-    auto unkey = [](unsigned kx) { const unsigned b = (kx & 0x80000000u) ? (kx & 0x7fffffffu) : ~kx; float f; memcpy(&f, &b, 4); return (double)f; };
-    for (size_t i = 0; i < cm_n; ++i) rs = std::max(rs, fabs(unkey(c0[i]) - unkey(c1[i])) / (m + 1e-30));
-  }
-  *max_rel_stat = rs;
-  return LDC_OK;
-}
-
-extern "C" int ldc_gn_microbench(ldc_ctx* c, int dtype, int B, int L, int C, int with_residual, int iters, double* ms_per_launch) {
-  if (!c || !ms_per_launch || iters < 1) return fail(LDC_E_INVALID, "bad arguments");
-  HIPCHK(hipSetDevice(c->device));
-  const int dt = dtype == LDC_BF16 ? DT_BF16 : DT_F32;
-  const size_t es = dt_size(dt), n = (size_t)B * L * C;
-  DevMem keep;
-  void *x = nullptr, *y = nullptr, *r = nullptr, *st = nullptr, *gb = nullptr;
-  LDCCHK(keep.alloc(&x, n * es)); LDCCHK(keep.alloc(&y, n * es)); LDCCHK(keep.alloc(&r, n * es));
-  LDCCHK(keep.alloc(&st, (size_t)B * 8 * kGnPad * 4)); LDCCHK(keep.alloc(&gb, (size_t)4 * C * 4));
-  HIPCHK(hipMemset(x, 0x3c, n * es)); HIPCHK(hipMemset(r, 0x3c, n * es));
-  std::vector<float> hs((size_t)B * 8 * kGnPad, 1.0f), hg((size_t)4 * C, 0.5f);
-  for (size_t i = 0; i < hs.size(); i += kGnPad) { hs[i] = 10.f; hs[i + 1] = 1e4f; }
-  HIPCHK(hipMemcpy(st, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(gb, hg.data(), hg.size() * 4, hipMemcpyHostToDevice));
-  float* g = (float*)gb;
-  hipStream_t s = c->own_stream;
-  void* yln = nullptr;
-  const int mode = getenv("LDC_GN_LN") ? atoi(getenv("LDC_GN_LN")) : 0;   // 1: fused LayerNorm output, 2: separate ln_rows launch
-  if (mode) LDCCHK(keep.alloc(&yln, n * es));
-  auto go = [&]() {
-    hipError_t e = launch_gn_apply(dt, x, y, with_residual ? r : nullptr, B, L, C, 8, (float*)st, g, g + C, g + 2 * C, 0, nullptr, ACT_SILU, s,
-                                   mode == 1 ? yln : nullptr, g);
-    if (e == hipSuccess && mode == 2) e = launch_ln_rows(dt, y, yln, nullptr, g, B * L, C, s);
-    return e;
-  };
-  for (int i = 0; i < 3; ++i) HIPCHK(go());
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) HIPCHK(go());
-  HIPCHK(hipEventRecord(e1, s));
-  HIPCHK(hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  *ms_per_launch = ms / iters;
   return LDC_OK;
 }
