@@ -133,11 +133,13 @@ def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, 
     fwd_flops, _ = eng.unet_step_cost(B, T // mc.hop_length)
     ach = 3.0 * fwd_flops * args.steps / elapsed / 1e12           # forward + dX + dW of every conv-shaped layer
     exact = bool(os.environ.get("LDC_TRAIN_FP32_MFMA"))
+    plain = bool(os.environ.get("LDC_TRAIN_BF16")) and not exact       # opt-in: hi terms only, one bf16 MFMA per product (autocast-class numerics)
     result = {
         "metric": "audio-sec per wall-sec through ONE optimisation step of the diffusion UNet (training, --run_diff)",
         "value": world * B * (T / 16000.0) * args.steps / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if exact else "bf16x3 (fp32 tensors; GEMM operands split into bf16 hi + lo, three MFMAs per product, fp32 accumulate)",
+        "dtype": "f32" if exact else ("bf16 (fp32 tensors; GEMM operands rounded to bf16, one MFMA per product, fp32 accumulate: LDC_TRAIN_BF16)" if plain else
+                                      "bf16x3 (fp32 tensors; GEMM operands split into bf16 hi + lo, three MFMAs per product, fp32 accumulate)"),
         "data": "synthetic (seeded weights with the reference key set, synthetic 16 kHz audio, device-drawn t / noise)",
         "config": {"workload": f"diffusion training step, diff_dims={u.dim}, seq_length {T // mc.hop_length}, batch={B}x{T / 16000.0:.1f} s per GPU, "
                                f"Adam over {n_par / 1e6:.1f} M parameters", "name": "c4", "global_batch": world * B,
@@ -147,6 +149,9 @@ def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, 
         "roofline": ({"bound": "mfma", "kernel": "convmm_kernel<0|1|2>: forward, dX and dW of every conv / pointwise layer on the exact-fp32 MFMA (csrc/train.hip)",
                       "achieved": ach, "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS["f32"], "traffic": None}
                      if exact else
+                     {"bound": "mfma", "kernel": "mm3_kernel<0|1|2>: forward, dX and dW with ONE bf16 MFMA per product (hi terms only, LDC_TRAIN_BF16; csrc/train_mm3.hip)",
+                      "achieved": ach, "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS["bf16"], "traffic": None}
+                     if plain else
                      {"bound": "mfma", "kernel": "mm3_kernel<0|1|2>: forward, dX and dW of every conv / pointwise / Linear / transposed-conv layer as three "
                                                  "bf16 MFMAs per fp32 product (csrc/train_mm3.hip)",
                       "achieved": ach, "peak": MFMA_PEAK_TFLOPS["bf16"] / 3.0, "unit": "TFLOP/s", "frac": 3.0 * ach / MFMA_PEAK_TFLOPS["bf16"], "traffic": None,

@@ -79,6 +79,7 @@ struct ConvKArgs {
   unsigned long long* kst;
   const int* kst_step;     // the part's device step state: [1] = iteration index
   int kst_stride;
+  int gn_nap, gn_nap0;     // fused GroupNorm exchange: s_sleep(1) repetitions between polls / before the first poll (ConvTune)
   const float* ln_s;       // folded PreNorm LayerNorm (ConvLayer::ln_s) or null
   char* y2;                // folded 1x1 conv (ConvLayer::wtaps): second output [rows][n], or null
   const float* bias2;
@@ -474,11 +475,12 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
       const int ms_wm = mine ? l / sub_n : 0, sub = mine ? l - ms_wm * sub_n : 0;   // (mslot * WM + wm'), block inside the group
       const char* src = base + ((size_t)ms_wm * nc32 + sub) * 16;
       u32x4_t v;
+      for (int z = 0; z < a.gn_nap0; ++z) __builtin_amdgcn_s_sleep(1);
       for (;;) {
         load16_sc1_issue(v, src);
         wait_vm0();
         if (__all(!mine || (v[0] == 1u && v[2] == 1u))) break;
-        __builtin_amdgcn_s_sleep(1);
+        for (int z = 0; z < a.gn_nap; ++z) __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t0 > 50000000ull) {   // 0.5 s: give up, raise the flag, poison the output
           if (lane == 0 && a.fail_flag) __hip_atomic_store(a.fail_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           s = __uint_as_float(0x7fc00000u);

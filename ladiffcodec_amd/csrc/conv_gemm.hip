@@ -403,6 +403,7 @@ static hipError_t conv_kargs(const ConvLayer& ly, const ConvCall& c, ConvKArgs& 
   a.fail_flag = c.fail_flag;
   a.kst = c.kst; a.kst_step = c.kst_step; a.kst_stride = c.kst_stride;
   a.ln_s = ly.ln_s;
+  a.gn_nap = c.tune ? c.tune->gn_nap : 1; a.gn_nap0 = c.tune ? c.tune->gn_nap0 : 0;
   a.y2 = (char*)c.y2; a.bias2 = ly.bias2; a.wtaps = ly.wtaps ? ly.wtaps : ly.taps;
   if ((c.y2 != nullptr) != (ly.wtaps != 0)) return hipErrorInvalidValue;   // a folded layer always writes its second output
   a.wscale = (ly.w8 || ly.dt == DT_FP8) ? ly.wscale : nullptr; a.w8 = ly.w8;

@@ -700,6 +700,8 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->tune.sk_u3 = env_int("LDC_SK_U3", c->tune.sk_u3);
   c->tune.m_fastest = env_int("LDC_CONV_MFAST", c->tune.m_fastest);
   c->tune.debug = env_int("LDC_CONV_DEBUG", 0);
+  c->tune.gn_nap = env_int("LDC_GN_NAP", c->tune.gn_nap);
+  c->tune.gn_nap0 = env_int("LDC_GN_NAP0", c->tune.gn_nap0);
   c->tune.force_tile = env_int("LDC_TILE_CFG", -1);
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
   c->coop_launch = getenv("LDC_COOP_LAUNCH") ? 1 : 0;

@@ -64,6 +64,7 @@ struct ConvTune {
   int sk_tiles = 200, sk_u2 = 24, sk_u3 = 60;   // LDC_SK_TILES / LDC_SK_U2 / LDC_SK_U3
   int m_fastest = 1;            // LDC_CONV_MFAST: 0 N-tile fastest | 1 by operand size | 2 M-tile fastest
   int debug = 0;                // LDC_CONV_DEBUG (bits, see conv_fast.inc)
+  int gn_nap = 16, gn_nap0 = 0;  // LDC_GN_NAP / LDC_GN_NAP0: 64-clock naps between the polls of the fused GroupNorm exchange / before the first
   int force_tile = -1;          // self-check / tuning: 0 = 64x64, 1 = 128x64, 2 = 128x128 tiles wherever the layer's N allows
 };
 

@@ -519,12 +519,24 @@ __global__ __launch_bounds__(256) void mm3_sum_parts_kernel(const float* ws, int
 }  // namespace mm3
 using namespace mm3;
 namespace {
-// packed-weight workspace (one training context per process; grows on demand, never inside a capture)
+// packed-weight workspace (one training context per process; grows on demand, never inside a capture).  Process-wide and bound to
+// the device it was first allocated on: a call from another device is refused (nullptr -> hipErrorOutOfMemory at the caller), and
+// growth waits for the WHOLE device, not only the calling stream, before the old buffer is freed (another trainer's stream may
+// still be reading it).
+int g_ws_device = -1;
+bool ws_device_ok() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (g_ws_device < 0) g_ws_device = dev;
+  return dev == g_ws_device;
+}
 void* g_pw = nullptr;
 size_t g_pw_bytes = 0;
 u32x4* pack_workspace(size_t bytes, hipStream_t s) {
+  if (!ws_device_ok()) return nullptr;
   if (bytes > g_pw_bytes) {
     (void)hipStreamSynchronize(s);
+    (void)hipDeviceSynchronize();
     if (g_pw) (void)hipFree(g_pw);
     g_pw = nullptr;
     g_pw_bytes = 0;
@@ -537,8 +549,10 @@ u32x4* pack_workspace(size_t bytes, hipStream_t s) {
 void* g_dw_ws = nullptr;      // partial dW tiles of a split reduction (same ownership rules as g_pw)
 size_t g_dw_ws_bytes = 0;
 float* dw_workspace(size_t bytes, hipStream_t s) {
+  if (!ws_device_ok()) return nullptr;
   if (bytes > g_dw_ws_bytes) {
     (void)hipStreamSynchronize(s);
+    (void)hipDeviceSynchronize();
     if (g_dw_ws) (void)hipFree(g_dw_ws);
     g_dw_ws = nullptr;
     g_dw_ws_bytes = 0;

@@ -385,8 +385,9 @@ def test_frozen_encoders_prefetched_on_a_second_engine_give_the_same_steps():
         if nxt is not None:       # what the side stream produced is what the in-line engine produces, bit for bit
             torch.cuda.current_stream().wait_event(pre._prefetched[3])
             assert torch.equal(pre._prefetched[1], e.get_cond(nxt)) and torch.equal(pre._prefetched[2], e.encode(L.MODEL_MAIN, nxt))
-    # the first loss is bit-identical; later ones see parameters after Adam's first steps (lr * sign(g): the fp32 atomics of the split
-    # reductions decide the sign of ~0 gradients, also between two runs of the SAME trainer), hence the looser bar
+    # the first loss is bit-identical; later ones see parameters after Adam's first steps (lr * sign(g)).  The split-bf16 GEMMs are
+    # atomic-free and bit-reproducible (test_split_bf16_step_is_bit_reproducible); what still differs between two trainers here is
+    # the exact-fp32 path's and the norms' fp32 atomics, which decide the sign of ~0 gradients: hence the looser bar
     assert got[0] == want[0] and max(abs(a - b) for a, b in zip(got, want)) < 2e-4, (got, want)
 
 
