@@ -30,6 +30,28 @@ pmc)
 shapes)
   LDC_PROFILE_DUMP=/tmp/d.txt timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined > $O/bench_shapes.json 2> $O/bench_shapes.err
   python tools/prof_shapes.py /tmp/d.txt > $O/layer_shapes.txt 2>&1; head -30 $O/layer_shapes.txt ;;
+timed)
+  timeout 600 python tools/timed_mode_stats.py > $O/timed_mode_kernel_stats.md 2> $O/timed_mode.err; head -12 $O/timed_mode_kernel_stats.md ;;
+configs)   # the other BASELINE configs (builder-run lines)
+  timeout 300 python bench.py --config c1 --steps 20 --warmup 3 > $O/bench_c1.json 2> $O/bench_c1.err; tail -1 $O/bench_c1.err
+  for c in c3 c8 c5 c4; do
+    timeout 900 python bench.py --config $c --steps 3 --warmup 1 > $O/bench_$c.json 2> $O/bench_$c.err; tail -1 $O/bench_$c.err
+  done
+  timeout 600 python bench.py --dtype fp8 --steps 4 --warmup 1 --no-cpu-baseline --no-pipelined > $O/bench_c2_fp8.json 2> /dev/null
+  python - <<PY
+import json, glob
+for f in sorted(glob.glob("$O/bench_*.json")):
+    try:
+        d = json.load(open(f))
+        print(f.split("/")[-1], round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms; roofline", round(d.get("roofline", {}).get("frac", 0), 4), "host", d.get("host"))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+  ;;
+final)   # PMC traffic first (bench.py reports it while the kernel-source hash matches), then the c2 line of record
+  bash $0 pmc
+  cp $O/conv_traffic.json profiles/r04_conv_traffic.json
+  bash $0 bench ;;
 *) echo "unknown stage $STAGE" ;;
 esac
 done
