@@ -684,6 +684,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
   c->gn_epi_min_l = env_int("LDC_GN_EPI_MINL", c->gn_epi_min_l);
+  c->gn_epi_max_tiles = env_int("LDC_GN_EPI_MAXTILES", c->gn_epi_max_tiles);
   c->fold_res = getenv("LDC_NO_RES_FOLD") ? 0 : 1;
   c->chain_convs = env_int("LDC_CHAIN", c->chain_convs);
   c->fold_ln = getenv("LDC_NO_LN_FOLD") ? 0 : 1;
@@ -1381,9 +1382,10 @@ struct PlanBuilder {
     if (epi_ok) {
       int t1[3], t2[3];
       conv_bm(r.c1, L, L, false, t1);
-      epi1 = (!f8 || dt == DT_BF16) && t1[0] > 0 && t1[0] <= 2 * L && take_part(&ge1, L, t1[0], t1[1], r.cout);   // f8: block1's output in fp8
+      auto few_tiles = [&](int bm) { return bm > 0 && (long)((rows + bm - 1) / bm) * (r.cout / 64) <= c->gn_epi_max_tiles; };
+      epi1 = (!f8 || dt == DT_BF16) && few_tiles(t1[0]) && t1[0] <= 2 * L && take_part(&ge1, L, t1[0], t1[1], r.cout);   // f8: block1's output in fp8
       conv_bm(f8 ? r.c2_f8 : r.c2, L, L, false, t2);
-      epi2 = (!(out_mode & 1) || dt == DT_BF16) && t2[0] > 0 && t2[0] <= 2 * L && take_part(&ge2, L, t2[0], t2[1], r.cout);
+      epi2 = (!(out_mode & 1) || dt == DT_BF16) && few_tiles(t2[0]) && t2[0] <= 2 * L && take_part(&ge2, L, t2[0], t2[1], r.cout);
     }
     void* a = epi1 ? nullptr : act(rows, r.cout);   // un-normalised conv outputs exist only on the unfused path
     void* d = epi2 ? nullptr : act(rows, r.cout);

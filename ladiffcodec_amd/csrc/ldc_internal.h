@@ -278,6 +278,9 @@ struct ldc_ctx {
   unsigned long long flow_n = 0;
   int flow_depth = 8;           // LDC_FLOW_DEPTH (0 = unbounded look-ahead)
   int fuse_gn_stats = 1;
+  int gn_epi_max_tiles = 1300;  // LDC_GN_EPI_MAXTILES: largest launch (output tiles) that fuses the GroupNorm apply.  A tile holds its slot until every tile
+                                // of its item has finished: fine while a launch is one to two rounds of workgroups (c2: 300-1200 tiles), a loss when an
+                                // item alone is 150 tiles of a 2400-tile launch (the L = 4800 layout: 501 instead of 450 ms per decode)
   int gn_epi_min_l = 0;         // LDC_GN_EPI_MINL: shortest level (positions per item) whose ResnetBlocks fuse the GroupNorm apply
   int fold_ln = 1;              // PreNorm LayerNorm of the attention blocks folded into to_qkv (LDC_NO_LN_FOLD / option "fold_ln")
   int chain_convs = 0;          // block1's and block2's convs of a ResnetBlock as ONE launch (conv_fast_pair_kernel; LDC_CHAIN=1 / option "chain_convs").
