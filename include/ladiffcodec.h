@@ -116,6 +116,11 @@ int ldc_destroy(ldc_ctx* ctx);
  * only), "fp8_act" (fp8 contexts, before ldc_finalize_weights), "train_fp32_mfma" = 1: the training GEMMs on the exact-fp32
  * MFMA (round-2 kernels) instead of the split-bf16 ones (three bf16 MFMAs per product, 2^-16-class: csrc/train_mm3.hip) -- this
  * one is process-wide, like "train_bf16" = 1: one bf16 MFMA per product in the training GEMMs (autocast-class numerics, opt-in).
+ * Launch structure of the UNet step (round 4; each keeps the reference's arithmetic, unet.py:137-246): "fuse_gn_epi" (default 1) = the
+ * GroupNorm apply of a ResnetBlock's Block inside the producing conv, behind an in-launch exchange of per-wave statistics -- 0 restores
+ * the conv + gn_apply launch pairs and is the fallback when a "[gn_wait]" device-side failure is reported; "fold_res" (1) = res_conv as a
+ * fourth weight slab of block1's conv; "fold_ln" (1) = the attention blocks' PreNorm LayerNorm inside to_qkv; "chain_convs" (0) = block1's
+ * and block2's convs as one launch with a per-M-tile hand-off (measured slower, kept for experiments).
  * Cached plans and graphs are dropped when a value changes. */
 int ldc_set_option(ldc_ctx* ctx, const char* name, int value);
 
