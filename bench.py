@@ -345,7 +345,7 @@ def main():
     log(f"rank {rank}/{world}: checkpoints ready ({len(sd_main)} + {len(sd_cond)} tensors)")
     from ladiffcodec_amd.model import Engine
     n_fl = max(1, args.in_flight)
-    if n_fl > 1:
+    if n_fl > 1 and not os.environ.get("LDC_BENCH_KEEP_SPLIT"):
         os.environ["LDC_NO_SPLIT"] = "1"      # read at ldc_create: with several batches in flight each batch is one chain
     engines, slot_streams = [], []
     for k in range(n_fl):
