@@ -81,6 +81,9 @@ struct ConvKArgs {
   int kst_stride;
   int gn_nap, gn_nap0;     // fused GroupNorm exchange: s_sleep(1) repetitions between polls / before the first poll (ConvTune)
   const float* ln_s;       // folded PreNorm LayerNorm (ConvLayer::ln_s) or null
+  const float* ln_rowstat; // ... its row statistics as partials [rows][C / 32][2] (sum, sum of squares per 32-column block) written by the
+                           // producer of the input (rowstat_out of the fused block2 conv), or null: the conv reads its rows once more
+  float* rowstat_out;      // fused GroupNorm apply with residual: also write those partials of the stored rows [rows][n / 32][2]
   char* y2;                // folded 1x1 conv (ConvLayer::wtaps): second output [rows][n], or null
   const float* bias2;
   int wtaps;               // weight slabs per channel chunk in the packed image (taps, or taps + 1 with the folded conv)
@@ -604,9 +607,20 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
         }
       }
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        f[e] += rr[e];
-        if (a.gn_out & 4) f[e] = fast_tanh(f[e]);
+      for (int e = 0; e < EPL; ++e) f[e] += rr[e];
+      if (a.rowstat_out) {   // per-row partial (sum, sum of squares) of this lane group's 32-column block: the PreNorm of the attention block behind
+        constexpr int G = 32 / EPL;   // lanes that share a row's 32-column block (consecutive lanes)
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { ps += f[e]; pq = fmaf(f[e], f[e], pq); }
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) { ps += __shfl_xor(ps, o); pq += __shfl_xor(pq, o); }
+        if ((chunk & (G - 1)) == 0 && m < M && col < a.n)
+          *reinterpret_cast<float2*>(a.rowstat_out + ((size_t)m * (a.n >> 5) + (col >> 5)) * 2) = make_float2(ps, pq);
+      }
+      if (a.gn_out & 4) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) f[e] = fast_tanh(f[e]);
       }
       uint4 v;
       if constexpr (sizeof(T) == 4) {

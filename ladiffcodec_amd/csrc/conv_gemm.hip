@@ -402,7 +402,7 @@ static hipError_t conv_kargs(const ConvLayer& ly, const ConvCall& c, ConvKArgs& 
   a.gn_part = (char*)c.gn_part; a.gn_mslots = c.gn_mslots; a.gn_gamma = c.gn_gamma; a.gn_beta = c.gn_beta; a.gn_ss = c.gn_ss; a.gn_out = c.gn_out; a.io_sc1 = c.io_sc1;
   a.fail_flag = c.fail_flag;
   a.kst = c.kst; a.kst_step = c.kst_step; a.kst_stride = c.kst_stride;
-  a.ln_s = ly.ln_s;
+  a.ln_s = ly.ln_s; a.ln_rowstat = c.ln_rowstat; a.rowstat_out = c.rowstat_out;
   a.gn_nap = c.tune ? c.tune->gn_nap : 1; a.gn_nap0 = c.tune ? c.tune->gn_nap0 : 0;
   a.y2 = (char*)c.y2; a.bias2 = ly.bias2; a.wtaps = ly.wtaps ? ly.wtaps : ly.taps;
   if ((c.y2 != nullptr) != (ly.wtaps != 0)) return hipErrorInvalidValue;   // a folded layer always writes its second output

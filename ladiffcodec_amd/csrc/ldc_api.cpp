@@ -1272,12 +1272,16 @@ struct PlanBuilder {
   }
   std::string info;   // description of the next op added
   void* y2_next = nullptr;   // second output of the next conv added (a layer with a folded 1x1 conv)
+  const float* ln_rowstat_next = nullptr;   // row-statistics partials of the next (LayerNorm-folded) conv's input
+  bool want_rowstat = false;                // the next resnet()'s fused block2 conv leaves those partials of its output ...
+  float* last_rowstat = nullptr;            // ... here (null when it could not)
   struct Captured { const ConvLayer* ly = nullptr; ConvCall cc; double flops = 0, bytes = 0; std::string info; };
   Captured* capture = nullptr;   // when set, conv() hands the call back instead of adding an op (chained pairs)
   // fused GroupNorm apply of a conv (see ConvCall::gn_cnt)
   struct GnEpi {
     void* part = nullptr;          // granule region of this conv
     int mslots = 0;
+    float* rowstat = nullptr;      // with a residual: per-row (sum, sumsq) partials of the output for a LayerNorm folded into the consumer
     const float* gamma = nullptr; const float* beta = nullptr; const float* ss = nullptr;
     int out = 0;
   };
@@ -1310,11 +1314,13 @@ struct PlanBuilder {
     cc.B = B; cc.L_in = L_in; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.residual = residual; cc.y_ld = ly.n;
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
     cc.y2 = y2_next; y2_next = nullptr;
+    cc.ln_rowstat = ly.ln_s ? ln_rowstat_next : nullptr; ln_rowstat_next = nullptr;
     if (pl->kst && pl->step_ops.size() < (size_t)kKstOps) {
       cc.kst = pl->kst + pl->step_ops.size() * 2; cc.kst_stride = kKstOps * 2; cc.kst_step = pl->step_state;
     }
     if (ge && ge->part) {
       cc.gn_groups = c->unet.groups;
+      cc.rowstat_out = residual ? ge->rowstat : nullptr;
       cc.gn_part = ge->part; cc.gn_mslots = ge->mslots; cc.gn_gamma = ge->gamma; cc.gn_beta = ge->beta; cc.gn_ss = ge->ss; cc.gn_out = ge->out;
       cc.fail_flag = c->dev_flag_dev;
     }
@@ -1374,6 +1380,9 @@ struct PlanBuilder {
     float* st2 = next_stats();
     const int cpg = r.cout / g;
     const bool fuse_stats = c->fuse_gn_stats && cpg >= 4 && (cpg & (cpg - 1)) == 0;
+    const bool rowstat_wanted = want_rowstat;
+    want_rowstat = false;
+    last_rowstat = nullptr;
     // GroupNorm apply inside the conv epilogue (in-launch per-item wait): the tile height must not exceed twice an item's rows
     // (a tile then straddles at most three items), and the output must be in the UNet dtype (fp8 outputs keep gn_apply)
     const bool epi_ok = c->fuse_gn_epi && cpg % 32 == 0 && r.cout % 32 == 0 && L >= c->gn_epi_min_l;
@@ -1427,6 +1436,7 @@ struct PlanBuilder {
         *xn_out = xn;
       }
       ge2.gamma = r.g2; ge2.beta = r.b2; ge2.ss = nullptr; ge2.out = out_mode & 4;
+      if (rowstat_wanted) ge2.rowstat = last_rowstat = (float*)ar->alloc((size_t)rows * (r.cout / 32) * 8);
       if (r.has_res && !folded) mark(3);
       capture = &k2;
       conv(r.c2, b, nullptr, out, res, L, L, nullptr, nullptr, 0, 0, 0, &ge2);
@@ -1463,6 +1473,7 @@ struct PlanBuilder {
     }
     if (epi2) {   // block2: conv -> GroupNorm -> SiLU -> + res (-> tanh), one launch; the PreNorm LayerNorm of a following attention block reads `out`
       ge2.gamma = r.g2; ge2.beta = r.b2; ge2.ss = nullptr; ge2.out = out_mode & 5;
+      if (rowstat_wanted && !f8) ge2.rowstat = last_rowstat = (float*)ar->alloc((size_t)rows * (r.cout / 32) * 8);
       if (r.has_res && !folded) mark(3);
       conv(f8 ? r.c2_f8 : r.c2, b, nullptr, out, res, L, L, nullptr, nullptr, 0, 0, 0, &ge2);
       if (xn) {
@@ -1496,6 +1507,8 @@ struct PlanBuilder {
     const int H = c->unet.heads, Dh = c->unet.dim_head, hid = H * Dh;
     const bool f8 = qkv_fp8(a);
     const bool lnf = !xn_pre && ln_foldable(a, L);     // LayerNorm inside to_qkv: the conv reads x itself
+    const float* rowstat = lnf ? last_rowstat : nullptr;   // (sum, sumsq) partials of x's rows left by the ResnetBlock in front, if it could
+    last_rowstat = nullptr;
     void* xn = lnf ? const_cast<void*>(x) : (xn_pre ? xn_pre : (f8 ? ar->alloc((size_t)rows * a.dim) : act(rows, a.dim)));
     const ConvLayer& qkv_ly = lnf ? a.qkv_ln : (f8 ? a.qkv_f8 : a.qkv);
     void* qkv = act(rows, 3 * hid);
@@ -1512,6 +1525,7 @@ struct PlanBuilder {
       const size_t wss = linattn_ws_floats_per_item(H, Dh);
       if (c->fuse_kmax && c->fuse_attn_tail && !a.out.w8 && linattn_tail_supported(dt, H, Dh, a.dim)) {
         // three launches: qkv conv (+ k column max) -> context -> tail (out, to_out conv, LayerNorm, + x)
+        ln_rowstat_next = rowstat;
         conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
         add([=](hipStream_t s) { return launch_linattn_ctx(dt, qkv, ws, Bn, L, H, Dh, s); }, false, 0, LDC_CLASS_LINATTN, 2.0 * rows * hid * es);
         const int dim = a.dim;
@@ -1522,10 +1536,12 @@ struct PlanBuilder {
         return out;
       }
       if (c->fuse_kmax) {
+        ln_rowstat_next = rowstat;
         conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
         add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, true, s); }, false, 0, LDC_CLASS_LINATTN,
             4.0 * rows * hid * es);
       } else {
+        ln_rowstat_next = rowstat;
         conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L);
         add([=](hipStream_t s) { return launch_linattn(dt, qkv, o, ws, Bn, L, H, Dh, false, s); }, false, 0, LDC_CLASS_LINATTN,
             5.0 * rows * hid * es);
@@ -1535,6 +1551,7 @@ struct PlanBuilder {
       add([=](hipStream_t s) { return launch_ln_rows(dt, t, out, x, ap->out_g, rows, ap->dim, s); }, false, 0, LDC_CLASS_LAYERNORM,
           3.0 * rows * a.dim * es);
     } else {
+      ln_rowstat_next = rowstat;
       conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L);
       add([=](hipStream_t s) { return launch_attn_full(dt, qkv, o, Bn, L, H, Dh, s); }, false, 0, LDC_CLASS_ATTN_FULL, 4.0 * rows * hid * es);
       conv(a.out, o, nullptr, out, x, L, L);   // + x in the epilogue
@@ -1640,7 +1657,7 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     const LevelW& lv = u.downs[i];
     x = pb.resnet(lv.b1, x, nullptr, Lc); hs.push_back({x, Lc});
     void* xn = nullptr;
-    if (pb.ln_foldable(lv.attn, Lc)) x = pb.resnet(lv.b2, x, nullptr, Lc);
+    if (pb.ln_foldable(lv.attn, Lc)) { pb.want_rowstat = true; x = pb.resnet(lv.b2, x, nullptr, Lc); }
     else x = pb.resnet(lv.b2, x, nullptr, Lc, lv.attn.norm_g, &xn, pb.qkv_fp8(lv.attn));
     x = pb.attention(lv.attn, x, Lc, true, xn); hs.push_back({x, Lc});
     int Ln = Lc;
@@ -1652,7 +1669,7 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   }
   {
     void* xn = nullptr;
-    if (pb.ln_foldable(u.mid_attn, Lc)) x = pb.resnet(u.mid1, x, nullptr, Lc);
+    if (pb.ln_foldable(u.mid_attn, Lc)) { pb.want_rowstat = true; x = pb.resnet(u.mid1, x, nullptr, Lc); }
     else x = pb.resnet(u.mid1, x, nullptr, Lc, u.mid_attn.norm_g, &xn, pb.qkv_fp8(u.mid_attn));
     x = pb.attention(u.mid_attn, x, Lc, false, xn);
   }
@@ -1663,7 +1680,7 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     if (hs.back().second != Lc) return fail(LDC_E_INVALID, "latent length %d is not divisible by 2^%zu", L, u.downs.size() - 1);
     x = pb.resnet(lv.b1, x, hs.back().first, Lc); hs.pop_back();
     void* xn = nullptr;
-    if (pb.ln_foldable(lv.attn, Lc)) x = pb.resnet(lv.b2, x, hs.back().first, Lc);
+    if (pb.ln_foldable(lv.attn, Lc)) { pb.want_rowstat = true; x = pb.resnet(lv.b2, x, hs.back().first, Lc); }
     else x = pb.resnet(lv.b2, x, hs.back().first, Lc, lv.attn.norm_g, &xn, pb.qkv_fp8(lv.attn));
     hs.pop_back();
     x = pb.attention(lv.attn, x, Lc, true, xn);

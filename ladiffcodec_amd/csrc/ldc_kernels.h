@@ -98,6 +98,8 @@ struct ConvCall {
   int gn_out = 0;                   // bit 2: tanh after the residual add
   int io_sc1 = 0;                   // in-launch producer / consumer hints (ConvKArgs::io_sc1)
   unsigned* fail_flag = nullptr;    // host-mapped word raised when the bounded in-launch wait gives up
+  float* rowstat_out = nullptr;        // fused apply with residual: per-row (sum, sumsq) partials of the output per 32-column block, [rows][n / 32][2]
+  const float* ln_rowstat = nullptr;   // LayerNorm-folded conv (ConvLayer::ln_s): those partials of its input, or null (it reads its rows once more)
   unsigned long long* kst = nullptr;   // timed-mode stamps of this launch (ConvKArgs::kst), pipelined kernel only
   const int* kst_step = nullptr;
   int kst_stride = 0;
