@@ -89,7 +89,7 @@ struct ConvKArgs {
   int wtaps;               // weight slabs per channel chunk in the packed image (taps, or taps + 1 with the folded conv)
   const ConvTune* tune;    // host-only (never read on the device)
   long long* sk_need;      // host-only: dry run
-  int* bm_out;             // host-only: dry run -- rows per tile the fast kernel would use (0: generic kernel); bm_out[1] = wave rows WM, bm_out[2] = split-K factor
+  int* bm_out;             // host-only: dry run -- rows per tile the fast kernel would use (0: generic kernel); bm_out[1] = wave rows WM, bm_out[2] = split-K factor, bm_out[3] = columns per tile
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -479,13 +479,17 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
       const char* src = base + ((size_t)ms_wm * nc32 + sub) * 16;
       u32x4_t v;
       for (int z = 0; z < a.gn_nap0; ++z) __builtin_amdgcn_s_sleep(1);
-      for (;;) {
+      for (unsigned spins = 0;; ++spins) {
         load16_sc1_issue(v, src);
         wait_vm0();
         if (__all(!mine || (v[0] == 1u && v[2] == 1u))) break;
         for (int z = 0; z < a.gn_nap; ++z) __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 50000000ull) {   // 0.5 s: give up, raise the flag, poison the output
-          if (lane == 0 && a.fail_flag) __hip_atomic_store(a.fail_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // give up after 0.5 s -- or at once when an earlier launch of this call already has (the host-mapped flag is still up: the call's
+        // result is void anyway, and every further fused launch waiting its own 0.5 s turned one stall into minutes).  The flag
+        // lives in host memory (one PCIe round trip): it is looked at every 256th poll of the slow path only.
+        const bool flagged = (spins & 255u) == 255u && a.fail_flag && __hip_atomic_load(a.fail_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        if (flagged || wall_clock64() - t0 > 50000000ull) {   // raise the flag, poison the output
+          if (lane == 0 && a.fail_flag && !flagged) __hip_atomic_store(a.fail_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           s = __uint_as_float(0x7fc00000u);
           break;
         }

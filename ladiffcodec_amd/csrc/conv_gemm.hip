@@ -398,7 +398,7 @@ static hipError_t conv_kargs(const ConvLayer& ly, const ConvCall& c, ConvKArgs& 
   if (ly.tr_stride) a.colmax = nullptr;
   a.ksplit = 1; a.sk_part = c.sk_part; a.sk_count = c.sk_count; a.sk_part_cap = c.sk_part_cap; a.sk_count_cap = c.sk_count_cap;
   a.tune = c.tune; a.sk_need = c.sk_need; a.bm_out = c.bm_out;
-  if (c.bm_out) { c.bm_out[0] = 0; c.bm_out[1] = 0; c.bm_out[2] = 1; }
+  if (c.bm_out) { c.bm_out[0] = 0; c.bm_out[1] = 0; c.bm_out[2] = 1; c.bm_out[3] = 0; }
   a.gn_part = (char*)c.gn_part; a.gn_mslots = c.gn_mslots; a.gn_gamma = c.gn_gamma; a.gn_beta = c.gn_beta; a.gn_ss = c.gn_ss; a.gn_out = c.gn_out; a.io_sc1 = c.io_sc1;
   a.fail_flag = c.fail_flag;
   a.kst = c.kst; a.kst_step = c.kst_step; a.kst_stride = c.kst_stride;

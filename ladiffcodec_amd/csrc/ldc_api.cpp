@@ -1287,13 +1287,13 @@ struct PlanBuilder {
   };
   // rows per tile the pipelined kernel would use for this conv (0: generic kernel) -- the fused apply needs L_out >= that
   // (out[0] = rows per tile, out[1] = wave rows, out[2] = split-K factor)
-  void conv_bm(const ConvLayer& ly, int L_in, int L_out, bool with_stats, int* out) {   // out: int[3]
+  void conv_bm(const ConvLayer& ly, int L_in, int L_out, bool with_stats, int* out) {   // out: int[4]
     ConvCall d;
     d.B = B; d.L_in = L_in; d.L_rows = L_out; d.y_ld = ly.n; d.tune = &c->tune;
     d.sk_part = sk_part; d.sk_count = sk_count; d.sk_part_cap = sk_part_cap; d.sk_count_cap = sk_count_cap;
     if (with_stats) { d.gn_sum = stats_pool; d.gn_groups = c->unet.groups; }
     long long need = 0;
-    out[0] = out[1] = 0; out[2] = 1;
+    out[0] = out[1] = 0; out[2] = 1; out[3] = 0;
     d.sk_need = &need; d.bm_out = out;
     (void)launch_conv(ly, d, nullptr);
   }
@@ -1389,12 +1389,27 @@ struct PlanBuilder {
     bool epi1 = false, epi2 = false;
     GnEpi ge1, ge2;
     if (epi_ok) {
-      int t1[3], t2[3];
+      int t1[4], t2[4];
       conv_bm(r.c1, L, L, false, t1);
-      auto few_tiles = [&](int bm) { return bm > 0 && (long)((rows + bm - 1) / bm) * (r.cout / 64) <= c->gn_epi_max_tiles; };
-      epi1 = (!f8 || dt == DT_BF16) && few_tiles(t1[0]) && t1[0] <= 2 * L && take_part(&ge1, L, t1[0], t1[1], r.cout);   // f8: block1's output in fp8
+      // Two gates on the tiles the dry run reports (BM x BN): (i) the launch as a whole stays within gn_epi_max_tiles (a performance gate:
+      // beyond two rounds of workgroups the waiting tiles cost more than the gn_apply launch they replace); (ii) a SAFETY gate per item --
+      // every tile spins until all tiles of its item(s) have published, and the dispatch order interleaves the items of a group of 8 M tiles,
+      // so an item's tiles plus two dispatch groups (the one it sits in, the one a straddling tile reaches into) must be resident together
+      // even while the other batch parts' launches hold their share of the chip (three workgroups of these kernels fit a CU: 41-51 KB of
+      // ring, <= 168 registers; the parts run concurrently).  A long single file (sample.py's whole-file mode: B = 1, L = samples / hop)
+      // fails (ii) and takes the conv + gn_apply pair instead of stalling every fused launch for its time-out.
+      const int concurrent = std::max(2, c->split_batch);
+      const long resident_slots = (long)(3 * 256 / concurrent) * 8 / 10;
+      auto few_tiles = [&](const int* t) {
+        if (t[0] <= 0 || t[3] <= 0) return false;
+        const long ntn = (r.cout + t[3] - 1) / t[3];
+        const long launch_tiles = (long)((rows + t[0] - 1) / t[0]) * ntn;
+        const long item_tiles = (long)((L + t[0] - 1) / t[0] + 1) * ntn;
+        return launch_tiles <= c->gn_epi_max_tiles && (launch_tiles <= resident_slots || item_tiles + 16 * ntn <= resident_slots);
+      };
+      epi1 = (!f8 || dt == DT_BF16) && few_tiles(t1) && t1[0] <= 2 * L && take_part(&ge1, L, t1[0], t1[1], r.cout);   // f8: block1's output in fp8
       conv_bm(f8 ? r.c2_f8 : r.c2, L, L, false, t2);
-      epi2 = (!(out_mode & 1) || dt == DT_BF16) && few_tiles(t2[0]) && t2[0] <= 2 * L && take_part(&ge2, L, t2[0], t2[1], r.cout);
+      epi2 = (!(out_mode & 1) || dt == DT_BF16) && few_tiles(t2) && t2[0] <= 2 * L && take_part(&ge2, L, t2[0], t2[1], r.cout);
     }
     void* a = epi1 ? nullptr : act(rows, r.cout);   // un-normalised conv outputs exist only on the unfused path
     void* d = epi2 ? nullptr : act(rows, r.cout);
@@ -1404,7 +1419,7 @@ struct PlanBuilder {
     bool folded = false;
     void* rr = r.has_res ? act(rows, r.cout) : nullptr;
     if (r.has_res && c->fold_res && r.c1r.w) {
-      int t[3];
+      int t[4];
       conv_bm(r.c1, L, L, false, t);
       folded = t[0] > 0 && t[2] == 1;
     }
@@ -1497,7 +1512,7 @@ struct PlanBuilder {
   // in front fuses its GroupNorm apply (else its gn_apply launch writes the LayerNorm output on the way at no extra launch)
   bool ln_foldable(const LinAttnW& a, int L) {
     if (!c->fold_ln || !c->fuse_gn_epi || c->w8 || !a.qkv_ln.w || L < c->gn_epi_min_l) return false;
-    int t[3];
+    int t[4];
     conv_bm(a.qkv_ln, L, L, false, t);
     return t[0] > 0;
   }

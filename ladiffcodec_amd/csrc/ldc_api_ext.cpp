@@ -86,22 +86,28 @@ extern "C" int ldc_resample(ldc_ctx* c, const float* wav, int C, int64_t T, int 
   }
   const int g = gcd_i(orig_freq, new_freq);
   const int orig = orig_freq / g, nnew = new_freq / g;
-  // torchaudio 0.13 _get_sinc_resample_kernel: lowpass_filter_width 6, rolloff 0.99, Hann window, built in float64
+  // torchaudio 0.13 _get_sinc_resample_kernel: lowpass_filter_width 6, rolloff 0.99, Hann window.  functional.resample (the entry
+  // srcs/sample.py:84 calls) hands the WAVEFORM's dtype to the kernel builder, so for the fp32 tensors torchaudio.load returns the bank
+  // is built in fp32 tensor arithmetic (float64 is the transforms.Resample path, dtype=None): the same operations in the same order
+  // here, every Python-float scalar rounded to fp32 where torch applies it to an fp32 tensor.
   const double lpw = 6.0, rolloff = 0.99, pi = 3.14159265358979323846;
   const double base_freq = std::min(orig, nnew) * rolloff;
   const int width = (int)ceil(lpw * orig / base_freq);
   const int K = 2 * width + orig;
   if ((double)nnew * K > 64e6) return fail(LDC_E_INVALID, "resampling %d -> %d needs a %d x %d filter bank: rates too incommensurate", orig_freq, new_freq, nnew, K);
   std::vector<float> bank((size_t)nnew * K);
-  const double scale = base_freq / orig;
+  const float scale_f = (float)(base_freq / orig), base_f = (float)base_freq, pi_f = (float)pi, lpw_f = (float)lpw;
   for (int p = 0; p < nnew; ++p)
     for (int k = 0; k < K; ++k) {
-      double t = ((double)(-p) / nnew + (double)(k - width) / orig) * base_freq;
-      t = std::max(-lpw, std::min(lpw, t));
-      const double win = cos(t * pi / lpw / 2.0);
-      const double tp = t * pi;
-      const double sinc = tp == 0.0 ? 1.0 : sin(tp) / tp;
-      bank[(size_t)p * K + k] = (float)(sinc * win * win * scale);
+      const float idx = (float)(k - width) / (float)orig;        // arange(-width, width + orig) / orig
+      float t = (float)(-p) / (float)nnew + idx;                 // arange(0, -new, -1) / new + idx
+      t *= base_f;
+      t = std::max(-lpw_f, std::min(lpw_f, t));
+      const float cw = cosf(t * pi_f / lpw_f / 2.0f);
+      const float win = cw * cw;                                 // ** 2
+      t *= pi_f;
+      const float sinc = t == 0.0f ? 1.0f : sinf(t) / t;
+      bank[(size_t)p * K + k] = sinc * (win * scale_f);          // kernels *= window * scale
     }
   const int64_t target = ldc_resample_out_len(T, orig_freq, new_freq);
   LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {

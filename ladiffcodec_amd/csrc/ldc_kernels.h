@@ -105,7 +105,7 @@ struct ConvCall {
   int kst_stride = 0;
   const ConvTune* tune = nullptr;   // null: defaults
   long long* sk_need = nullptr;     // dry run: no launch, *sk_need = split-K workspace floats this call would use
-  int* bm_out = nullptr;            // dry run (with sk_need): int[2] = rows per tile of the pipelined kernel (0 when the generic kernel would run), wave rows WM, split-K factor
+  int* bm_out = nullptr;            // dry run (with sk_need): int[4] = rows per tile of the pipelined kernel (0 when the generic kernel would run), wave rows WM, split-K factor, columns per tile
 };
 
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);

@@ -145,7 +145,13 @@ def wav_header(path: str) -> Tuple[int, int, int]:
             cid, size = hdr[:4], struct.unpack("<I", hdr[4:])[0]
             if cid == b"fmt ":
                 fmt = f.read(size + (size & 1))
-                _, ch, sr, _, block, _ = struct.unpack("<HHIIHH", fmt[:16])
+                if len(fmt) < 16:
+                    raise ValueError(f"{path}: 'fmt ' chunk of {len(fmt)} bytes (16 needed)")
+                tag, ch, sr, _, block, _ = struct.unpack("<HHIIHH", fmt[:16])
+                if tag == 0xFFFE and len(fmt) >= 26:            # WAVE_FORMAT_EXTENSIBLE: the real tag opens the sub-format GUID
+                    tag = struct.unpack("<H", fmt[24:26])[0]
+                if tag not in (1, 3):                            # PCM / IEEE float: the only containers whose block count is a sample count
+                    raise ValueError(f"{path}: WAVE format tag {tag:#x} is not PCM or IEEE float")
             elif cid == b"data":
                 here = f.tell()
                 f.seek(0, 2)
@@ -156,12 +162,17 @@ def wav_header(path: str) -> Tuple[int, int, int]:
     if not ch or not sr or not block or n_bytes is None:
         raise ValueError(f"{path}: no 'fmt ' / 'data' chunk")
     n = n_bytes // block
-    if sr == 16000:
-        n16 = n
-    else:
-        from . import lib as L
-        n16 = int(L.load().ldc_resample_out_len(n, int(sr), 16000))
-    return int(ch), int(n16), int(sr)
+    return int(ch), resample_out_len(n, int(sr), 16000), int(sr)
+
+
+def resample_out_len(n: int, sr_in: int, sr_out: int) -> int:
+    """Samples torchaudio.functional.resample returns for n input samples: ceil(new * n / orig) on the gcd-reduced rates
+    (the arithmetic of ldc_resample_out_len, restated in Python so that header planning needs no built library;
+    tests/test_cli_and_parallel_cpu.py holds the two to each other)."""
+    import math
+    g = math.gcd(int(sr_in), int(sr_out))
+    o, nw = int(sr_in) // g, int(sr_out) // g
+    return int(-(-nw * int(n) // o))
 
 
 class LazyWavs:
