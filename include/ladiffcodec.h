@@ -354,6 +354,11 @@ int ldc_timeline_read(ldc_ctx* ctx, int part, int n, uint64_t* ticks);
 int ldc_kstamps_enable(ldc_ctx* ctx, int on);
 int ldc_kstamps_reset(ldc_ctx* ctx);
 int ldc_kstamps_read(ldc_ctx* ctx, int idx, int n_steps, int* n_ops, uint64_t* ticks, char* infos, int info_cap, int* classes);
+/* Tuning aid (LDC_CHAIN_STAMPS=1 in the environment before the plan is built): the per-tile s_memtime stamps of chain `chain` of the
+ * last UNet call's XCD-team plan: out[8 teams][meta[0]][12] (0 body start, 1 prologue done, 2 K loop done, 3 tile end, 4 tile tables,
+ * 5 first copies issued, 7 dependency wait over, 8 before the ticket pull, 9 ticket known, 10 after the tile, 11 conv index);
+ * meta[1] = convs of the chain, meta[2 ...] = int[8][17] first ticket of every conv per team.  out == NULL: only *n_chains. */
+int ldc_chain_stamps(ldc_ctx* ctx, int chain, unsigned long long* out, long long cap_u64, int* meta, int* n_chains, char* info, int info_cap);
 /* Tuning aid: times the GroupNorm-apply kernel on [B,L,C] (random data, fixed statistics). */
 int ldc_gn_microbench(ldc_ctx* ctx, int dtype, int B, int L, int C, int with_residual, int iters, double* ms_per_launch);
 /* Tuning aid: times `iters` launches of one conv-GEMM (random weights/inputs) of the given shape with

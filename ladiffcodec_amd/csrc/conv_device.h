@@ -10,6 +10,18 @@ namespace ldc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Thread index of the epilogue / prologue helpers.  In the chain kernel (LDC_OPAQUE_TID) the tile body sits inside a persistent loop and
+// everything that depends on the lane alone (LDS staging offsets of the epilogues, swizzles, fragment offsets: ~55 registers) would be
+// hoisted out of the loop and stay live across the whole tile (168 registers + 34 spilled instead of ~150); an opaque copy per use
+// keeps those values where they are consumed.  Costs no instruction.
+__device__ __forceinline__ int ldc_tid() {
+  int t = (int)threadIdx.x;
+#ifdef LDC_OPAQUE_TID
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
+
 static constexpr int kRowBytes = 64;   // bytes of K (channels) per LDS row per chunk: 32 bf16 or 16 f32
 
 // Division by a launch-invariant divisor (Granlund-Montgomery, exact for every 32-bit n): gfx950 has no integer divide, so
@@ -25,7 +37,9 @@ inline FastDivU make_fastdiv(unsigned d) {
   r.m = (unsigned)m; r.sh1 = l < 1 ? l : 1u; r.sh2 = l > 0 ? l - 1 : 0u;
   return r;
 }
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDivU& d) {
+// (D: FastDivU in any address space -- the chain kernel reads its descriptors through the constant address space)
+template <typename D>
+__device__ __forceinline__ unsigned fdiv(unsigned n, const D& d) {
   const unsigned t = __umulhi(d.m, n);
   return (t + ((n - t) >> d.sh1)) >> d.sh2;
 }
@@ -87,9 +101,92 @@ struct ConvKArgs {
   char* y2;                // folded 1x1 conv (ConvLayer::wtaps): second output [rows][n], or null
   const float* bias2;
   int wtaps;               // weight slabs per channel chunk in the packed image (taps, or taps + 1 with the folded conv)
+  int m_decide;            // host-only: GEMM rows the tile-shape / split-K decisions are made for (0: the call's own B * L_rows).  The XCD-team
+                           // chains (conv_chain_kernel) process the whole batch in one launch but keep the shapes tuned for half of it
   const ConvTune* tune;    // host-only (never read on the device)
   long long* sk_need;      // host-only: dry run
   int* bm_out;             // host-only: dry run -- rows per tile the fast kernel would use (0: generic kernel); bm_out[1] = wave rows WM, bm_out[2] = split-K factor, bm_out[3] = columns per tile
+};
+
+// ---- geometry of one launch of the pipelined kernel (conv_fast.inc), decided on the host ----
+struct FastGeom {
+  int a_rows;        // window rows per plane (multiple of 16 * waves); each plane is followed by a zero row
+  int b_rows;        // weight rows per unit (NS * BN rounded up to 16 * waves)
+  int stage_bytes;
+  int ngroups;       // tap groups per chunk group (k=7: 2)
+  int m_fastest;     // tile order inside an XCD's run: M-tile fastest (weights dominate) or N-tile fastest
+  int item_major;    // fused GroupNorm apply: dispatch order follows the items (see the tile-order comment in the kernel)
+  FastDivU d_grp, d_rem, d_per;   // item_major: divisions by 8 * ntn, by ntm % 8 and by ntn / 8
+  int grid;          // workgroups of this conv (tiles x split-K slices)
+  int ln_off;        // folded LayerNorm: LDS byte offset of the tile's (mean, rstd) table, behind the ring and the epilogue staging
+  // chained pair (conv_fast_pair_kernel): the producer's waves count their finished, drained stores per M tile in pair_done
+  // (zeroed by the step's first kernel); a consumer tile starts its window copies once the M tiles under its window show
+  // pair_expect arrivals each
+  unsigned* pair_done;
+  unsigned pair_expect;
+  int debug;         // tuning aid (LDC_CONV_DEBUG) bits: 1 no copies after the prologue, 4 no output stores, 8 return at once, 16 one unit only
+  int ntiles, ntn, ntm;                      // output tiles, tiles along N / along M (set by the launcher)
+  FastDivU d_ntiles, d_ntn, d_ntm, d_ksplit; // divisions by them, prepared on the host
+  unsigned long long* stamps;   // tuning aid: per workgroup {start, prologue done, loop done, end} s_memtime
+};
+
+// what the launcher of the pipelined kernel decided for one conv, captured instead of launched (chained pair, XCD-team chains)
+struct FastPrep {
+  ConvKArgs a;
+  FastGeom gm;
+  int wm, wn, tm, tn, tg, kc, na, rf;
+  size_t lds;
+  bool set = false;
+};
+
+// ---- XCD-team chains (conv_chain_kernel, round 5) ------------------------------------------------------------------------------
+// A run of consecutive convs of the denoise step as ONE persistent launch.  The batch items are pinned to the eight XCDs (team x
+// owns items [B x / 8, B (x + 1) / 8) of EVERY conv of the chain), a workgroup reads its XCC id, joins that XCD's team and pulls
+// tiles from the team's ticket head (conv-major: all tiles of conv 0, then conv 1, ...; N tile fastest inside an M tile).  A
+// consumer tile waits only for the producer tiles under its window -- flags the producers plain-store into their XCD's L2 once
+// their output rows have drained (the reader polls and reads its window past the L1: sc1) -- so a layer boundary inside a team
+// costs a 0.4 us hand-off instead of a 2.6 us kernel boundary plus a chip-wide cold first-unit burst, the activations between
+// two convs of a chain never leave the XCD's L2, and the eight teams and the items inside a team drift out of phase
+// (profiles/r05_xcd_team_probe.md).  Flags carry the epoch of the UNet pass (step state word 4), never cleared.
+static constexpr int kChainMax = 16;    // convs per chain
+struct ChainDep {
+  int prod;            // index of the producing conv inside the chain, -1: the tensor was written before the launch
+  int bm_shift;        // log2 of the producer's tile height
+  int ntn;             // producer tiles along N (flags per M tile)
+  int lrows;           // rows per item of the producer's output
+  unsigned flag_off;   // the producer's flag region (words from ChainHead::flags)
+  unsigned team_words; // ... stride between teams
+};
+struct ChainConv {
+  ConvKArgs a;
+  FastGeom gm;
+  int variant;         // kernel shape index (conv_chain_kernel's switch)
+  int bm, bn;
+  unsigned flag_off;   // this conv's flags: [team][M tile of the team][N tile] words from ChainHead::flags + flag_off
+  unsigned team_words;
+  int sk_team_tiles;   // split-K: tile slots per team in this conv's own workspace (a.sk_part / a.sk_count)
+  ChainDep dep[3];     // producers of x1 (and its row statistics), x2, residual
+};
+struct ChainHead {
+  int nconv, B;
+  unsigned* heads;         // [8][16] ticket heads, one 64-byte line per team, zeroed by the step's first kernel
+  unsigned* flags;
+  const int* step_state;   // [4] = epoch of the UNet pass (incremented by launch_step_begin)
+  unsigned* fail_flag;
+  unsigned long long* stamps;    // tuning aid (LDC_CHAIN_STAMPS): 12 s_memtime stamps per tile at [(team * stamp_team_stride + ticket) * 12], or null
+  int stamp_team_stride;
+  int first[8][kChainMax + 1];   // per team: first ticket of every conv; [nconv] = tickets of the team
+};
+struct ChainCtx {          // what a tile of a chained conv knows about its team (registers of conv_chain_kernel)
+  int m_lo, m_hi;          // the team's rows of this conv's output
+  int b_lo;                // the team's first item
+  unsigned epoch;
+  unsigned* my_flags;      // this conv's flags of this team
+  const unsigned* dep_flags[3];
+  int dep_shift[3], dep_ntn[3], dep_base[3];   // producer's tile-height shift, N tiles, first row of its tiling for this team
+  int sk_tile_base;
+  unsigned* fail_flag;
+  unsigned long long t_dep;   // tuning aid: s_memtime after the dependency wait
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -145,7 +242,8 @@ __device__ __forceinline__ float load_in<__bf16>(const char* p, size_t idx) {
 }
 
 // flat input row reached from GEMM row (b, l) with tap offset `toff` (= tap*dil); -1 when it is padding
-__device__ __forceinline__ int gather_row(const ConvKArgs& a, int b, int l, int toff) {
+template <typename KA>
+__device__ __forceinline__ int gather_row(const KA& a, int b, int l, int toff) {
   int u = l * a.stride + toff - a.pad_left;
   const int leff = a.L_in << a.ups;
   if (a.pad_mode == PAD_REFLECT) {
@@ -157,7 +255,8 @@ __device__ __forceinline__ int gather_row(const ConvKArgs& a, int b, int l, int 
 }
 
 // [R_lo, R_hi]: flat input rows a BM-row tile starting at m0 touches (zero-pad convs; monotone in m and tap)
-__device__ __forceinline__ void tile_window(const ConvKArgs& a, int m0, int BM, int M, int& R_lo, int& R_hi) {
+template <typename KA>
+__device__ __forceinline__ void tile_window(const KA& a, int m0, int BM, int M, int& R_lo, int& R_hi) {
   const int leff = a.L_in << a.ups;
   const int m_last = min(m0 + BM, M) - 1;
   int b = (int)fdiv((unsigned)m0, a.lrows_div), l = m0 - b * a.L_rows;
@@ -174,8 +273,8 @@ __device__ __forceinline__ void tile_window(const ConvKArgs& a, int m0, int BM, 
 }
 
 // bias (+ residual) (+ activation) and store of a wave's TM x TN accumulators (plain conv, row-major [M][n])
-template <typename T, int TM, int TN, bool RES, bool ACT>
-__device__ __forceinline__ void epilogue_plain(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M) {
+template <typename T, int TM, int TN, bool RES, bool ACT, typename KA>
+__device__ __forceinline__ void epilogue_plain(const KA& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = col0 + j * 32;
@@ -214,10 +313,10 @@ __device__ __forceinline__ unsigned float_order_key(float f) {
 // Fused column max per item of the stored (dtype-rounded) conv output, columns [colmax_lo, colmax_hi): the
 // max over positions that LinearAttention's k.softmax(dim=-1) needs (unet.py:214), so that no extra pass over
 // the qkv tensor is required for it.
-template <typename T, int TM, int TN>
-__device__ __forceinline__ void epilogue_colmax(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int m0, int BM,
+template <typename T, int TM, int TN, typename KA>
+__device__ __forceinline__ void epilogue_colmax(const KA& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int m0, int BM,
                                                 int M) {
-  const int lane = threadIdx.x & 63;
+  const int lane = ldc_tid() & 63;
   const int b_first = (int)fdiv((unsigned)m0, a.lrows_div);
   const int b_last = (int)fdiv((unsigned)(min(m0 + BM, M) - 1), a.lrows_div);
 #pragma unroll
@@ -251,10 +350,10 @@ __device__ __forceinline__ void epilogue_colmax(const ConvKArgs& a, f32x16 (&acc
 // i.e. one group; lanes of a group are reduced with xor-shuffles (channels per group: a power of two >= 4 that
 // divides or is a multiple of 32), then one lane per group issues the two atomics.  Rows of several items can
 // meet in one tile, hence the (wave-uniform) loop over the items the tile touches.
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue_gn_stats(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int m0,
+template <int TM, int TN, typename KA>
+__device__ __forceinline__ void epilogue_gn_stats(const KA& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int m0,
                                                   int BM, int M) {
-  const int lane = threadIdx.x & 63;
+  const int lane = ldc_tid() & 63;
   const int b_first = (int)fdiv((unsigned)m0, a.lrows_div);
   const int b_last = (int)fdiv((unsigned)(min(m0 + BM, M) - 1), a.lrows_div);
   const int cpg = a.gn_cpg;
@@ -311,8 +410,8 @@ __device__ __forceinline__ void epilogue_gn_stats(const ConvKArgs& a, f32x16 (&a
   }
 }
 
-template <typename T, int TM, int TN>
-__device__ __forceinline__ void epilogue_dispatch(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M,
+template <typename T, int TM, int TN, typename KA>
+__device__ __forceinline__ void epilogue_dispatch(const KA& a, f32x16 (&acc)[TM][TN], int mrow0, int col0, int M,
                                                   int m0 = 0, int BM = 0) {
   if (a.gn_sum) epilogue_gn_stats<TM, TN>(a, acc, mrow0, col0, m0, BM, M);
   if (a.colmax) epilogue_colmax<T, TM, TN>(a, acc, mrow0, col0, m0, BM, M);
@@ -329,14 +428,14 @@ __device__ __forceinline__ void epilogue_dispatch(const ConvKArgs& a, f32x16 (&a
 // a 64x64 wave tile; measured ~375 cycles per store instruction, ~10 us per workgroup -- longer than the whole
 // MFMA loop of a 256-channel k=3 conv).  Here each wave transposes its tile through LDS (ring stages are free
 // once the K loop has drained) and writes whole rows: 16 bytes per lane, 8 rows x 128 B per store instruction.
-template <typename T, int TM, int TN, bool RES, bool ACT>
-__device__ __forceinline__ void epilogue_rows(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
+template <typename T, int TM, int TN, bool RES, bool ACT, typename KA>
+__device__ __forceinline__ void epilogue_rows(const KA& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
                                               int col_wave0, int M) {
   constexpr int RB = TN * 32 * (int)sizeof(T);      // bytes per tile row
   constexpr int PITCH = RB + 16;
   constexpr int LPR = RB / 16;                      // lanes per row in the read-back
   constexpr int RPS = 64 / LPR;                     // rows per sweep
-  const int lane = threadIdx.x & 63;
+  const int lane = ldc_tid() & 63;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = col_wave0 + j * 32 + (lane & 31);
@@ -386,6 +485,8 @@ __device__ __forceinline__ void store16_wt(char* p, const uint4& v) {
 __device__ __forceinline__ void load16_sc1_issue(u32x4_t& dst, const char* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(dst) : "v"(p) : "memory");
 }
+// a PLAIN dword store the compiler can neither drop nor promote (a volatile store compiles to `sc0 sc1`): stays in this XCD's L2
+__device__ __forceinline__ void store_plain_u32(unsigned* p, unsigned v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Fused GroupNorm apply of a wave's TM x TN accumulators (ConvKArgs::gn_part != null).
@@ -402,10 +503,12 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 // residual is added to the un-rounded value as 16-byte pieces in the row phase (one rounding, like gn_apply), then the
 // optional tanh.  A tile may straddle items (flat M tiling); the launcher guarantees 2 * L_rows >= BM, i.e. at most three.
 // The spin is bounded by the 100 MHz wall clock: tiles that are not all resident in time raise the host-mapped flag, never a hang.
-template <typename T, int TM, int TN, bool RES>
-__device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
-                                                  int col_wave0, int M, int m0, int BM, int WM, int wm) {
-  const int lane = threadIdx.x & 63;
+template <typename T, int TM, int TN, bool RES, typename KA>
+__device__ __forceinline__ void epilogue_gn_fused(const KA& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
+                                                  int col_wave0, int M, int m0, int BM, int WM, int wm, int m_base = 0) {
+  // m_base: first row of the M tiling this tile belongs to (0: the flat tiling of a launch of its own; an XCD team of a chain tiles
+  // its own rows from its first item's first row, and M is then the team's last row + 1)
+  const int lane = ldc_tid() & 63;
   const int b_first = (int)fdiv((unsigned)m0, a.lrows_div);
   const int b_last = (int)fdiv((unsigned)(min(m0 + BM, M) - 1), a.lrows_div);
   const int m_split = (b_first + 1) * a.L_rows;   // rows >= m_split belong to item b_first + 1, rows >= m_split2 to b_first + 2
@@ -413,7 +516,7 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
   const int cpg = a.gn_cpg;                       // a multiple of 32: a 32-column block lies inside one group
   const int sub_n = cpg >> 5;                     // 32-column blocks per group (a power of two)
   const int nc32 = a.n >> 5;
-  const int mt = m0 / BM;
+  const int mt = (m0 - m_base) / BM;
   float bv[TN], wsc[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -456,7 +559,7 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
         ss += __shfl_xor(ss, o);
       }
       if (lane == 0 && c32 < nc32) {
-        const int mslot = mt - lo / BM;
+        const int mslot = mt - (lo - m_base) / BM;
         char* dst = a.gn_part + ((((size_t)bb * a.gn_mslots + mslot) * WM + wm) * nc32 + c32) * 16;
         store16_wt(dst, make_uint4(1u, __float_as_uint(s), 1u, __float_as_uint(ss)));
       }
@@ -469,7 +572,7 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
   // statistics of (item bb, the group of 32-column block c32_0) -> mean, rstd (wave-uniform values, computed by every lane)
   auto gather = [&](int bb, int g, float& mean, float& rstd) {
     const int lo = bb * a.L_rows, hi = min(lo + a.L_rows, M);
-    const int total = ((hi - 1) / BM - lo / BM + 1) * WM * sub_n;   // granule pairs of (item bb, group g)
+    const int total = ((hi - 1 - m_base) / BM - (lo - m_base) / BM + 1) * WM * sub_n;   // granule pairs of (item bb, group g)
     const char* base = a.gn_part + (size_t)bb * a.gn_mslots * WM * nc32 * 16 + (size_t)g * sub_n * 16;
     float s = 0.f, ss = 0.f;
     for (int l0 = 0; l0 < total; l0 += 64) {
@@ -657,14 +760,14 @@ __device__ __forceinline__ void epilogue_gn_fused(const ConvKArgs& a, f32x16 (&a
 }
 
 // Second output of a launch with a folded 1x1 conv (ConvKArgs::y2): acc + bias2, whole-row stores through the same LDS staging.
-template <typename T, int TM, int TN>
-__device__ __forceinline__ void epilogue_rows_second(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
+template <typename T, int TM, int TN, typename KA>
+__device__ __forceinline__ void epilogue_rows_second(const KA& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
                                                      int col_wave0, int M) {
   constexpr int RB = TN * 32 * (int)sizeof(T);
   constexpr int PITCH = RB + 16;
   constexpr int LPR = RB / 16;
   constexpr int RPS = 64 / LPR;
-  const int lane = threadIdx.x & 63;
+  const int lane = ldc_tid() & 63;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = col_wave0 + j * 32 + (lane & 31);
@@ -692,13 +795,13 @@ __device__ __forceinline__ void epilogue_rows_second(const ConvKArgs& a, f32x16 
   }
 }
 
-template <typename T, int TM, int TN>
-__device__ __forceinline__ void epilogue_rows_dispatch(const ConvKArgs& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
-                                                       int col_wave0, int M, int m0, int BM, int WM = 1, int wm = 0) {
-  const int lane = threadIdx.x & 63;
+template <typename T, int TM, int TN, typename KA>
+__device__ __forceinline__ void epilogue_rows_dispatch(const KA& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
+                                                       int col_wave0, int M, int m0, int BM, int WM = 1, int wm = 0, int m_base = 0) {
+  const int lane = ldc_tid() & 63;
   if (a.gn_part) {   // fused GroupNorm apply (uniform over the launch)
-    if (a.residual || (a.gn_out & 1)) epilogue_gn_fused<T, TM, TN, true>(a, acc, wave_lds, m_wave0, col_wave0, M, m0, BM, WM, wm);
-    else epilogue_gn_fused<T, TM, TN, false>(a, acc, wave_lds, m_wave0, col_wave0, M, m0, BM, WM, wm);
+    if (a.residual || (a.gn_out & 1)) epilogue_gn_fused<T, TM, TN, true>(a, acc, wave_lds, m_wave0, col_wave0, M, m0, BM, WM, wm, m_base);
+    else epilogue_gn_fused<T, TM, TN, false>(a, acc, wave_lds, m_wave0, col_wave0, M, m0, BM, WM, wm, m_base);
     return;
   }
   if (a.gn_sum) epilogue_gn_stats<TM, TN>(a, acc, m_wave0 + 4 * (lane >> 5), col_wave0 + (lane & 31), m0, BM, M);
@@ -719,6 +822,11 @@ hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a, int M, int 
 hipError_t launch_conv_fast_fp8(const ConvLayer& ly, const ConvKArgs& a_in, int M, int span_rows, hipStream_t s, bool* launched);
 hipError_t launch_conv_fast_bf16w8(const ConvLayer& ly, const ConvKArgs& a_in, int M, int span_rows, hipStream_t s, bool* launched);
 // two dependent ResnetBlock convs as one launch (conv_fast.inc: conv_fast_pair_kernel); bf16 / f32 weights only
+// XCD-team chains (bf16 engine): decisions of the pipelined kernel for one conv (prep), then the persistent launch (conv_chain_bf16.hip)
+hipError_t prep_conv_fast_bf16(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, FastPrep* out, bool* ok);
+int conv_chain_variant(const FastPrep& p);   // -1: this kernel shape is not in the chain kernel
+hipError_t launch_conv_chain_bf16(const ChainHead* head_dev, const ChainConv* convs_dev, size_t lds_bytes, int grid, hipStream_t s);
+int conv_chain_max_blocks_per_cu(size_t lds_bytes);
 hipError_t launch_conv_fast_pair(const ConvLayer& ly0, const ConvKArgs& a0, int M0, int span0, const ConvLayer& ly1, const ConvKArgs& a1, int M1,
                                  int span1, unsigned* pair_done, int pair_done_cap, hipStream_t s, bool* launched);
 

@@ -336,15 +336,17 @@ __global__ void step_set_kernel(int* st, int t, int j, unsigned key_lo, unsigned
 }
 // Also clears the step's accumulator region (GroupNorm sums, split-K counters, k-max keys: until round 3 a memset node of its own
 // in front of every step): zero_n16 16-byte pieces starting at `zero`.
-__global__ __launch_bounds__(256) void step_begin_kernel(const float* table, int stride, const int* st, float* cur,
+// st[4]: epoch of the UNet pass, counted up here: the XCD-team chains tag their tile flags with it (never cleared, never 0)
+__global__ __launch_bounds__(256) void step_begin_kernel(const float* table, int stride, int* st, float* cur,
                                                          unsigned long long* tl, uint4* zero, long long zero_n16) {
   if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[2 * (st[1] & 2047)] = wall_clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 0) st[4] = st[4] + 1;
   const float* row = table + (size_t)st[0] * stride;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < stride; i += gridDim.x * 256) cur[i] = row[i];
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n16; i += (long long)gridDim.x * 256) zero[i] = z;
 }
-hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, unsigned long long* tl, hipStream_t s,
+hipError_t launch_step_begin(const float* table, int stride, int* st, float* cur, unsigned long long* tl, hipStream_t s,
                              void* zero, size_t zero_bytes) {
   const long long n16 = (long long)((zero_bytes + 15) / 16);
   const long long want = std::max<long long>((stride + 255) / 256, (n16 + 1023) / 1024);

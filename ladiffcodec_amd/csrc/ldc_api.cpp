@@ -683,6 +683,10 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->side_streams = (getenv("LDC_SIDE") && c->split_batch == 1) ? 1 : 0;
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
+  c->xcd_teams = env_int("LDC_TEAMS", c->xcd_teams);
+  c->teams_min_b = std::max(1, env_int("LDC_TEAMS_MINB", c->teams_min_b));
+  c->teams_parts = std::max(1, env_int("LDC_TEAMS_PARTS", c->teams_parts));
+  c->teams_max_chain = std::max(1, std::min(kConvChainMax, env_int("LDC_TEAMS_MAXCHAIN", c->teams_max_chain)));
   c->gn_epi_min_l = env_int("LDC_GN_EPI_MINL", c->gn_epi_min_l);
   c->gn_epi_max_tiles = env_int("LDC_GN_EPI_MAXTILES", c->gn_epi_max_tiles);
   c->fold_res = getenv("LDC_NO_RES_FOLD") ? 0 : 1;
@@ -829,6 +833,10 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->fuse_gn_epi) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fuse_gn_epi = value ? 1 : 0; }
     return LDC_OK;
   }
+  if (n == "xcd_teams") {   // XCD-team chains on / off (plans are rebuilt); off = the round-4 launch structure (two batch parts, one launch per conv)
+    if ((value ? 1 : 0) != c->xcd_teams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->xcd_teams = value ? 1 : 0; }
+    return LDC_OK;
+  }
   if (n == "fold_ln") {
     if ((value ? 1 : 0) != c->fold_ln) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fold_ln = value ? 1 : 0; }
     return LDC_OK;
@@ -846,7 +854,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
@@ -1248,8 +1256,12 @@ struct PlanBuilder {
     pl->act_bytes += (double)rows * C * es;
     return ar->alloc((size_t)rows * C * es);
   }
+  bool team = false;   // XCD-team plan: tile shapes decided for half the batch, every conv op recorded for build_chains
+  int m_decide(int L_out) const { return team ? (c->teams_parts > 1 ? B : (B + 1) / 2) * L_out : 0; }
   int where = 0;   // stream selector for the ops being added (0 main, 1 side)
   void mark(int kind) {   // 2 = fork (side waits for main), 3 = join (main waits for side)
+    pl->step_chain.push_back(Plan::ChainSlot());
+    pl->step_chain.back().marker = true;
     pl->step_ops.push_back([](hipStream_t) { return hipSuccess; });
     pl->step_is_conv.push_back(0);
     pl->step_where.push_back(kind);
@@ -1260,8 +1272,9 @@ struct PlanBuilder {
   }
   void add(std::function<hipError_t(hipStream_t)> f, bool is_conv = false, double flops = 0, int cls = LDC_CLASS_OTHER,
            double bytes = 0) {
+    pl->step_chain.push_back(Plan::ChainSlot());
     pl->step_ops.push_back(std::move(f));
-    pl->step_where.push_back(where);
+    pl->step_where.push_back(team ? 0 : where);
     pl->step_is_conv.push_back(is_conv ? 1 : 0);
     pl->step_flops.push_back(flops);
     pl->step_class.push_back(is_conv ? LDC_CLASS_CONV : cls);
@@ -1289,7 +1302,7 @@ struct PlanBuilder {
   // (out[0] = rows per tile, out[1] = wave rows, out[2] = split-K factor)
   void conv_bm(const ConvLayer& ly, int L_in, int L_out, bool with_stats, int* out) {   // out: int[4]
     ConvCall d;
-    d.B = B; d.L_in = L_in; d.L_rows = L_out; d.y_ld = ly.n; d.tune = &c->tune;
+    d.B = B; d.L_in = L_in; d.L_rows = L_out; d.y_ld = ly.n; d.tune = &c->tune; d.m_decide = m_decide(L_out);
     d.sk_part = sk_part; d.sk_count = sk_count; d.sk_part_cap = sk_part_cap; d.sk_count_cap = sk_count_cap;
     if (with_stats) { d.gn_sum = stats_pool; d.gn_groups = c->unet.groups; }
     long long need = 0;
@@ -1327,6 +1340,7 @@ struct PlanBuilder {
     cc.colmax = colmax; cc.colmax_lo = cm_lo; cc.colmax_hi = cm_hi; cc.colmax_stride = cm_stride;
     cc.sk_part = sk_part; cc.sk_count = sk_count; cc.sk_part_cap = sk_part_cap; cc.sk_count_cap = sk_count_cap;
     cc.tune = &c->tune;
+    cc.m_decide = m_decide(L_out);
     {   // dry run of the launcher: how much split-K workspace would this conv use?
       ConvCall d = cc;
       long long need = 0;
@@ -1349,6 +1363,36 @@ struct PlanBuilder {
       return;
     }
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out, LDC_CLASS_CONV, cbytes);
+    if (team) chain_slot(ly, cc, L_out);
+  }
+  // XCD-team plan: what this conv needs as a member of a chain -- its tile flags (epoch-tagged, cleared once), its own team-major split-K
+  // workspace (the convs of a chain overlap in time: the plan-wide workspace of the stand-alone launches cannot be shared) -- allocated in
+  // every planning pass from the shapes alone; whether it ends up in a chain is decided by build_chains in the final pass
+  void chain_slot(const ConvLayer& ly, const ConvCall& cc_in, int L_out) {
+    Plan::ChainSlot& sl = pl->step_chain.back();
+    sl.is_conv = true; sl.ly = &ly; sl.cc = cc_in;
+    sl.cc.kst = nullptr;
+    if (cc_in.gn_sum) return;
+    ChainInfo info;
+    if (conv_chain_info(ly, sl.cc, &info) != hipSuccess || !info.ok) return;
+    const int team_items = (B + 7) / 8;
+    const int max_mt = (team_items * L_out + info.bm - 1) / info.bm;
+    sl.info = info;
+    sl.team_words = (unsigned)(max_mt * info.ntn);
+    const size_t flag_bytes = (size_t)8 * sl.team_words * 4;
+    sl.flags = (unsigned*)ar->alloc(flag_bytes);
+    if (ar->base) pl->zero_once.push_back({sl.flags, flag_bytes});
+    if (!pl->chain_flags_base && ar->base) pl->chain_flags_base = sl.flags;
+    sl.chainable = true;
+    if (info.ks > 1) {
+      sl.sk_team_tiles = max_mt * info.ntn;
+      const long long floats = (long long)8 * sl.sk_team_tiles * info.ks * info.bm * info.bn;
+      sl.cc.sk_part = (float*)ar->alloc((size_t)floats * 4);
+      sl.cc.sk_part_cap = floats;
+      sl.cc.sk_count = (unsigned*)take_raw((size_t)8 * sl.sk_team_tiles * 4);   // (cleared every step with the granules; null while the pool is being sized)
+      sl.cc.sk_count_cap = 8 * sl.sk_team_tiles;
+      if (!sl.cc.sk_count) sl.chainable = false;
+    }
   }
   // zeroed-every-step bytes from the granule pool (nullptr while the pool is being sized)
   void* take_raw(size_t bytes) {
@@ -1403,7 +1447,7 @@ struct PlanBuilder {
       auto few_tiles = [&](const int* t) {
         if (t[0] <= 0 || t[3] <= 0) return false;
         const long ntn = (r.cout + t[3] - 1) / t[3];
-        const long launch_tiles = (long)((rows + t[0] - 1) / t[0]) * ntn;
+        const long launch_tiles = (long)(((team ? m_decide(L) : rows) + t[0] - 1) / t[0]) * ntn;   // (team plans keep the half-batch decisions)
         const long item_tiles = (long)((L + t[0] - 1) / t[0] + 1) * ntn;
         return launch_tiles <= c->gn_epi_max_tiles && (launch_tiles <= resident_slots || item_tiles + 16 * ntn <= resident_slots);
       };
@@ -1575,6 +1619,111 @@ struct PlanBuilder {
   }
 };
 
+// XCD-team plan, final pass: runs of consecutive chainable convs of the step list become ONE persistent launch each
+// (conv_fast.inc: conv_chain_kernel).  A conv joins the run in front of it unless
+//   * its residual is produced inside the run and it has no fused GroupNorm epilogue (only that epilogue reads the residual past the L1),
+//   * it folds a LayerNorm and would have to re-read rows produced inside the run (no row statistics handed over),
+//   * a fused GroupNorm exchange could not be guaranteed its workgroups: the tiles of two adjacent items of the conv (a straddling tile
+//     waits for both) + 1 must fit a team's resident workgroups (occupancy of the chain kernel with the run's LDS x 32 CUs).
+// Markers of the (disabled) side stream inside a run are dropped.
+static int build_chains(ldc_ctx* c, Plan* pl) {
+  const size_t n = pl->step_ops.size();
+  std::vector<std::function<hipError_t(hipStream_t)>> ops;
+  std::vector<int> is_conv, where, cls;
+  std::vector<double> flops, bytes;
+  std::vector<std::string> info;
+  std::vector<Plan::ChainSlot> slots;
+  auto keep = [&](size_t i) {
+    ops.push_back(pl->step_ops[i]); is_conv.push_back(pl->step_is_conv[i]); where.push_back(pl->step_where[i]); cls.push_back(pl->step_class[i]);
+    flops.push_back(pl->step_flops[i]); bytes.push_back(pl->step_bytes[i]); info.push_back(pl->step_info[i]); slots.push_back(pl->step_chain[i]);
+  };
+  size_t table_off = 0;
+  int n_chains = 0, n_chained = 0;
+  const int cus = 256;
+  size_t i = 0;
+  while (i < n) {
+    const Plan::ChainSlot& s0 = pl->step_chain[i];
+    if (!(s0.is_conv && s0.chainable) || c->teams_max_chain < 2 || n_chains >= kChainHeads) { keep(i); ++i; continue; }
+    // grow the run
+    std::vector<size_t> run;          // op indices of the member convs
+    std::vector<ChainConvDesc> desc;
+    size_t lds = 0;
+    size_t j = i;
+    auto producer = [&](const void* p) -> int {
+      if (!p) return -1;
+      for (int k = (int)desc.size() - 1; k >= 0; --k)
+        if (desc[k].cc.y == p || desc[k].cc.y2 == p) return k;
+      return -1;
+    };
+    while (j < n && (int)run.size() < c->teams_max_chain) {
+      const Plan::ChainSlot& sl = pl->step_chain[j];
+      if (sl.marker) { ++j; continue; }
+      if (!(sl.is_conv && sl.chainable)) break;
+      ChainConvDesc d;
+      d.ly = sl.ly; d.cc = sl.cc; d.flags = sl.flags; d.team_words = sl.team_words; d.sk_team_tiles = sl.sk_team_tiles;
+      d.dep[0] = producer(sl.cc.x1); d.dep[1] = producer(sl.cc.x2); d.dep[2] = producer(sl.cc.residual);
+      if (d.dep[2] >= 0 && !sl.cc.gn_part) break;
+      if (sl.ly->ln_s && d.dep[0] >= 0) {
+        if (!sl.cc.ln_rowstat || desc[d.dep[0]].cc.rowstat_out != sl.cc.ln_rowstat) break;
+      }
+      const size_t lds_try = std::max(lds, sl.info.lds);
+      if (sl.cc.gn_part) {
+        const int slots_team = conv_chain_blocks_per_cu(lds_try) * (cus / 8) / std::max(1, c->teams_parts);
+        const int need = (2 * ((sl.cc.L_rows + sl.info.bm - 1) / sl.info.bm) + 1) * sl.info.ntn + 1;
+        if (need > slots_team) break;
+        // (the members already in the run were admitted with a smaller or equal LDS footprint: re-check them against the new occupancy)
+        bool all_ok = true;
+        for (const ChainConvDesc& e : desc)
+          if (e.cc.gn_part) {
+            ChainInfo ei;
+            (void)conv_chain_info(*e.ly, e.cc, &ei);
+            if ((2 * ((e.cc.L_rows + ei.bm - 1) / ei.bm) + 1) * ei.ntn + 1 > slots_team) all_ok = false;
+          }
+        if (!all_ok) break;
+      }
+      lds = lds_try;
+      desc.push_back(d);
+      run.push_back(j);
+      ++j;
+    }
+    // trailing markers stay outside the run
+    while (j > i && !run.empty() && j - 1 > run.back()) --j;
+    if (run.size() < 2) { keep(i); ++i; continue; }
+    const size_t tb = conv_chain_table_bytes((int)run.size());
+    if (table_off + tb > pl->chain_table_bytes) { keep(i); ++i; continue; }
+    void* table = pl->chain_tables + table_off;
+    table_off += (tb + 255) / 256 * 256;
+    size_t lds_out = 0;
+    unsigned* heads = pl->chain_heads + (size_t)n_chains * 8 * 16;
+    Plan::ChainDbg dbg;
+    dbg.stamps = pl->chain_stamps ? pl->chain_stamps + (size_t)n_chains * 8 * kChainStampStride * 12 : nullptr;
+    dbg.nconv = (int)desc.size();
+    hipError_t e = conv_chain_build(desc.data(), (int)desc.size(), pl->B, heads, pl->chain_flags_base, pl->step_state, c->dev_flag_dev, table, &lds_out,
+                                    dbg.stamps, kChainStampStride, dbg.first);
+    if (e != hipSuccess) return fail(LDC_E_HIP, "conv_chain_build failed: %s", hipGetErrorString(e));
+    const int blocks = std::max(1, conv_chain_blocks_per_cu(lds_out));
+    const int grid = blocks * cus / std::max(1, c->teams_parts);
+    double fl = 0, by = 0;
+    std::string inf = "chain" + std::to_string(run.size()) + ":";
+    for (size_t r : run) { fl += pl->step_flops[r]; by += pl->step_bytes[r]; inf += " " + pl->step_info[r]; }
+    dbg.info = inf;
+    pl->chain_dbg.push_back(dbg);
+    ops.push_back([table, lds_out, grid](hipStream_t st) { return launch_conv_chain(table, lds_out, grid, st); });
+    is_conv.push_back(1); where.push_back(0); cls.push_back(LDC_CLASS_CONV); flops.push_back(fl); bytes.push_back(by); info.push_back(inf);
+    slots.push_back(Plan::ChainSlot());
+    ++n_chains; n_chained += (int)run.size();
+    i = j;
+  }
+  pl->step_ops.swap(ops); pl->step_is_conv.swap(is_conv); pl->step_where.swap(where); pl->step_class.swap(cls);
+  pl->step_flops.swap(flops); pl->step_bytes.swap(bytes); pl->step_info.swap(info); pl->step_chain.swap(slots);
+  pl->n_chains = n_chains; pl->n_chained_convs = n_chained;
+  if (getenv("LDC_TEAMS_VERBOSE")) {
+    fprintf(stderr, "[ldc] XCD-team plan B=%d L=%d: %zu launches per step (%d chains holding %d convs)\n", pl->B, pl->L, pl->step_ops.size(), n_chains, n_chained);
+    for (size_t k = 0; k < pl->step_ops.size(); ++k) fprintf(stderr, "[ldc]   %3zu %s\n", k, pl->step_info[k].c_str());
+  }
+  return LDC_OK;
+}
+
 int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const UnetW& u = c->unet;
   pl->B = B; pl->L = L; pl->F = F;
@@ -1584,6 +1733,8 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const size_t es = dt_size(dt);
   const int Cc = u.cond_channels, Cx = u.channels;
   PlanBuilder pb{c, pl, &ar, B, es};
+  pb.team = pl->team_mode;
+  pl->step_chain.clear(); pl->zero_once.clear(); pl->chain_flags_base = nullptr; pl->n_chains = 0; pl->n_chained_convs = 0; pl->chain_dbg.clear();
   const int n_gn = 2 * (int)(2 * u.downs.size() + 2 + 2 * u.ups.size() + 1);
   const size_t gn_bytes = (size_t)n_gn * B * u.groups * kGnPad * 4;
   const size_t n_lin = c->fuse_kmax ? u.downs.size() + u.ups.size() : 1;
@@ -1605,6 +1756,8 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   pb.sk_part = (float*)ar.alloc((size_t)std::max<long long>(pb.sk_part_cap, 4) * 4);
   pl->maxabs = (float*)ar.alloc((size_t)B * 4);
   pl->step_state = (int*)ar.alloc(64);
+  if (ar.base) pl->zero_once.push_back({pl->step_state, 64});   // [4] = the epoch of the UNet pass (launch_step_begin counts it up)
+  pl->chain_heads = pl->team_mode ? (unsigned*)pb.take_raw((size_t)kChainHeads * 8 * 64) : nullptr;
   pl->kst = c->kstamps ? (unsigned long long*)ar.alloc((size_t)2048 * kKstOps * 2 * 8) : nullptr;
   pl->cur_ss = (float*)ar.alloc((size_t)std::max(1, u.ss_stride) * 4);
   pl->x_cl = ar.alloc((size_t)B * L * Cx * es);
@@ -1724,6 +1877,14 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     }
     pb.conv(f8 ? u.final_conv_f8 : u.final_conv, th, nullptr, pl->eps_cl, nullptr, L, L);
   }
+  if (pl->team_mode) {
+    int n_conv = 0;
+    for (const auto& sl : pl->step_chain) n_conv += sl.is_conv ? 1 : 0;
+    pl->chain_table_bytes = (size_t)n_conv * conv_chain_table_bytes(1) + 4096;   // (a head per conv at worst)
+    pl->chain_tables = (char*)ar.alloc(pl->chain_table_bytes);
+    pl->chain_stamps = getenv("LDC_CHAIN_STAMPS") ? (unsigned long long*)ar.alloc((size_t)kChainHeads * 8 * kChainStampStride * 12 * 8) : nullptr;
+    if (ar.base) LDCCHK(build_chains(c, pl));
+  }
   return LDC_OK;
 }
 
@@ -1747,19 +1908,26 @@ static void evict_plan(ldc_ctx* c, size_t idx) {
   c->plans.erase(c->plans.begin() + idx);
 }
 
-static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Plan** out) {
+static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Plan** out, bool team = false) {
   for (auto& p : c->plans)
-    if (p->B == B && p->L == L && p->F == F && p->slot == slot) {
+    if (p->B == B && p->L == L && p->F == F && p->slot == slot && p->team_mode == team) {
       p->last_use = ++c->use_tick;
       *out = p.get();
       return LDC_OK;
     }
   std::unique_ptr<Plan> pl(new Plan());
+  pl->team_mode = team;
   {   // pass 1: what do the convs of this plan need as split-K workspace?
     Arena dry;
     LDCCHK(build_plan(c, pl.get(), dry, B, L, F));
     pl->sk_floats = pl->sk_need_max;
     pl->part_bytes = pl->part_need;
+    // once more with those sizes: convs that fuse their GroupNorm apply only once the granule pool exists ask for more of it (an XCD-team
+    // plan also keeps the split-K counters of its chained convs there), and the split-K decisions feed back into what is folded
+    Arena dry2;
+    LDCCHK(build_plan(c, pl.get(), dry2, B, L, F));
+    pl->sk_floats = std::max(pl->sk_floats, pl->sk_need_max);
+    pl->part_bytes = std::max(pl->part_bytes, pl->part_need);
   }
   Arena measure;
   LDCCHK(build_plan(c, pl.get(), measure, B, L, F));
@@ -1782,6 +1950,10 @@ static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Pl
   real.cap = want;
   int rc = build_plan(c, pl.get(), real, B, L, F);
   if (rc != LDC_OK) { (void)hipFree(base); return rc; }
+  for (const auto& z : pl->zero_once) {   // tile flags of the chains, the epoch word: cleared once, before the plan's first use
+    hipError_t ez = hipMemsetAsync(z.first, 0, z.second, s);
+    if (ez != hipSuccess) { (void)hipFree(base); return fail(LDC_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(ez)); }
+  }
   pl->arena_base = base;
   pl->arena_bytes = want;
   pl->slot = slot;
@@ -1801,10 +1973,14 @@ static int get_halves(ldc_ctx* c, int B, int L, int F, hipStream_t s, Halves* h)
   // other's floors.  Measured on one box (32 x 2.4 s): 2 x 16 items 503 audio-s/s, 3 chains 505, 4 x 8 items 510 -- but
   // the convs of a 4 x 8 decode run at 209 instead of 344 TFLOP/s per launch, so two chains stay the default (LDC_SPLIT).
   h->n = std::max(1, std::min(c->split_batch, B));
+  // XCD-team chains: the whole batch is ONE chain of launches (runs of convs as persistent launches with the items pinned to XCDs); the
+  // concurrency the two batch parts bought comes from the teams and the items inside a team drifting out of phase instead
+  const bool team = c->xcd_teams && c->dt == DT_BF16 && !c->w8 && c->fuse_gn_epi && !c->kstamps && !c->side_streams && B >= c->teams_min_b;
+  if (team) h->n = std::max(1, std::min(c->teams_parts, std::min(kMaxParts, B / 8)));   // (LDC_TEAMS_PARTS: experiment -- one persistent chain kernel per batch part, each with its share of the workgroups)
   for (int k = 0; k < h->n; ++k) {
     const int lo = (int)((long long)B * k / h->n), hi = (int)((long long)B * (k + 1) / h->n);
     h->b0[k] = lo;
-    LDCCHK(get_plan(c, hi - lo, L, F, k, s, &h->p[k]));
+    LDCCHK(get_plan(c, hi - lo, L, F, k, s, &h->p[k], team));
   }
   c->last_halves = *h;
   return LDC_OK;

@@ -103,6 +103,7 @@ struct ConvCall {
   unsigned long long* kst = nullptr;   // timed-mode stamps of this launch (ConvKArgs::kst), pipelined kernel only
   const int* kst_step = nullptr;
   int kst_stride = 0;
+  int m_decide = 0;                 // GEMM rows the tile-shape / split-K decisions are made for (0: B * L_rows); see ConvKArgs::m_decide
   const ConvTune* tune = nullptr;   // null: defaults
   long long* sk_need = nullptr;     // dry run: no launch, *sk_need = split-K workspace floats this call would use
   int* bm_out = nullptr;            // dry run (with sk_need): int[4] = rows per tile of the pipelined kernel (0 when the generic kernel would run), wave rows WM, split-K factor, columns per tile
@@ -114,6 +115,32 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
 // output at least), zeroed before every launch (the step's first kernel does it).
 hipError_t launch_conv_pair(const ConvLayer& ly0, const ConvCall& c0, const ConvLayer& ly1, const ConvCall& c1, unsigned* pair_done,
                             int pair_done_cap, hipStream_t s);
+// ---- XCD-team chains (round 5; conv_device.h: ChainHead / ChainConv, conv_fast.inc: conv_chain_kernel) ----
+// A run of consecutive convs of the denoise step as one persistent launch: batch items pinned to XCDs, tiles pulled from per-XCD ticket
+// heads, producer -> consumer hand-offs through flags in the XCD's L2.  bf16 engine only.
+struct ChainInfo {        // what the pipelined kernel would do with this conv (shape-only: no pointer is read)
+  bool ok = false;        // runs on the pipelined kernel in a shape the chain kernel contains
+  int variant = -1, bm = 0, bn = 0, ks = 1, ntn = 0;
+  size_t lds = 0;         // dynamic LDS of a tile
+};
+hipError_t conv_chain_info(const ConvLayer& ly, const ConvCall& cc, ChainInfo* out);
+struct ChainConvDesc {
+  const ConvLayer* ly = nullptr;
+  ConvCall cc;                      // sk_part / sk_count: this conv's OWN team-major workspace; m_decide as planned
+  int dep[3] = {-1, -1, -1};        // producers of x1 (and its row statistics), x2, residual inside the chain, or -1
+  unsigned* flags = nullptr;        // [8 teams][team_words] epoch-tagged tile flags (zeroed once at plan creation)
+  unsigned team_words = 0;
+  int sk_team_tiles = 0;
+};
+size_t conv_chain_table_bytes(int nconv);
+static constexpr int kConvChainMax = 16;
+// fills the device table (synchronous upload) for convs[0..n); flags_base: the address every ChainConvDesc::flags is an offset of
+// stamps (tuning aid, may be null): [8][stamp_team_stride][12] u64; first_out (may be null): int[8][kConvChainMax + 1] per-team first tickets
+hipError_t conv_chain_build(const ChainConvDesc* convs, int n, int B, unsigned* heads, unsigned* flags_base, const int* step_state, unsigned* fail_flag,
+                            void* table_dev, size_t* lds_out, unsigned long long* stamps = nullptr, int stamp_team_stride = 0, int* first_out = nullptr);
+hipError_t launch_conv_chain(const void* table_dev, size_t lds, int grid, hipStream_t s);
+int conv_chain_blocks_per_cu(size_t lds);
+
 size_t conv_packed_weight_bytes(const ConvLayer& ly);
 // host-side packers (fp32 [Cout][Cin][k] or, transposed, [Cin][Cout][k]) -> packed image in ly.dt
 void pack_conv_weights(const ConvLayer& ly, const float* w_oik, void* dst_host);
@@ -205,7 +232,7 @@ hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s); 
 // cur[0..stride) = table[st[0]][0..stride): the current timestep's scale/shift row, so that consumers need no
 // dependent load through the step counter
 // also zeroes [zero, zero + zero_bytes) (rounded up to 16 bytes: the caller pads the region): the step's accumulators
-hipError_t launch_step_begin(const float* table, int stride, const int* st, float* cur, unsigned long long* tl, hipStream_t s,
+hipError_t launch_step_begin(const float* table, int stride, int* st, float* cur, unsigned long long* tl, hipStream_t s,
                              void* zero = nullptr, size_t zero_bytes = 0);
 hipError_t launch_step_set(int* st, int t, int j, uint64_t noise_key, hipStream_t s);
 // output normalisation (sample.py:133-134); ws: double [B][2] + float [B] zeroed by the launcher

@@ -404,3 +404,35 @@ def test_fused_gn_epilogue_equals_the_separate_gn_apply(dtype):
         e.set_option("chain_convs", 0)
         e.set_option("fold_res", 1)
         e.set_option("fold_ln", 1)
+
+
+# ------------------------------------------------------------------------------------------- XCD-team chains (round 5, opt-in)
+def test_xcd_team_chains_equal_the_separate_launches():
+    """Round 5: runs of consecutive convs of the step as ONE persistent launch each, batch items pinned to XCDs, producer ->
+    consumer hand-offs through flags in the XCD's L2 (conv_fast.inc: conv_chain_kernel; unet.py:422-469 is what a step computes).
+    Off by default (measured slower, profiles/r05_team_chain_experiments.md) but kept correct: the same eps as the separate
+    launches at the bench grid -- every product is accumulated in the same order, only the partition of the GroupNorm statistics
+    into tiles differs -- over several passes (the tile flags carry the epoch of the pass and are never cleared), against the
+    reference fixture as well, and the bounded waits must not have given up (unet_forward raises on the device-side flag)."""
+    e, mc, u, cc, sd, _ = full_engine("c2", "bf16")
+    B, Lz, F = 32, 1200, 120
+    g = torch.Generator().manual_seed(47)
+    x = (torch.randn(B, 128, Lz, generator=g) * 0.7).cuda()
+    cond = torch.randn(B, 128, F, generator=g).cuda()
+    try:
+        ref = e.unet_forward(x, 211, cond).cpu().numpy()
+        e.set_option("xcd_teams", 1)
+        for rep in range(3):
+            got = e.unet_forward(x, 211, cond).cpu().numpy()
+            assert np.isfinite(got).all()
+            assert rel(got, ref) < TOL["bf16"]["eps_bench"], (rep, rel(got, ref))
+        # a ragged batch: teams with different item counts (20 items: 2 3 2 3 2 3 2 3), and one below the team threshold (13: the separate launches)
+        for Bs in (13, 20):
+            e.set_option("xcd_teams", 0)
+            r2 = e.unet_forward(x[:Bs], 37, cond[:Bs]).cpu().numpy()
+            e.set_option("xcd_teams", 1)
+            g2 = e.unet_forward(x[:Bs], 37, cond[:Bs]).cpu().numpy()
+            assert rel(g2, r2) < TOL["bf16"]["eps_bench"], (Bs, rel(g2, r2))
+    finally:
+        e.set_option("xcd_teams", 0)
+    e.close()
