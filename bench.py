@@ -312,8 +312,14 @@ def main():
     os.dup2(2, 1)
 
     rank, local_rank, world = parallel.init_process_group("nccl")
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # --gpus N means N RCCL ranks: anything else (a forgotten torch.distributed.run, a group that did not come up) fails loudly instead
+    # of printing a one-GPU number under an N-GPU label
+    n_ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    if world != args.gpus or n_ranks != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: WORLD_SIZE={world}, RCCL ranks={n_ranks} -- launch it as `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
+    if world > 1 and torch.distributed.get_backend() != "nccl":
+        raise SystemExit(f"bench.py: the process group runs on {torch.distributed.get_backend()}, not RCCL")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -376,15 +382,27 @@ def main():
 
     step_no = [0]
 
+    failures = []      # device-side failure flags (a bounded in-launch wait that gave up: [gn_wait] / [coop_lstm]) seen by the timed calls
+
+    def checked_decode(e_k):
+        try:
+            return e_k.decode(wav, N, noise=None, per_item=True)
+        except RuntimeError as ex:
+            if "device-side failure" not in str(ex):
+                raise
+            failures.append(str(ex)[:160])
+            log(f"DEVICE-SIDE FAILURE in a timed call: {ex}")
+            return torch.full((B, 1, T), float("nan"), device=dev)
+
     def step():
         k = step_no[0] % n_fl
         step_no[0] += 1
         if n_fl == 1:
-            out = eng.decode(wav, N, noise=None, per_item=True)
+            out = checked_decode(eng)
             parallel.gather_results(out, world)      # RCCL all_gather of the decoded waveforms (no-op without a process group)
             return out
         with torch.cuda.stream(slot_streams[k]):
-            out = engines[k].decode(wav, N, noise=None, per_item=True)
+            out = checked_decode(engines[k])
             parallel.gather_results(out, world)
         return out
 
@@ -404,7 +422,11 @@ def main():
     torch.cuda.synchronize(dev)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+    mine_s = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(mine_s, device=dev)
+    per_rank_ms = [1000.0 * float(v) / args.steps for v in parallel.gather_results(torch.tensor([mine_s], dtype=torch.float64, device=dev), world)]
+    if failures:
+        raise SystemExit(f"bench.py: {len(failures)} device-side failure(s) inside the timed region -- the number would be invalid: {failures[0]}")
     assert os.environ.get("LDC_CONV_DEBUG") or bool(torch.isfinite(out).all()), "non-finite output"   # (ablation runs compute garbage)
     log(f"timed region: {elapsed:.3f} s for {args.steps} step(s)")
     hs = [e_k.host_stats(reset=True) for e_k in engines]
@@ -419,12 +441,13 @@ def main():
                                f"{N}-step DDPM, batch={B}x{T / 16000.0:.1f} s utterances per GPU", "name": args.config,
                    "global_batch": world * B, "latent_len": T // mc.hop_length, "denoise_steps": N,
                    "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-                   "batches_in_flight": n_fl,
+                   "batches_in_flight": n_fl, "ms_per_step_by_rank": per_rank_ms,
                    "parallelism": f"dp{world} (utterance-sharded, no data-path collective)"},
         # host side of the timed region (rank 0): what one process spends inside hipGraphLaunch per bench step -- the ceiling of
         # one process once the kernels get faster -- and how long it waited for its own look-ahead window (GPU-bound when > 0)
         "host": {"graph_launch_ms_per_step": sum(h[0] for h in hs) / args.steps, "lookahead_wait_ms_per_step": sum(h[1] for h in hs) / args.steps,
-                 "graph_replays_per_step": sum(h[2] for h in hs) / args.steps},
+                 "graph_replays_per_step": sum(h[2] for h in hs) / args.steps,
+                 "device_side_failures": len(failures)},   # (raised flags of the bounded in-launch waits; a non-zero count aborts the run above)
     }
 
     if rank == 0 and not args.no_roofline:
@@ -452,9 +475,11 @@ def main():
         traffic, traffic_src = None, None
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from pmc_traffic import csrc_hash            # the figure is reported only while it was measured on THESE kernel sources
-        for name in ("r04_conv_traffic.json",):
+        for name in ("r05_conv_traffic.json", "r04_conv_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(tpath) and args.dtype == "bf16" and B == 32 and N == 50 and args.config == "c2":
+            if not os.path.exists(tpath):
+                continue
+            if args.dtype == "bf16" and B == 32 and N == 50 and args.config == "c2":
                 rec = json.load(open(tpath))
                 if rec.get("csrc_sha256_16") == csrc_hash():
                     traffic = rec["hbm_bytes_per_launch"]
@@ -470,6 +495,14 @@ def main():
                               "algorithmic_flops_per_launch": flops / max(1, launches),
                               "launches": launches, "avg_launch_us": 1000.0 * ms / max(1, launches),
                               "unet_step_gflop": step_flops / 1e9, "unet_step_conv_algorithmic_gb": step_bytes / 1e9}
+        # matrix-pipe occupancy of the dominant kernel from the committed SQ counter passes (profiles/r05_conv_counters.md): busy cycles of
+        # the MFMA pipes / (1024 SIMDs x launch duration), over the five top shape classes at the bench's per-part batch
+        cpath = os.path.join(ROOT, "profiles", "r05_conv_counters.json")
+        if os.path.exists(cpath) and args.dtype == "bf16":
+            crec = json.load(open(cpath))
+            result["roofline"]["mfma_busy_frac"] = crec["mfma_busy_frac"]
+            result["roofline"]["mfma_busy_frac_by_shape"] = {k: round(v["mfma_busy_frac_of_launch"], 4) for k, v in crec["shapes"].items()}
+            result["roofline"]["mfma_busy_source"] = "profiles/r05_conv_counters.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES over tools/conv_one.py, isolated launches)"
         # the other kernel classes of the UNet step against the roof that bounds them (same profiling pass)
         other = []
         for name, cms, cn, cfl, cby in classes:
