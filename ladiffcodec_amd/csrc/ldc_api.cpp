@@ -713,6 +713,9 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   g_train_valu = getenv("LDC_TRAIN_VALU") ? 1 : 0;
   if (getenv("LDC_TRAIN_BF16")) g_train_bf16 = 1;
   if (getenv("LDC_TRAIN_FP32_MFMA")) g_train_fp32_mfma = 1;   // (process-wide; ldc_set_option("train_fp32_mfma") changes it later)
+  c->lstm_xcd = env_int("LDC_LSTM_XCD", c->lstm_xcd);
+  c->xcd_resident[0] = lstm_xcd_resident(256) ? 1 : 0;
+  c->xcd_resident[1] = lstm_xcd_resident(512) ? 1 : 0;
   c->coop_resident[0] = lstm_coop_resident(256) ? 1 : 0;
   c->coop_resident[1] = lstm_coop_resident(512) ? 1 : 0;
   c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
@@ -816,6 +819,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     return LDC_OK;
   }
   if (n == "lstm_stream") { c->lstm_stream_only = value ? 1 : 0; return LDC_OK; }
+  if (n == "lstm_xcd") { c->lstm_xcd = value ? 1 : 0; return LDC_OK; }
   if (n == "fp8_act") {   // fp8-weight contexts: fp8 x fp8 MFMA where a tensor's only consumer is a conv (decided when the weights are packed)
     if (c->finalized) return fail(LDC_E_STATE, "fp8_act must be set before ldc_finalize_weights");
     c->fp8_act = value ? 1 : 0;
@@ -854,7 +858,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
@@ -1019,7 +1023,7 @@ int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in, int L
             HIPCHK(launch_conv(op.lstm[n].in_proj, cc, R.s));
             const bool lastl = n + 1 == op.lstm.size();
             hipError_t le = hipErrorCooperativeLaunchTooLarge;
-            if (coop) le = launch_lstm_coop(DT_F32, pre, op.lstm[n].w_rm, o, lastl ? x : nullptr, R.B, L, H, lws, R.c->dev_flag_dev, R.c->coop_launch, R.s);
+            if (coop) le = launch_lstm_coop(DT_F32, pre, op.lstm[n].w_rm, o, lastl ? x : nullptr, R.B, L, H, lws, R.c->dev_flag_dev, (R.c->lstm_xcd && R.c->xcd_resident[H == 512 ? 1 : 0]) ? 2 : R.c->coop_launch, R.s);
             if (le == hipErrorCooperativeLaunchTooLarge) {   // (or not eligible): one workgroup per item, W_hh streamed from L2
               (void)hipGetLastError();
               le = launch_lstm_layer(DT_F32, pre, op.lstm[n].w_hh, o, lastl ? x : nullptr, R.B, L, H, R.s);
@@ -2314,23 +2318,32 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
       HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       evs.push_back(e);
     }
-    for (int j = 0; j < n_rep; ++j)
-      for (int k = 0; k < h.n; ++k) {
+    // (a failure between fork and join must still join: the auxiliary streams would otherwise be left with work that is unordered
+    // against the caller's stream -- ADVICE r4.  Note for asynchronous callers: the look-ahead wait below blocks the HOST for up to
+    // `depth` replays of a part, on events of this context.)
+    hipError_t err = hipSuccess;
+    const char* what = "";
+    for (int j = 0; j < n_rep && err == hipSuccess; ++j)
+      for (int k = 0; k < h.n && err == hipSuccess; ++k) {
         hipStream_t sk = k == 0 ? s : c->aux_stream[k];
         hipEvent_t ev = evs[(size_t)k * depth + j % depth];
         if (j >= depth) {
           const auto t0 = std::chrono::steady_clock::now();
-          HIPCHK(hipEventSynchronize(ev));   // replay j - depth of this part has finished
+          err = hipEventSynchronize(ev);   // replay j - depth of this part has finished
           c->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+          if (err != hipSuccess) { what = "hipEventSynchronize"; break; }
         }
         const auto t0 = std::chrono::steady_clock::now();
-        HIPCHK(hipGraphLaunch(sg->pexec[k][(j < n_big || K == 1) ? 0 : 1], sk));
+        err = hipGraphLaunch(sg->pexec[k][(j < n_big || K == 1) ? 0 : 1], sk);
         c->host_graph_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ++c->host_graph_launches;
-        HIPCHK(hipEventRecord(ev, sk));
+        if (err != hipSuccess) { what = "hipGraphLaunch"; break; }
+        err = hipEventRecord(ev, sk);
+        if (err != hipSuccess) what = "hipEventRecord";
       }
-    LDCCHK(join_parts(c, h, s));
-    return LDC_OK;
+    const int jr = join_parts(c, h, s);
+    if (err != hipSuccess) return fail(LDC_E_HIP, "%s failed in the per-part graph replay: %s", what, hipGetErrorString(err));
+    return jr;
   }
   for (; i + K <= n_steps; i += K) LDCCHK(replay(sg->exec[0]));
   for (; i < n_steps; ++i) LDCCHK(replay(sg->exec[K == 1 ? 0 : 1]));

@@ -292,6 +292,11 @@ struct ldc_ctx {
   int fuse_kmax = 1;
   int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
   int coop_launch = 0;          // LDC_COOP_LAUNCH: hipLaunchCooperativeKernel for the cooperative LSTM (see seanet.hip)
+  int lstm_xcd = 0;             // LDC_LSTM_XCD / option "lstm_xcd": few-item (B <= 4) cooperative LSTM with the hidden-state exchange inside ONE XCD and the
+                                // products on the VALU (seanet.hip: lstm_xcd_kernel).  OFF: parity-clean but measured slower than lstm_coop_kernel spread over the
+                                // chip (configs[0]: 4.13 vs 3.33 ms per clip, profiles/r05_team_chain_experiments.md); a device-side failure of it switches
+                                // the context back to the placement-independent kernel
+  int xcd_resident[2] = {0, 0};
   int coop_resident[2] = {0, 0};   // [H == 512]: the cooperative LSTM's H/4 workgroups fit the device together (asked at ldc_create)
   int fuse_attn_tail = 1;       // LinearAttention out + to_out conv + LayerNorm + residual in one launch (bf16 engine)
   // Flow control of the step-graph replays: with more than ~10-20 multi-thousand-node graph launches outstanding the ROCm 7.2
@@ -369,6 +374,7 @@ inline int check_dev_flag(ldc_ctx* c) {
       return fail(LDC_E_HIP, "device-side failure [gn_wait]: the in-launch GroupNorm exchange of a fused conv timed out (its tiles were "
                              "not all resident in time: is the GPU shared with another process?); the outputs of that call are NaN; "
                              "ldc_set_option(ctx, \"fuse_gn_epi\", 0) restores the separate conv + gn_apply launches");
+    c->lstm_xcd = 0;   // (if it was the XCD-local form that gave up, the retry takes the placement-independent kernel)
     return fail(LDC_E_HIP, "device-side failure [coop_lstm]: cooperative LSTM: the hidden-state exchange timed out (its workgroups were "
                            "not co-resident: is the GPU shared with another process?); the outputs of that call are NaN; "
                            "ldc_set_option(ctx, \"lstm_stream\", 1) selects the streamed LSTM kernel");

@@ -349,6 +349,142 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const f
   if (dead && tid == 0 && host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Few items (B <= 4: configs[0]'s single clip, a file decoded alone by the CLI): the same weight-stationary recurrence with the
+// hidden-state exchange kept inside ONE XCD and the matrix-vector products on the VALU (round 5).
+//   * profiles/r05_xcd_team_probe.md: a plain store stays in the writing XCD's L2 and an L1-bypassing (sc1) load from another CU of
+//     the SAME XCD reads it there -- flag latency 0.4 us, against 0.8-1.0 us + cross-XCD-rate reads for the write-through /
+//     memory-side-atomic protocol of lstm_coop_kernel, of which a step has three dependent legs (h stores, arrival atomics, h loads).
+//   * The launch has 8 x H/4 workgroups; every workgroup reads HW_REG_XCC_ID, the ones on XCC 0 take a rank (one atomic per launch)
+//     and the first H/4 of them do the work, four to a CU; everybody else leaves at once.  Team membership comes from the hardware
+//     id, so the L2 the data sits in IS the L2 the readers ask; a team that does not fill ends in the bounded spin (NaN output +
+//     host flag) and the context goes back to lstm_coop_kernel.
+//   * With one to four items a 16-item MFMA tile is 15/16 padding, and 128 workgroups on 32 CUs would serialise four waves' MFMA
+//     chains per SIMD (measured: the MFMA form of this kernel ran 4.5 us per step against 3.5 us for lstm_coop_kernel spread over the
+//     chip).  Here thread (gate row r, K segment g) keeps its H/16 weights in registers and a step is H/16 FMAs per item + a
+//     16-lane shuffle reduction.
+// Per step: plain stores of the h slice -> vmcnt(0) -> the workgroup's flag word (plain store of the step number) | one wave polls
+// the H/4 flag words (sc1) -> sc1 loads of h.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int H>
+__global__ __launch_bounds__(256, 4) void lstm_xcd_kernel(const void* pre, const float* w_hh, void* out, const void* skip,
+                                                          int B, int T_len, float* hbuf, unsigned* sync, unsigned* host_flag) {
+  constexpr int KS = H / 16;     // k range of one thread
+  constexpr int NV = KS / 4;     // float4 pieces of it
+  constexpr int NB = H / 4;      // workgroups of the team
+  __shared__ float sgate[4][16];
+  __shared__ int s_dead, s_rank;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 7u;   // HW_REG_XCC_ID
+  if (xcc != 0u) return;
+  if (tid == 0) {
+    s_rank = (int)__hip_atomic_fetch_add(sync + 202, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_dead = 0;
+  }
+  __syncthreads();
+  const int j = s_rank;
+  if (j >= NB) return;
+  unsigned* flags = sync;        // [NB] words: the step a workgroup has published (zeroed before the launch)
+  const int r = tid >> 4, g = tid & 15;          // gate row of this workgroup (gate = r >> 2, unit = r & 3), K segment
+  f32x4 wreg[NV];
+  {
+    const size_t row = (size_t)(r >> 2) * H + 4 * j + (r & 3);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) wreg[v] = *reinterpret_cast<const f32x4*>(w_hh + row * H + g * KS + 4 * v);
+  }
+  const int ob = tid >> 2, ou = tid & 3;
+  const bool owner = tid < 4 * B;
+  float c_state = 0.f;
+  float pnext[4] = {0.f, 0.f, 0.f, 0.f};
+  if (owner) {
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) pnext[gg] = sld<T>(pre, ((size_t)ob * T_len) * (4 * H) + gg * H + 4 * j + ou);
+  }
+  bool dead = false;
+  int t = 0;
+  for (; t < T_len; ++t) {
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t > 0) {
+      if (w == 0) {
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned spins = 0;; ++spins) {
+          bool ok = true;
+#pragma unroll
+          for (int k = 0; k < (NB + 63) / 64; ++k) {
+            const int i = k * 64 + lane;
+            if (i < NB) ok = ok && __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)t;
+          }
+          if (__all(ok)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((spins & 255u) == 255u) {
+            const unsigned flag = lane == 0 ? __hip_atomic_load(sync + 200, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (__any(flag != 0u) || wall_clock64() - t0 > 20000000ull) {   // 0.2 s
+              if (lane == 0) { __hip_atomic_store(sync + 200, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dead = 1; }
+              break;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (s_dead) { dead = true; break; }
+      const float* hp = hbuf + (size_t)((t + 1) & 1) * 32 * H + g * KS;
+      // one item at a time through one operand buffer (four buffers would spill: 128 + 32 registers against the 128 that four
+      // workgroups per CU allow)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (b < B) {
+          f32x4 hreg[NV];
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hreg[v]) : "v"(hp + (size_t)b * H + 4 * v) : "memory");   // past the L1, from this XCD's L2
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            asm volatile("" : "+v"(hreg[v]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot[b] = fmaf(hreg[v][e], wreg[v][e], dot[b]);
+          }
+        }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dot[b] += __shfl_xor(dot[b], o);
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) sgate[b][r] = dot[b];
+    }
+    __syncthreads();
+    if (owner) {
+      float gates[4];
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) gates[gg] = pnext[gg] + sgate[ob][gg * 4 + ou];
+      const float ig = sigmoid_acc(gates[0]), fg = sigmoid_acc(gates[1]);
+      const float gv = tanhf(gates[2]), og = sigmoid_acc(gates[3]);
+      c_state = fg * c_state + ig * gv;
+      const float h = og * tanhf(c_state);
+      // plain store: the line stays in this XCD's L2, where the team's sc1 loads find it
+      asm volatile("global_store_dword %0, %1, off" ::"v"(hbuf + (size_t)(t & 1) * 32 * H + (size_t)ob * H + 4 * j + ou), "v"(h) : "memory");
+      const size_t o = ((size_t)ob * T_len + t) * H + 4 * j + ou;
+      const float sk = skip ? sld<T>(skip, o) : 0.f;
+      if (t + 1 < T_len) {
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) pnext[gg] = sld<T>(pre, ((size_t)ob * T_len + t + 1) * (4 * H) + gg * H + 4 * j + ou);
+      }
+      sst<T>(out, o, h + sk);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && t + 1 < T_len) {
+      asm volatile("global_store_dword %0, %1, off" ::"v"(flags + j), "v"((unsigned)(t + 1)) : "memory");
+    }
+  }
+  if (dead && owner) {
+    for (int tt = t; tt < T_len; ++tt) sst<T>(out, ((size_t)ob * T_len + tt) * H + 4 * j + ou, __builtin_nanf(""));
+  }
+  if (dead && tid == 0 && host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <typename T>
 static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out, const void* skip, int B, int T_len, int H,
                                    void* ws, unsigned* host_flag, int coop_launch, hipStream_t s) {
@@ -371,7 +507,10 @@ static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out
     const void* pp = p; void* oo = o; const void* kk = k; int nbv = nb, tl = T_len;
     void* args[] = {&pp, &w_rm, &oo, &kk, &nbv, &tl, &hbuf, &sync, &host_flag};
     const void* fn = H == 512 ? reinterpret_cast<const void*>(lstm_coop_kernel<T, 512>) : reinterpret_cast<const void*>(lstm_coop_kernel<T, 256>);
-    if (coop_launch) e = hipLaunchCooperativeKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
+    if (coop_launch == 2 && nb <= 4) {   // few items: XCD-local exchange, 8 x H/4 workgroups, the ones on XCC 0 form the team
+      const void* fx = H == 512 ? reinterpret_cast<const void*>(lstm_xcd_kernel<T, 512>) : reinterpret_cast<const void*>(lstm_xcd_kernel<T, 256>);
+      e = hipLaunchKernel(fx, dim3(8 * (H / 4)), dim3(256), args, 0, s);
+    } else if (coop_launch == 1) e = hipLaunchCooperativeKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
     else e = hipLaunchKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
     if (e != hipSuccess) return e;
   }
@@ -379,6 +518,20 @@ static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out
 }
 
 bool lstm_coop_eligible(int H) { return H == 256 || H == 512; }
+// the XCD-local form needs the team's H/4 workgroups on the 32 CUs of one XCD
+bool lstm_xcd_resident(int H) {
+  if (!lstm_coop_eligible(H)) return false;
+  const void* fn = H == 512 ? reinterpret_cast<const void*>(lstm_xcd_kernel<float, 512>) : reinterpret_cast<const void*>(lstm_xcd_kernel<float, 256>);
+  int per_cu = 0, cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  // (no margin to give: 128 workgroups on 32 CUs is exactly the four per CU that 110 registers allow; the kernel uses 80 SGPRs, inside the
+  // range where the occupancy query is exact -- MI355X_MICROARCH.md -- and a team that does not fill ends in the bounded spin)
+  return cus % 8 == 0 && (long long)per_cu * (cus / 8) >= H / 4;
+}
 
 // Can the H/4 workgroups of the cooperative kernel be resident together on the current device?  Asked once per context
 // (ldc_create); the occupancy API can over-report by one block per CU for SGPR-heavy kernels (MI355X_MICROARCH.md), hence the margin.

@@ -35,6 +35,8 @@
 
 #include "ldc_kernels.h"
 
+extern long long g_device_syncs;   // ldc_api.cpp: every device-wide synchronisation of the library is counted (ldc_debug_sync_count)
+
 namespace ldc {
 namespace mm3 {
 
@@ -535,8 +537,10 @@ size_t g_pw_bytes = 0;
 u32x4* pack_workspace(size_t bytes, hipStream_t s) {
   if (!ws_device_ok()) return nullptr;
   if (bytes > g_pw_bytes) {
-    (void)hipStreamSynchronize(s);
-    (void)hipDeviceSynchronize();
+    // (counted like every device-wide sync of the library: ldc_debug_sync_count; a failed sync means work may still read the buffer)
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    ++g_device_syncs;
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
     if (g_pw) (void)hipFree(g_pw);
     g_pw = nullptr;
     g_pw_bytes = 0;
@@ -551,8 +555,9 @@ size_t g_dw_ws_bytes = 0;
 float* dw_workspace(size_t bytes, hipStream_t s) {
   if (!ws_device_ok()) return nullptr;
   if (bytes > g_dw_ws_bytes) {
-    (void)hipStreamSynchronize(s);
-    (void)hipDeviceSynchronize();
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    ++g_device_syncs;
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
     if (g_dw_ws) (void)hipFree(g_dw_ws);
     g_dw_ws = nullptr;
     g_dw_ws_bytes = 0;
