@@ -370,6 +370,10 @@ int ldc_conv_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin
  * difference of the fused GroupNorm statistics / column maxima. */
 int ldc_conv_compare(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups, int tile_cfg,
                      int with_gn, int with_colmax, int with_residual, double* max_abs_diff, double* max_abs_ref, double* max_rel_stat);
+/* Self-check of the LayerNorm folded into a 1x1 conv (the attention blocks' PreNorm in front of to_qkv) on rows x = dc + U(-1, 1):
+ * against launch_ln_rows + a plain conv; max_abs_diff2[0]: the folded conv computing the row statistics itself, [1]: from per-row
+ * (sum, centred M2) partials per 32-column block as the fused ResnetBlock conv in front leaves them. */
+int ldc_ln_fold_compare(ldc_ctx* ctx, int dtype, int rows, int C, int n_out, double dc, double* max_abs_diff2, double* max_abs_ref);
 /* Self-check of the fp8 x fp8 conv-GEMM (block-scaled fp8 MFMA): operands drawn on the e4m3 grid through that kernel and through
  * the bf16-activation x fp8-weight kernel, which then computes the same products exactly. */
 int ldc_conv_compare_fp8(ldc_ctx* ctx, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups, int with_gn, int with_colmax,

@@ -95,9 +95,9 @@ struct ConvKArgs {
   int kst_stride;
   int gn_nap, gn_nap0;     // fused GroupNorm exchange: s_sleep(1) repetitions between polls / before the first poll (ConvTune)
   const float* ln_s;       // folded PreNorm LayerNorm (ConvLayer::ln_s) or null
-  const float* ln_rowstat; // ... its row statistics as partials [rows][C / 32][2] (sum, sum of squares per 32-column block) written by the
+  const float* ln_rowstat; // ... its row statistics as partials [rows][C / 32][2] (sum, centred M2 per 32-column block) written by the
                            // producer of the input (rowstat_out of the fused block2 conv), or null: the conv reads its rows once more
-  float* rowstat_out;      // fused GroupNorm apply with residual: also write those partials of the stored rows [rows][n / 32][2]
+  float* rowstat_out;      // fused GroupNorm apply with residual: also write those partials of the stored rows [rows][n / 32][2]: (sum, M2 about the block mean)
   char* y2;                // folded 1x1 conv (ConvLayer::wtaps): second output [rows][n], or null
   const float* bias2;
   int wtaps;               // weight slabs per channel chunk in the packed image (taps, or taps + 1 with the folded conv)
@@ -715,13 +715,23 @@ __device__ __forceinline__ void epilogue_gn_fused(const KA& a, f32x16 (&acc)[TM]
       }
 #pragma unroll
       for (int e = 0; e < EPL; ++e) f[e] += rr[e];
-      if (a.rowstat_out) {   // per-row partial (sum, sum of squares) of this lane group's 32-column block: the PreNorm of the attention block behind
+      if (a.rowstat_out) {   // per-row partial of this lane group's 32-column block for the PreNorm of the attention block behind:
+        // (sum, M2 about the block's own mean) of the values AS STORED (bf16-rounded: what the consumer's matmul reads), merged
+        // Chan-style in the consumer's prologue -- a single-pass sum of squares cancels where |mean| >> std
         constexpr int G = 32 / EPL;   // lanes that share a row's 32-column block (consecutive lanes)
+        float fr[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) fr[e] = (sizeof(T) == 2 && !(a.gn_out & 4)) ? bf16_to_f32(f32_to_bf16(f[e])) : f[e];
         float ps = 0.f, pq = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) { ps += f[e]; pq = fmaf(f[e], f[e], pq); }
+        for (int e = 0; e < EPL; ++e) ps += fr[e];
 #pragma unroll
-        for (int o = 1; o < G; o <<= 1) { ps += __shfl_xor(ps, o); pq += __shfl_xor(pq, o); }
+        for (int o = 1; o < G; o <<= 1) ps += __shfl_xor(ps, o);
+        const float bm = ps * (1.0f / 32.0f);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) pq = fmaf(fr[e] - bm, fr[e] - bm, pq);
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) pq += __shfl_xor(pq, o);
         if ((chunk & (G - 1)) == 0 && m < M && col < a.n)
           *reinterpret_cast<float2*>(a.rowstat_out + ((size_t)m * (a.n >> 5) + (col >> 5)) * 2) = make_float2(ps, pq);
       }

@@ -720,3 +720,108 @@ extern "C" int ldc_chain_stamps(ldc_ctx* c, int chain, unsigned long long* out, 
   if (info && info_cap > 0) snprintf(info, (size_t)info_cap, "%s", d.info.c_str());
   return LDC_OK;
 }
+
+// Self-check of the folded PreNorm LayerNorm (ConvLayer::ln_s, unet.py:82-101 in front of to_qkv) on rows with a DC offset:
+// y_ref = conv1x1(LayerNorm(x) * g) through launch_ln_rows + a plain conv, against the LayerNorm-folded conv reading x itself
+// (out[0]) and reading per-row (sum, centred M2) partials per 32-column block as the fused block2 conv leaves them (out[1]).
+// x = dc + U(-1, 1).  ADVICE r4: the round-4 single-pass variance cancelled where |mean| >> std.
+extern "C" int ldc_ln_fold_compare(ldc_ctx* c, int dtype, int rows, int C, int n_out, double dc, double* max_abs_diff2, double* max_abs_ref) {
+  if (!c || !max_abs_diff2 || !max_abs_ref || rows < 1 || C < 32 || C % 32 || n_out < 1) return fail(LDC_E_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  const int dt = dtype == LDC_F32 ? DT_F32 : DT_BF16;
+  const size_t es = dt_size(dt);
+  auto round_dt = [&](float v) {
+    if (dt == DT_F32) return v;
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    float r;
+    memcpy(&r, &u, 4);
+    return r;
+  };
+  unsigned seed = 777u;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) * (1.0f / 8388608.0f)) - 1.0f; };
+  std::vector<float> w((size_t)n_out * C), g(C), w2((size_t)n_out * C), sn(n_out), xh((size_t)rows * C), part((size_t)rows * (C / 32) * 2);
+  for (auto& v : w) v = rnd() * 0.1f;
+  for (auto& v : g) v = 1.0f + 0.25f * rnd();
+  for (auto& v : xh) v = round_dt((float)dc + rnd());
+  for (int n = 0; n < n_out; ++n) {
+    double acc = 0;
+    for (int k = 0; k < C; ++k) { w2[(size_t)n * C + k] = w[(size_t)n * C + k] * g[k]; acc += (double)round_dt(w2[(size_t)n * C + k]); }
+    sn[n] = (float)acc;
+  }
+  for (int r = 0; r < rows; ++r)
+    for (int b = 0; b < C / 32; ++b) {
+      float s = 0.f, m2 = 0.f;
+      for (int k = 0; k < 32; ++k) s += xh[(size_t)r * C + b * 32 + k];
+      for (int k = 0; k < 32; ++k) { const float d = xh[(size_t)r * C + b * 32 + k] - s / 32.0f; m2 += d * d; }
+      part[((size_t)r * (C / 32) + b) * 2] = s; part[((size_t)r * (C / 32) + b) * 2 + 1] = m2;
+    }
+  DevMem keep;
+  const bool saved_w8 = c->w8;
+  c->w8 = false;
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  ConvLayer plain, folded;
+  ConvSpec sp;
+  sp.dt = dt; sp.cin1 = C; sp.cout = n_out; sp.k = 1;
+  int rc = make_conv(c, sp, w.data(), nullptr, &plain);
+  if (rc == LDC_OK) rc = make_conv(c, sp, w2.data(), nullptr, &folded);
+  float *d_g = nullptr, *d_sn = nullptr, *d_part = nullptr;
+  if (rc == LDC_OK) rc = c->wmem.upload(&d_g, g);
+  if (rc == LDC_OK) rc = c->wmem.upload(&d_sn, sn);
+  if (rc == LDC_OK) rc = c->wmem.upload(&d_part, part);
+  std::swap(keep.ptrs, c->wmem.ptrs);
+  c->w8 = saved_w8;
+  LDCCHK(rc);
+  folded.ln_s = d_sn;
+  void *x = nullptr, *xn = nullptr, *y[3] = {nullptr, nullptr, nullptr};
+  LDCCHK(keep.alloc(&x, (size_t)rows * C * es));
+  LDCCHK(keep.alloc(&xn, (size_t)rows * C * es));
+  {
+    std::vector<char> hb((size_t)rows * C * es);
+    for (size_t i = 0; i < xh.size(); ++i) {
+      if (dt == DT_F32) reinterpret_cast<float*>(hb.data())[i] = xh[i];
+      else { uint32_t u; memcpy(&u, &xh[i], 4); reinterpret_cast<uint16_t*>(hb.data())[i] = (uint16_t)(u >> 16); }
+    }
+    HIPCHK(hipMemcpy(x, hb.data(), hb.size(), hipMemcpyHostToDevice));
+  }
+  hipStream_t s = c->own_stream;
+  for (int v = 0; v < 3; ++v) {
+    LDCCHK(keep.alloc(&y[v], (size_t)rows * n_out * es));
+    HIPCHK(hipMemset(y[v], 0, (size_t)rows * n_out * es));
+    ConvCall cc;
+    cc.B = 1; cc.L_in = rows; cc.L_rows = rows; cc.y = y[v]; cc.y_ld = n_out; cc.tune = &c->tune;
+    if (v == 0) {
+      HIPCHK(launch_ln_rows(dt, x, xn, nullptr, d_g, rows, C, s));
+      cc.x1 = xn;
+      HIPCHK(launch_conv(plain, cc, s));
+    } else {
+      cc.x1 = x;
+      cc.ln_rowstat = v == 2 ? d_part : nullptr;
+      HIPCHK(launch_conv(folded, cc, s));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<char> h[3];
+  for (int v = 0; v < 3; ++v) { h[v].resize((size_t)rows * n_out * es); HIPCHK(hipMemcpy(h[v].data(), y[v], h[v].size(), hipMemcpyDeviceToHost)); }
+  auto val = [&](const std::vector<char>& hv, size_t i) {
+    if (dt == DT_F32) return (double)reinterpret_cast<const float*>(hv.data())[i];
+    const uint32_t u = (uint32_t)reinterpret_cast<const uint16_t*>(hv.data())[i] << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return (double)f;
+  };
+  double m = 0;
+  max_abs_diff2[0] = max_abs_diff2[1] = 0;
+  for (size_t i = 0; i < (size_t)rows * n_out; ++i) {
+    const double a = val(h[0], i);
+    m = std::max(m, fabs(a));
+    for (int v = 1; v < 3; ++v) {
+      const double b = val(h[v], i);
+      max_abs_diff2[v - 1] = (b == b) ? std::max(max_abs_diff2[v - 1], fabs(a - b)) : 1e30;
+    }
+  }
+  *max_abs_ref = m;
+  return LDC_OK;
+}

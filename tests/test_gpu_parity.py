@@ -549,3 +549,21 @@ def test_warm_decode_never_waits_for_the_device():
         e.denoise(cu(g["img0"]), cond, 6)
     torch.cuda.synchronize()
     assert lib.ldc_debug_sync_count() == before, (before, lib.ldc_debug_sync_count())
+
+
+def test_folded_layernorm_on_rows_with_a_large_mean():
+    """the PreNorm LayerNorm folded into to_qkv (unet.py:82-101: biased variance ABOUT THE MEAN) took its variance as
+    E[x^2] - mean^2 from single-pass fp32 sums, which cancels where |mean| >> std.  The statistics are centred now (two passes
+    over rows read by the conv itself, Chan-merged (sum, M2) partials per 32-column block from the producing conv): rows with
+    mean / std ~ 170 through the folded conv, against launch_ln_rows + a plain conv.  The fold's own rearrangement
+    rstd * (W x - mean * s_n) loses log10(mean / std) digits of an fp32 accumulator, hence 2e-3 rather than 2e-5 at dc = 100
+    (the single-pass variance was off by 10 % there)."""
+    import ctypes as C
+    e = engine("r84", "f32")
+    lib = L.load()
+    for dtype, dc, tol in ((L.LDC_F32, 0.0, 2e-5), (L.LDC_F32, 100.0, 2e-3), (L.LDC_BF16, 2.0, 3e-2)):
+        for C_, n_out in ((256, 384), (1024, 384)):
+            d = (C.c_double * 2)()
+            m = C.c_double()
+            L.check(lib.ldc_ln_fold_compare(e._ctx, dtype, 300, C_, n_out, dc, d, C.byref(m)))
+            assert m.value > 0.1 and d[0] < tol * m.value and d[1] < tol * m.value, (dtype, dc, C_, d[0], d[1], m.value)
