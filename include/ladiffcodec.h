@@ -303,6 +303,10 @@ int ldc_train_maxscale(ldc_ctx* ctx, const float* x, const float* dy, int B, int
  * beta1 0.9, beta2 0.999, eps 1e-8, no weight decay, no amsgrad).  `step` counts from 1 (bias correction). */
 int ldc_train_adam_step(ldc_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
                         float beta1, float beta2, float eps, void* stream);
+/* The same with the step count in device memory (*step_dev is counted up first, then used): the form a captured (hipGraph) optimisation
+ * step needs -- a host-side count would be frozen into the graph. */
+int ldc_train_adam_step_dev(ldc_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t* step_dev,
+                            float lr, float beta1, float beta2, float eps, void* stream);
 
 /* L1 primitives (reference srcs/modules/conv.py, lstm.py), exposed for the parity tests ---------- */
 /* SConv1d.forward (conv.py:217-232), reflect padding.  w [Cout,Cin,k] (already weight-norm folded),

@@ -330,6 +330,16 @@ extern "C" int ldc_train_adam_step(ldc_ctx* c, float* param, const float* grad, 
   return finish_stream(c, stream);
 }
 
+extern "C" int ldc_train_adam_step_dev(ldc_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t* step_dev,
+                                       float lr, float beta1, float beta2, float eps, void* stream) {
+  LDCCHK(check_dev(c));
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || n < 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
+    return fail(LDC_E_INVALID, "bad arguments");
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_adam_dev(param, grad, exp_avg, exp_avg_sq, n, step_dev, lr, beta1, beta2, eps, s));
+  return finish_stream(c, stream);
+}
+
 extern "C" int ldc_train_layernorm_forward(ldc_ctx* c, const float* x, const float* g, int B, int C, int L, float* y, float* stats, void* stream) {
   LDCCHK(check_dev(c));
   if (!x || !g || !y || !stats || B < 1 || C < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");

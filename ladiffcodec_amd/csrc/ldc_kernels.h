@@ -322,6 +322,7 @@ hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Co
                          float* db = nullptr);
 extern int g_train_valu;   // LDC_TRAIN_VALU: the training path's GEMM shapes on the VALU reference kernels instead of the fp32 MFMA ones
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, hipStream_t s);
+hipError_t launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, int* step_dev, float lr, float b1, float b2, float eps, hipStream_t s);
 hipError_t launch_train_ln_forward(const float* x, const float* g, int B, int C, int L, float* y, float* stats, hipStream_t s);
 hipError_t launch_train_ln_backward(const float* dy, const float* x, const float* g, const float* stats, int B, int C, int L, float* dx,
                                     float* dg, hipStream_t s);

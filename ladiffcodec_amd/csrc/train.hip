@@ -699,6 +699,32 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     p[i] -= step_size * (mi / denom);
   }
 }
+// The same with the step count on the device (a captured optimisation step: the count advances with every replay).  `step_dev` is
+// counted up by a one-thread kernel in front; the bias corrections are evaluated per thread in fp32 (exp2 / log2: ~1e-7 relative, against
+// the host's double in launch_adam).
+__global__ void adam_tick_kernel(int* step_dev) { step_dev[0] += 1; }
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                                                       float eps, const int* step_dev) {
+  const float st = (float)step_dev[0];
+  const float bc1 = 1.0f - exp2f(st * log2f(b1)), bc2 = 1.0f - exp2f(st * log2f(b2));
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+hipError_t launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, int* step_dev, float lr, float b1, float b2, float eps, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step_dev);
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, step_dev);
+  return hipGetLastError();
+}
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);

@@ -148,12 +148,26 @@ class Adam:
         self.eng, self.param, self.lr, self.betas, self.eps = eng, param, float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.exp_avg, self.exp_avg_sq = t.zeros_like(param), t.zeros_like(param)
         self.steps = 0
+        self.step_dev = None      # device-side step count (int32[1]) once the optimisation step is replayed from a hipGraph
+
+    def use_device_count(self):
+        """From here on the step count lives on the device (a captured step: a host-side count would be frozen into the graph)."""
+        t = self.eng.torch
+        if self.step_dev is None:
+            self.step_dev = t.tensor([self.steps], dtype=t.int32, device=self.param.device)
 
     def step(self, grad):
         t = self.eng.torch
         grad = grad.to(self.param.device, t.float32).contiguous()
         assert grad.numel() == self.param.numel()
         self.steps += 1
+        if self.step_dev is not None:
+            s = self.eng._enter()
+            L.check(self.eng.lib.ldc_train_adam_step_dev(self.eng._ctx, self.param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                         self.exp_avg_sq.data_ptr(), self.param.numel(), self.step_dev.data_ptr(), self.lr,
+                                                         self.betas[0], self.betas[1], self.eps, s))
+            self.eng._exit()
+            return self.param
         s = self.eng._enter()
         L.check(self.eng.lib.ldc_train_adam_step(self.eng._ctx, self.param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
                                                  self.exp_avg_sq.data_ptr(), self.param.numel(), self.steps, self.lr, self.betas[0],
@@ -696,6 +710,9 @@ class DiffusionTrainer:
         self._grad_views = {p.data_ptr(): g for p, g in zip(self.state_dict().values(), self._views(self.flat_g).values())}
         self.num_timesteps = int(eng.lib.ldc_train_num_timesteps(eng._ctx))
         self.opt = Adam(eng, self.flat, lr=lr)
+        import os
+        self.use_graph = bool(int(os.environ.get("LDC_TRAIN_GRAPH", "0")))     # the step as one replayed hipGraph (see _step_graphed)
+        self._graph, self._graph_key, self._graph_seen, self._graph_in, self._graph_out = None, None, 0, None, None
 
     def _views(self, flat):
         out, off = {}, 0
@@ -734,7 +751,48 @@ class DiffusionTrainer:
         return out
 
     def step(self, x_start, cond, t, noise, monitor: bool = False, wav=None, latent_scale: float = 18.0, update: bool = True):
+        if self.use_graph and update and not monitor:
+            return self._on_engine_stream(lambda: self._step_graphed(x_start, cond, t, noise))
         return self._on_engine_stream(lambda: self._step(x_start, cond, t, noise, monitor, wav, latent_scale, update))
+
+    def _step_graphed(self, x_start, cond, t, noise):
+        """The optimisation step replayed from ONE hipGraph (round 5; `use_graph` / LDC_TRAIN_GRAPH=1).  The step's shapes are static and
+        its ~1 600 launches are issued layer by layer from Python; captured once on the engine's stream (a single-stream graph, which
+        ROCm 7.2 replays from recorded AQL packets) they cost the host one call.  The first step of a shape runs eagerly (lazy
+        workspaces, function attributes), the second is captured over static input buffers and replayed, every later one copies its
+        inputs into those buffers and replays.  The loss tensor returned is the graph's static output (valid until the next step).
+        A training step with gradient reduction over ranks stays eager (the collectives are not captured)."""
+        tt = self.torch
+        eng = self.eng
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return self._step(x_start, cond, t, noise)
+        x_start = x_start.to(eng.device, tt.float32).contiguous()
+        cond = cond.to(eng.device, tt.float32).contiguous()
+        t = t.to(eng.device, tt.int64).contiguous()
+        noise = noise.to(eng.device, tt.float32).contiguous()
+        key = (tuple(x_start.shape), tuple(cond.shape))
+        if self._graph_key != key:
+            self._graph, self._graph_key, self._graph_seen = None, key, 0
+        if self._graph is None:
+            self._graph_seen += 1
+            if self._graph_seen < 2:
+                return self._step(x_start, cond, t, noise)
+            self._graph_in = tuple(tt.empty_like(v) for v in (x_start, cond, t, noise))
+            for dst, src in zip(self._graph_in, (x_start, cond, t, noise)):
+                dst.copy_(src)
+            self.opt.use_device_count()
+            g = tt.cuda.CUDAGraph()
+            with tt.cuda.graph(g, stream=eng.stream):
+                self._graph_out = self._step(*self._graph_in)
+            self.opt.steps -= 1           # (the capture itself executed nothing)
+            self._graph = g
+        else:
+            for dst, src in zip(self._graph_in, (x_start, cond, t, noise)):
+                dst.copy_(src)
+        self._graph.replay()
+        self.opt.steps += 1
+        return self._graph_out
 
     def _step(self, x_start, cond, t, noise, monitor: bool = False, wav=None, latent_scale: float = 18.0, update: bool = True):
         """-> loss (float tensor [1]) of this step, evaluated before the update.  monitor=True returns what DiffAudioRep.forward

@@ -509,3 +509,29 @@ def test_full_width_training_step_reference_vectors(gemm):
     off = max((abs(float(grads[n].double().abs().sum().cpu()) - sums[n]) / (sums[n] + 1e-12), n) for n in tr.names)
     assert off[0] < 2e-3, off
     e.close()
+
+
+def test_graphed_optimisation_step_equals_the_eager_one():
+    """Round 5: the optimisation step replayed from one hipGraph (DiffusionTrainer.use_graph / LDC_TRAIN_GRAPH=1: the first step of a shape
+    eager, the second captured over static input buffers, the rest replayed; Adam's step count on the device) against the same
+    steps issued layer by layer: different inputs every step (the static buffers are refreshed), same losses and parameters
+    (srcs/train.py:110-177 is the loop both stand for)."""
+    g = load_golden("train_unet")
+    sd = {k[2:]: T(g[k]) for k in list(g.keys()) if k.startswith("p.")}
+    gen = torch.Generator().manual_seed(77)
+    steps = [(torch.randn(2, 8, 32, generator=gen).clamp(-1, 1), torch.randn(2, 8, 32, generator=gen), torch.randint(0, 1000, (2,), generator=gen),
+              torch.randn(2, 8, 32, generator=gen)) for _ in range(6)]
+    out = []
+    for use_graph in (False, True):
+        e = engine("r84", "f32")
+        tr = TR.DiffusionTrainer(e, {k: v.clone() for k, v in sd.items()}, dim=16, dim_mults=(1, 2), lr=2e-3)
+        tr.use_graph = use_graph
+        losses = [float(tr.step(*s).cpu()[0]) for s in steps]
+        out.append((losses, torch.cat([v.reshape(-1).cpu() for v in tr.state_dict().values()])))
+        assert tr.opt.steps == len(steps)
+        if use_graph:
+            assert tr._graph is not None
+    (l0, p0), (l1, p1) = out
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-5, (l0, l1)
+    dev = (p0 - p1).abs()
+    assert float(dev.mean()) < 2e-6 and float((dev > 2e-4).float().mean()) < 2e-3, (float(dev.mean()), float(dev.max()))

@@ -9,7 +9,10 @@ def short(name: str) -> str:
     name = re.sub(r"^void ", "", name)
     name = name.replace("ldc::", "")
     name = re.sub(r"\(.*\)$", "", name)
-    return name[:90]
+    # template arguments in full (two conv_fast_kernel rows used to differ only past the 90th character: VERDICT r4); the spelled-out
+    # names of the non-type parameters are dropped to keep the rows readable
+    name = re.sub(r"\b(?:bool|int|unsigned) _?[A-Za-z]\w*, ?", "", name)
+    return name[:200]
 
 
 def main(path):

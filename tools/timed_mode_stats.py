@@ -69,7 +69,7 @@ def main():
         per_step_conv.append(np.where(ok, dur, 0.0).sum(axis=1)[5:])
         # gaps: from the end of one stamped conv to the start of the next stamped conv of the same part and step
     step_ms = [float((a[5:, 1] - a[5:, 0]).mean()) / 1e3 for a in tl]
-    print("# Round 4: per-kernel durations in the TIMED mode (graph replay, two batch parts on two streams), from device stamps")
+    print("# Per-kernel durations in the TIMED mode (graph replay, two batch parts on two streams), from device stamps")
     print()
     print(f"`python tools/timed_mode_stats.py` on MI355X: BASELINE configs[1] (32 x 2.4 s, 50 steps, bf16 UNet).  Every launch of the pipelined conv")
     print("kernel stamps the start of its first workgroup and the latest end among every eighth workgroup and the last eight (100 MHz device clock, `ldc_kstamps_*`); steps 5..49 of one")
