@@ -683,6 +683,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->side_streams = (getenv("LDC_SIDE") && c->split_batch == 1) ? 1 : 0;
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
+  c->split_ends = getenv("LDC_NO_SPLIT_ENDS") ? 0 : 1;
   c->xcd_teams = env_int("LDC_TEAMS", c->xcd_teams);
   c->teams_min_b = std::max(1, env_int("LDC_TEAMS_MINB", c->teams_min_b));
   c->teams_parts = std::max(1, env_int("LDC_TEAMS_PARTS", c->teams_parts));
@@ -820,6 +821,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
   }
   if (n == "lstm_stream") { c->lstm_stream_only = value ? 1 : 0; return LDC_OK; }
   if (n == "lstm_xcd") { c->lstm_xcd = value ? 1 : 0; return LDC_OK; }
+  if (n == "split_ends") { c->split_ends = value ? 1 : 0; return LDC_OK; }
   if (n == "fp8_act") {   // fp8-weight contexts: fp8 x fp8 MFMA where a tensor's only consumer is a conv (decided when the weights are packed)
     if (c->finalized) return fail(LDC_E_STATE, "fp8_act must be set before ldc_finalize_weights");
     c->fp8_act = value ? 1 : 0;
@@ -858,7 +860,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
@@ -2473,42 +2475,65 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
   hipStream_t s = pick_stream(c, stream);
   Halves h;
   LDCCHK(get_halves(c, B, L, F, s, &h));
+  // The codec front end (cond encoder -> RVQ -> upsampler -> start image) and back end (decoder) are chains of ~40 latency-bound
+  // launches each (fp32 convs on a fraction of the CUs, LSTM recurrences): with per-utterance normalisation nothing couples the
+  // items, so every batch part runs its own front / back end on its own stream, like its denoise steps, and the parts' chains fill
+  // each other's gaps (round 5; `split_ends` 0 / LDC_NO_SPLIT_ENDS restores the whole-batch ends).  The RVQ codes are written
+  // [n_q][B][F]: a caller that wants them gets the whole-batch path.
+  const bool split_ends = c->split_ends && per_item && !codes_out && h.n >= 2 && parts_parallel(c, h);
   LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
-    float* qr = nullptr;
-    int Fq = 0;
-    LDCCHK(get_cond_rows(c, wav, B, T, 0.f, ar, dry, s, &qr, &Fq, codes_out));
-    if (!dry && Fq != F) return fail(LDC_E_INVALID, "internal: encoder produced %d frames, expected %d", Fq, F);
     float* x = latents_out ? latents_out : (float*)ar.alloc((size_t)B * D * L * 4);
     float* mx = (float*)ar.alloc((size_t)B * 4);
-    // start image: upsample, /= max|.|+1e-8 (sample.py:125-129)
-    void* up = nullptr;
-    int Lu = 0;
-    LDCCHK(upsample_rows(c, qr, B, F, ar, dry, s, &up, &Lu));
-    if (!dry) {
-      if (cond_out) HIPCHK(launch_from_cl(DT_F32, qr, cond_out, B, D, F, nullptr, 0, 0.f, s));
-      HIPCHK(hipMemsetAsync(mx, 0, (size_t)B * 4, s));
-      HIPCHK(launch_maxabs(DT_F32, up, B, (int64_t)L * D, per_item ? 1 : 0, mx, s));
-      HIPCHK(launch_from_cl(DT_F32, up, x, B, D, L, mx, per_item ? 1 : 0, 1e-8f, s));
+    if (!dry && split_ends) LDCCHK(fork_parts(c, h, s));
+    const int n_front = split_ends ? h.n : 1;
+    for (int k = 0; k < n_front; ++k) {
+      hipStream_t sk = (split_ends && k > 0) ? c->aux_stream[k] : s;
+      const int b0 = split_ends ? h.b0[k] : 0, Bk = split_ends ? h.p[k]->B : B;
+      float* qr = nullptr;
+      int Fq = 0;
+      LDCCHK(get_cond_rows(c, wav + (size_t)b0 * T, Bk, T, 0.f, ar, dry, sk, &qr, &Fq, codes_out));
+      if (!dry && Fq != F) return fail(LDC_E_INVALID, "internal: encoder produced %d frames, expected %d", Fq, F);
+      // start image: upsample, /= max|.|+1e-8 (sample.py:125-129)
+      void* up = nullptr;
+      int Lu = 0;
+      LDCCHK(upsample_rows(c, qr, Bk, F, ar, dry, sk, &up, &Lu));
+      if (dry) continue;
+      if (cond_out) HIPCHK(launch_from_cl(DT_F32, qr, cond_out + (size_t)b0 * D * F, Bk, D, F, nullptr, 0, 0.f, sk));
+      HIPCHK(hipMemsetAsync(mx + b0, 0, (size_t)Bk * 4, sk));
+      HIPCHK(launch_maxabs(DT_F32, up, Bk, (int64_t)L * D, per_item ? 1 : 0, mx + b0, sk));
+      HIPCHK(launch_from_cl(DT_F32, up, x + (size_t)b0 * D * L, Bk, D, L, mx + b0, per_item ? 1 : 0, 1e-8f, sk));
       // process_cond for the UNet (rows are already channels-last fp32)
-      for (int k = 0; k < h.n; ++k) {
-        Plan* pl = h.p[k];
-        HIPCHK(hipMemcpyAsync(pl->cond_in_cl, qr + (size_t)h.b0[k] * F * D, (size_t)pl->B * F * D * 4, hipMemcpyDeviceToDevice, s));
-        LDCCHK(run_ops(c, pl, pl->cond_ops, false, s));
+      for (int kk = 0; kk < h.n; ++kk) {
+        if (split_ends && kk != k) continue;
+        Plan* pl = h.p[kk];
+        HIPCHK(hipMemcpyAsync(pl->cond_in_cl, qr + (size_t)(h.b0[kk] - b0) * F * D, (size_t)pl->B * F * D * 4, hipMemcpyDeviceToDevice, sk));
+        LDCCHK(run_ops(c, pl, pl->cond_ops, false, sk));
+        HIPCHK(launch_to_cl(c->dt, x + (size_t)h.b0[kk] * c->unet.channels * pl->L, pl->x_cl, pl->B, c->unet.channels, pl->L, nullptr, 0, 0.f, sk));
       }
-      LDCCHK(load_x(c, h, x, s));
+    }
+    if (!dry) {
+      if (split_ends) LDCCHK(join_parts(c, h, s));
       next_noise_key(c, noise == nullptr);
       LDCCHK(denoise_loop(c, h, B, x, noise, n_steps, s));
+      if (split_ends) LDCCHK(fork_parts(c, h, s));
     }
     // decoder (quirk Q3: no x18 un-scaling on this path, sample.py:131)
-    SeaRun R{c, &ar, s, dry, B};
-    void* zc = ar.alloc((size_t)B * L * D * 4);
-    if (!dry) HIPCHK(launch_to_cl(DT_F32, x, zc, B, D, L, nullptr, 0, 0.f, s));
-    void* y = nullptr;
-    int Lo = 0, C = 0;
-    LDCCHK(run_seanet(R, mc.dec, zc, L, &y, &Lo, &C));
+    int Lo_all = T;
+    for (int k = 0; k < n_front; ++k) {
+      hipStream_t sk = (split_ends && k > 0) ? c->aux_stream[k] : s;
+      const int b0 = split_ends ? h.b0[k] : 0, Bk = split_ends ? h.p[k]->B : B;
+      SeaRun R{c, &ar, sk, dry, Bk};
+      void* zc = ar.alloc((size_t)Bk * L * D * 4);
+      if (!dry) HIPCHK(launch_to_cl(DT_F32, x + (size_t)b0 * D * L, zc, Bk, D, L, nullptr, 0, 0.f, sk));
+      void* y = nullptr;
+      int Lo = 0, Cd = 0;
+      LDCCHK(run_seanet(R, mc.dec, zc, L, &y, &Lo, &Cd));
+      if (!dry) HIPCHK(hipMemcpyAsync(wav_out + (size_t)b0 * Lo, y, (size_t)Bk * Lo * 4, hipMemcpyDeviceToDevice, sk));
+      Lo_all = Lo;
+    }
     if (!dry) {
-      HIPCHK(hipMemcpyAsync(wav_out, y, (size_t)B * Lo * 4, hipMemcpyDeviceToDevice, s));
-      HIPCHK(launch_output_normalise(wav_out, B, Lo, per_item ? 1 : 0, c->outnorm_ws, s));
+      if (split_ends) LDCCHK(join_parts(c, h, s));
+      HIPCHK(launch_output_normalise(wav_out, B, Lo_all, per_item ? 1 : 0, c->outnorm_ws, s));
     }
     return LDC_OK;
   }));

@@ -280,6 +280,7 @@ struct ldc_ctx {
   hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int split_batch = 2;
+  int split_ends = 1;           // ldc_decode: the codec front / back ends per batch part on the parts' streams too (per-utterance normalisation only)
   int fp8_act = 1;              // LDC_FP8_ACT: in an fp8-weight context, tensors whose only consumer is a conv are produced in fp8 and
                                 // that conv runs fp8 x fp8 on the block-scaled MFMA (0: bf16 activations x fp8 weights everywhere)
   int part_graphs = 1;          // one single-stream graph per batch part, replays interleaved behind a bounded look-ahead: recorded-AQL replay path,
