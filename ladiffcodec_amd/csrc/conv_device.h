@@ -474,6 +474,73 @@ __device__ __forceinline__ void epilogue_rows(const KA& a, f32x16 (&acc)[TM][TN]
   }
 }
 
+// The same with a residual: the rows are staged in fp32 and the residual is added in the row phase as 16-byte pieces (one rounding,
+// as before) -- the accumulator-layout form above issues sixteen 2-byte residual loads per lane and 32 x 32 sub-tile.
+template <typename T, int TM, int TN, bool ACT, typename KA>
+__device__ __forceinline__ void epilogue_rows_res(const KA& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0, int col_wave0, int M) {
+  constexpr int PITCH = TN * 32 * 4 + 16;
+  constexpr int EPL = 16 / (int)sizeof(T);          // output elements per lane in the row phase (16 bytes)
+  constexpr int LPR = TN * 32 / EPL;                // lanes per row
+  constexpr int RPS = 64 / LPR;                     // rows per sweep
+  constexpr int NSW = TM * 32 / RPS;
+  const int lane = ldc_tid() & 63;
+  const int rsub = lane / LPR, chunk = lane % LPR;
+  const int col = col_wave0 + chunk * EPL;
+  uint4 rres[NSW];
+#pragma unroll
+  for (int sw = 0; sw < NSW; ++sw) {
+    const int m = m_wave0 + sw * RPS + rsub;
+    const bool ok = m < M && col < a.n;
+    rres[sw] = *reinterpret_cast<const uint4*>(a.residual + ((size_t)(ok ? m : 0) * a.n + (ok ? col : 0)) * sizeof(T));
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int c = col_wave0 + j * 32 + (lane & 31);
+    const bool col_ok = c < a.n;
+    const float bv = (a.bias && col_ok) ? a.bias[c] : 0.0f;
+    const float sc = (a.wscale && col_ok) ? a.wscale[c] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        reinterpret_cast<float*>(wave_lds + (size_t)row * PITCH)[j * 32 + (lane & 31)] = fmaf(acc[i][j][r], sc, bv);
+      }
+  }
+  // same wave wrote and reads: LDS executes a wave's operations in order
+#pragma unroll
+  for (int sw = 0; sw < NSW; ++sw) {
+    const int row = sw * RPS + rsub;
+    const int m = m_wave0 + row;
+    float f[EPL];
+    const float* sp = reinterpret_cast<const float*>(wave_lds + (size_t)row * PITCH + chunk * EPL * 4);
+#pragma unroll
+    for (int e = 0; e < EPL; e += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(sp + e);
+      f[e] = t.x; f[e + 1] = t.y; f[e + 2] = t.z; f[e + 3] = t.w;
+    }
+    const unsigned rw[4] = {rres[sw].x, rres[sw].y, rres[sw].z, rres[sw].w};
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) f[e] += __uint_as_float(rw[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPL; e += 2) {
+        f[e] += __uint_as_float(rw[e >> 1] << 16);
+        f[e + 1] += __uint_as_float(rw[e >> 1] & 0xffff0000u);
+      }
+    }
+    if (ACT) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) f[e] = act_apply(f[e], a.post_act);
+    }
+    uint4 v;
+    if constexpr (sizeof(T) == 4) v = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    else v = make_uint4(hw_bf16x2(f[0], f[1]), hw_bf16x2(f[2], f[3]), hw_bf16x2(f[4], f[5]), hw_bf16x2(f[6], f[7]));
+    if (m < M && col < a.n) *reinterpret_cast<uint4*>(a.y + ((size_t)m * a.y_ld + col) * sizeof(T)) = v;
+  }
+}
+
 // 16-byte global accesses that other workgroups of the SAME launch may rely on (the eight XCD L2s are not coherent and a
 // CU's L1 is never refreshed by another CU's stores): write-through (sc1) stores, L1-bypassing (sc1) loads.  Inline asm: the
 // compiler neither counts nor waits for them -- the caller drains with wait_vm0().
@@ -816,9 +883,9 @@ __device__ __forceinline__ void epilogue_rows_dispatch(const KA& a, f32x16 (&acc
   }
   if (a.gn_sum) epilogue_gn_stats<TM, TN>(a, acc, m_wave0 + 4 * (lane >> 5), col_wave0 + (lane & 31), m0, BM, M);
   if (a.colmax) epilogue_colmax<T, TM, TN>(a, acc, m_wave0 + 4 * (lane >> 5), col_wave0 + (lane & 31), m0, BM, M);
-  if (a.residual) {
-    if (a.post_act == ACT_NONE) epilogue_rows<T, TM, TN, true, false>(a, acc, wave_lds, m_wave0, col_wave0, M);
-    else epilogue_rows<T, TM, TN, true, true>(a, acc, wave_lds, m_wave0, col_wave0, M);
+  if (a.residual) {   // (fp32 staging: the launcher sized the LDS for it)
+    if (a.post_act == ACT_NONE) epilogue_rows_res<T, TM, TN, false>(a, acc, wave_lds, m_wave0, col_wave0, M);
+    else epilogue_rows_res<T, TM, TN, true>(a, acc, wave_lds, m_wave0, col_wave0, M);
   } else {
     if (a.post_act == ACT_NONE) epilogue_rows<T, TM, TN, false, false>(a, acc, wave_lds, m_wave0, col_wave0, M);
     else epilogue_rows<T, TM, TN, false, true>(a, acc, wave_lds, m_wave0, col_wave0, M);

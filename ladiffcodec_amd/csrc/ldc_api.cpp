@@ -479,6 +479,25 @@ static int build_unet(ldc_ctx* c, std::string* missing) {
   WeightReader wr{c, LDC_MODEL_MAIN, ""};
   const std::string P = "diff_model";
   LDCCHK(build_plain_conv(c, wr, P + ".init_conv", u.cond_channels, u.channels, u.dim, 7, 1, 3, 0, &u.init));
+  {
+    // init_conv(cat(cond, x)) = W_c * cond + b  +  W_x * x (unet.py:434): the processed condition does not change over the denoise steps, so its
+    // half of the contraction is evaluated once per sampler call (init_c, with the bias) and every step runs only the x half (init_x) and adds it
+    HostTensor* w = wr.get(P + ".init_conv.weight", {u.dim, u.cond_channels + u.channels, 7});
+    HostTensor* b = wr.get(P + ".init_conv.bias", {u.dim});
+    if (w && b) {
+      const int Cc = u.cond_channels, Cx = u.channels, Ct = Cc + Cx;
+      std::vector<float> wc((size_t)u.dim * Cc * 7), wx((size_t)u.dim * Cx * 7);
+      for (int o = 0; o < u.dim; ++o) {
+        for (int i = 0; i < Cc; ++i) for (int k = 0; k < 7; ++k) wc[((size_t)o * Cc + i) * 7 + k] = w->data[((size_t)o * Ct + i) * 7 + k];
+        for (int i = 0; i < Cx; ++i) for (int k = 0; k < 7; ++k) wx[((size_t)o * Cx + i) * 7 + k] = w->data[((size_t)o * Ct + Cc + i) * 7 + k];
+      }
+      ConvSpec sc;
+      sc.dt = c->dt; sc.cin1 = Cc; sc.cout = u.dim; sc.k = 7; sc.stride = 1; sc.pad_left = 3;
+      LDCCHK(make_conv(c, sc, wc.data(), b->data.data(), &u.init_c));
+      sc.cin1 = Cx;
+      LDCCHK(make_conv(c, sc, wx.data(), nullptr, &u.init_x));
+    }
+  }
   const int nlev = (int)u.dims.size() - 1;
   int ss_off = 0;
   auto take_ss = [&](ResnetW& r) { r.ss_off = ss_off; ss_off += 2 * r.cout; };
@@ -684,6 +703,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
   c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
   c->split_ends = getenv("LDC_NO_SPLIT_ENDS") ? 0 : 1;
+  c->split_init = getenv("LDC_NO_SPLIT_INIT") ? 0 : 1;
   c->xcd_teams = env_int("LDC_TEAMS", c->xcd_teams);
   c->teams_min_b = std::max(1, env_int("LDC_TEAMS_MINB", c->teams_min_b));
   c->teams_parts = std::max(1, env_int("LDC_TEAMS_PARTS", c->teams_parts));
@@ -822,6 +842,10 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
   if (n == "lstm_stream") { c->lstm_stream_only = value ? 1 : 0; return LDC_OK; }
   if (n == "lstm_xcd") { c->lstm_xcd = value ? 1 : 0; return LDC_OK; }
   if (n == "split_ends") { c->split_ends = value ? 1 : 0; return LDC_OK; }
+  if (n == "split_init") {
+    if ((value ? 1 : 0) != c->split_init) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->split_init = value ? 1 : 0; }
+    return LDC_OK;
+  }
   if (n == "fp8_act") {   // fp8-weight contexts: fp8 x fp8 MFMA where a tensor's only consumer is a conv (decided when the weights are packed)
     if (c->finalized) return fail(LDC_E_STATE, "fp8_act must be set before ldc_finalize_weights");
     c->fp8_act = value ? 1 : 0;
@@ -860,7 +884,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | split_init | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
@@ -1822,7 +1846,19 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     in_cond = cs; in_x = xs;
   }
   void* x0 = pb.act(B * L, u.dim);
-  pb.conv(u.init, in_cond, in_x, x0, nullptr, L, L);
+  if (c->split_init && !c->w8 && !c->cfg.unet_scale_x && u.init_c.w && u.init_x.w) {
+    // the condition's half of init_conv once per sampler call (behind process_cond), the x half + that tensor every step
+    void* pc = pb.act(B * L, u.dim);
+    {
+      ConvCall cc;
+      cc.B = B; cc.L_in = L; cc.L_rows = L; cc.x1 = pl->cond_cl; cc.y = pc; cc.y_ld = u.init_c.n; cc.tune = &c->tune;
+      const ConvLayer* lp = &u.init_c;
+      pl->cond_ops.push_back([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); });
+    }
+    pb.conv(u.init_x, in_x, nullptr, x0, pc, L, L);
+  } else {
+    pb.conv(u.init, in_cond, in_x, x0, nullptr, L, L);
+  }
   pl->taps["init"] = {x0, u.dim, L};
   const void* x = x0;
   int Lc = L;

@@ -156,6 +156,7 @@ struct UnetW {
   int dim = 0, time_dim = 0, groups = 8, heads = 4, dim_head = 32, channels = 128, cond_channels = 128;
   std::vector<int> dims;
   ConvLayer init, final_conv;
+  ConvLayer init_c, init_x;     // init_conv split by input: the condition's half (+ bias) is evaluated once per sampler call, x's half every step
   ConvLayer final_conv_f8;      // final_conv with fp8 inputs
   std::vector<LevelW> downs, ups;
   ResnetW mid1, mid2, fin;
@@ -280,6 +281,7 @@ struct ldc_ctx {
   hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int split_batch = 2;
+  int split_init = 1;           // init_conv's condition half hoisted out of the denoise loop (LDC_NO_SPLIT_INIT / option "split_init")
   int split_ends = 1;           // ldc_decode: the codec front / back ends per batch part on the parts' streams too (per-utterance normalisation only)
   int fp8_act = 1;              // LDC_FP8_ACT: in an fp8-weight context, tensors whose only consumer is a conv are produced in fp8 and
                                 // that conv runs fp8 x fp8 on the block-scaled MFMA (0: bf16 activations x fp8 weights everywhere)
