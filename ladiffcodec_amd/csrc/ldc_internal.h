@@ -295,10 +295,9 @@ struct ldc_ctx {
   int fuse_kmax = 1;
   int fuse_ln = 1;              // PreNorm LayerNorm written by the preceding ResnetBlock's last kernel
   int coop_launch = 0;          // LDC_COOP_LAUNCH: hipLaunchCooperativeKernel for the cooperative LSTM (see seanet.hip)
-  int lstm_xcd = 0;             // LDC_LSTM_XCD / option "lstm_xcd": few-item (B <= 4) cooperative LSTM with the hidden-state exchange inside ONE XCD and the
-                                // products on the VALU (seanet.hip: lstm_xcd_kernel).  OFF: parity-clean but measured slower than lstm_coop_kernel spread over the
-                                // chip (configs[0]: 4.13 vs 3.33 ms per clip, profiles/r05_team_chain_experiments.md); a device-side failure of it switches
-                                // the context back to the placement-independent kernel
+  int lstm_xcd = 1;             // LDC_LSTM_XCD / option "lstm_xcd": the cooperative LSTM of ONE or TWO items on sixteen 1024-thread workgroups of one XCD, the
+                                // hidden-state exchange through that XCD's L2 (seanet.hip: lstm_xcd_kernel; configs[0]: 2.6 instead of 3.3 ms per clip); a
+                                // device-side failure of it switches the context back to the placement-independent kernel
   int xcd_resident[2] = {0, 0};
   int coop_resident[2] = {0, 0};   // [H == 512]: the cooperative LSTM's H/4 workgroups fit the device together (asked at ldc_create)
   int fuse_attn_tail = 1;       // LinearAttention out + to_out conv + LayerNorm + residual in one launch (bf16 engine)

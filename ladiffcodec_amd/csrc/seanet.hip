@@ -7,6 +7,7 @@
 //               projection for all T runs as one GEMM on the conv kernel; what is left is the strictly
 //               sequential h_{t-1} -> h_t chain, latency-bound: one workgroup per utterance keeps W_hh in
 //               registers (H <= 128: one gate row per thread) or streams a k-major copy from L2 (H = 512).
+#include <type_traits>
 #include "ldc_kernels.h"
 #include "ldc_math.h"
 
@@ -252,9 +253,12 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const f
   const bool owner = tid < 4 * B;
   float c_state = 0.f;
   float pnext[4] = {0.f, 0.f, 0.f, 0.f};
+  float sknext = 0.f;      // the skip input of the coming step, fetched a step ahead like the gate pre-activations: loaded inside the
+                           // step (round 4) its HBM latency sat between the h stores and the arrival that releases the other workgroups
   if (owner) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) pnext[g] = sld<T>(pre, ((size_t)ob * T_len) * (4 * H) + g * H + 4 * j + ou);
+    if (skip) sknext = sld<T>(skip, ((size_t)ob * T_len) * H + 4 * j + ou);
   }
   __syncthreads();
   bool dead = false;
@@ -329,15 +333,15 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const f
       c_state = fg * c_state + ig * gg;
       const float h = og * tanhf(c_state);
       __hip_atomic_store(hbuf + (size_t)(t & 1) * 32 * H + (size_t)ob * H + 4 * j + ou, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the h store has reached memory; nothing else of this thread is in flight here)
       const size_t o = ((size_t)ob * T_len + t) * H + 4 * j + ou;
-      const float sk = skip ? sld<T>(skip, o) : 0.f;
+      sst<T>(out, o, h + sknext);
       if (t + 1 < T_len) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) pnext[g] = sld<T>(pre, ((size_t)ob * T_len + t + 1) * (4 * H) + g * H + 4 * j + ou);
+        if (skip) sknext = sld<T>(skip, o + H);
       }
-      sst<T>(out, o, h + sk);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && t + 1 < T_len)
       __hip_atomic_fetch_add(sync + (j % LSTM_COOP_SHARDS) * LSTM_COOP_SHARD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -350,29 +354,50 @@ __global__ __launch_bounds__(256) void lstm_coop_kernel(const void* pre, const f
 }
 
 // ---------------------------------------------------------------------------------------------
-// Few items (B <= 4: configs[0]'s single clip, a file decoded alone by the CLI): the same weight-stationary recurrence with the
-// hidden-state exchange kept inside ONE XCD and the matrix-vector products on the VALU (round 5).
+// One or two items (configs[0]'s single clip, a file decoded alone by the CLI): the weight-stationary recurrence on SIXTEEN workgroups
+// of 1024 threads, all on one XCD, one per CU (round 5).
 //   * profiles/r05_xcd_team_probe.md: a plain store stays in the writing XCD's L2 and an L1-bypassing (sc1) load from another CU of
-//     the SAME XCD reads it there -- flag latency 0.4 us, against 0.8-1.0 us + cross-XCD-rate reads for the write-through /
-//     memory-side-atomic protocol of lstm_coop_kernel, of which a step has three dependent legs (h stores, arrival atomics, h loads).
-//   * The launch has 8 x H/4 workgroups; every workgroup reads HW_REG_XCC_ID, the ones on XCC 0 take a rank (one atomic per launch)
-//     and the first H/4 of them do the work, four to a CU; everybody else leaves at once.  Team membership comes from the hardware
-//     id, so the L2 the data sits in IS the L2 the readers ask; a team that does not fill ends in the bounded spin (NaN output +
-//     host flag) and the context goes back to lstm_coop_kernel.
-//   * With one to four items a 16-item MFMA tile is 15/16 padding, and 128 workgroups on 32 CUs would serialise four waves' MFMA
-//     chains per SIMD (measured: the MFMA form of this kernel ran 4.5 us per step against 3.5 us for lstm_coop_kernel spread over the
-//     chip).  Here thread (gate row r, K segment g) keeps its H/16 weights in registers and a step is H/16 FMAs per item + a
-//     16-lane shuffle reduction.
-// Per step: plain stores of the h slice -> vmcnt(0) -> the workgroup's flag word (plain store of the step number) | one wave polls
-// the H/4 flag words (sc1) -> sc1 loads of h.
+//     the SAME XCD reads it there -- flag latency 0.4 us against 0.8-1.0 us + memory-rate reads for the write-through / memory-side-
+//     atomic protocol of lstm_coop_kernel, of which a step has three dependent legs.
+//   * Workgroup j keeps the four gate rows of units [j H/16, (j + 1) H/16) in registers (4H/16 rows x H weights = 64 per thread at
+//     H = 512); a step is H/16-wide dot products on the VALU (a 16-item MFMA tile would be 15/16 padding), a shuffle reduction, the
+//     gates of H/16 units, H/16 plain stores of h and ONE flag word; sixteen participants instead of 128, each alone on its CU (the
+//     128-workgroup XCD-local forms measured slower than the chip-wide kernel: four workgroups' pollers and gate arithmetic per CU).
+//   * The launch has 8 x 16 workgroups; the ones on XCC 0 take a rank (one atomic per launch), everybody else leaves at once.  Team
+//     membership comes from the hardware id, so the L2 the data sits in IS the L2 the readers ask; a team that does not fill ends in
+//     the bounded spin (NaN output + host flag) and the context goes back to lstm_coop_kernel.
 // ---------------------------------------------------------------------------------------------
+// sum over groups of G consecutive lanes (G = 8, 16, 32 or 64), left in every lane of the group: DPP lane permutations on the VALU for the
+// first steps (the generic __shfl_xor goes through the LDS crossbar: ds_bpermute)
+template <int G>
+__device__ __forceinline__ float dpp_sum_group(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>());    // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>());    // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x141>());   // row_half_mirror: the other quad of the 8 lanes
+  if (G >= 16) v += dpp(v, std::integral_constant<int, 0x140>());   // row_mirror: the other half of the 16 lanes
+  if (G >= 32) v += __shfl_xor(v, 16);
+  if (G >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
 template <typename T, int H>
-__global__ __launch_bounds__(256, 4) void lstm_xcd_kernel(const void* pre, const float* w_hh, void* out, const void* skip,
-                                                          int B, int T_len, float* hbuf, unsigned* sync, unsigned* host_flag) {
-  constexpr int KS = H / 16;     // k range of one thread
-  constexpr int NV = KS / 4;     // float4 pieces of it
-  constexpr int NB = H / 4;      // workgroups of the team
-  __shared__ float sgate[4][16];
+__global__ __launch_bounds__(1024) void lstm_xcd_kernel(const void* pre, const float* w_hh, void* out, const void* skip,
+                                                        int B, int T_len, float* hbuf, unsigned* sync, unsigned* host_flag, unsigned long long* dbg = nullptr) {
+  constexpr int NB = 16;              // workgroups of the team
+  constexpr int U = H / NB;           // hidden units of a workgroup
+  constexpr int ROWS = 4 * U;         // gate rows of a workgroup
+  constexpr int RPT = 2;              // gate rows per thread: a thread's h segment is read from LDS once for two rows.  (One row per thread:
+                                      // every thread reads 256 bytes of h, 1 000 cycles of LDS bandwidth per step; four rows: a 32-lane reduction
+                                      // whose last step leaves the DPP for the LDS crossbar.  Products of a step: 1 560 / this / 3 070 cycles.)
+  constexpr int KSEG = 1024 / (ROWS / RPT);   // threads per row group (32 at H = 512, 64 at H = 256)
+  constexpr int KS = H / KSEG;        // k range of one thread (16 / 4)
+  constexpr int NV = KS / 4;
+  constexpr int KPAD = KS >= 8 ? 4 : 0;      // LDS: segment g starts at g * (KS + KPAD) floats -- the segments a wave reads at once sit in different banks
+  __shared__ float sgate[2][ROWS];
+  __shared__ __attribute__((aligned(16))) float sh[2][H + KPAD * KSEG];   // (unpadded 256-byte segments: an 8-way bank conflict on every read, 9 200 cycles per step)
   __shared__ int s_dead, s_rank;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 7u;   // HW_REG_XCC_ID
@@ -384,38 +409,41 @@ __global__ __launch_bounds__(256, 4) void lstm_xcd_kernel(const void* pre, const
   __syncthreads();
   const int j = s_rank;
   if (j >= NB) return;
-  unsigned* flags = sync;        // [NB] words: the step a workgroup has published (zeroed before the launch)
-  const int r = tid >> 4, g = tid & 15;          // gate row of this workgroup (gate = r >> 2, unit = r & 3), K segment
-  f32x4 wreg[NV];
-  {
-    const size_t row = (size_t)(r >> 2) * H + 4 * j + (r & 3);
+  unsigned* flags = sync;             // [NB] words on one line: the step a workgroup has published (zeroed before the launch)
+  const int rg = tid / KSEG, g = tid % KSEG;        // row group (rows rg * RPT ..), k segment
+  f32x4 wreg[RPT][NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) wreg[v] = *reinterpret_cast<const f32x4*>(w_hh + row * H + g * KS + 4 * v);
+  for (int q = 0; q < RPT; ++q) {
+    const int r = rg * RPT + q;
+    const size_t row = (size_t)(r / U) * H + (size_t)j * U + (r % U);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) wreg[q][v] = *reinterpret_cast<const f32x4*>(w_hh + row * H + g * KS + 4 * v);
   }
-  const int ob = tid >> 2, ou = tid & 3;
-  const bool owner = tid < 4 * B;
+  const int ob = tid / U, ou = tid % U;             // gate owner: (item, unit)
+  const bool owner = tid < U * B;
   float c_state = 0.f;
   float pnext[4] = {0.f, 0.f, 0.f, 0.f};
+  float sknext = 0.f;
   if (owner) {
 #pragma unroll
-    for (int gg = 0; gg < 4; ++gg) pnext[gg] = sld<T>(pre, ((size_t)ob * T_len) * (4 * H) + gg * H + 4 * j + ou);
+    for (int gg = 0; gg < 4; ++gg) pnext[gg] = sld<T>(pre, ((size_t)ob * T_len) * (4 * H) + gg * H + j * U + ou);
+    if (skip) sknext = sld<T>(skip, ((size_t)ob * T_len) * H + j * U + ou);
   }
   bool dead = false;
   int t = 0;
   for (; t < T_len; ++t) {
-    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    float dot[2][RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) dot[0][q] = dot[1][q] = 0.f;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0;
+    const bool rec = dbg && j == 3 && tid == 0 && t >= 16 && t < 48;
+    if (rec) st0 = __builtin_amdgcn_s_memtime();
     if (t > 0) {
       if (w == 0) {
         const unsigned long long t0 = wall_clock64();
         for (unsigned spins = 0;; ++spins) {
-          bool ok = true;
-#pragma unroll
-          for (int k = 0; k < (NB + 63) / 64; ++k) {
-            const int i = k * 64 + lane;
-            if (i < NB) ok = ok && __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)t;
-          }
+          const bool ok = lane >= NB || __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)t;
           if (__all(ok)) break;
-          __builtin_amdgcn_s_sleep(1);
           if ((spins & 255u) == 255u) {
             const unsigned flag = lane == 0 ? __hip_atomic_load(sync + 200, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             if (__any(flag != 0u) || wall_clock64() - t0 > 20000000ull) {   // 0.2 s
@@ -426,61 +454,75 @@ __global__ __launch_bounds__(256, 4) void lstm_xcd_kernel(const void* pre, const
         }
       }
       __syncthreads();
+      if (rec) st1 = __builtin_amdgcn_s_memtime();
       if (s_dead) { dead = true; break; }
-      const float* hp = hbuf + (size_t)((t + 1) & 1) * 32 * H + g * KS;
-      // one item at a time through one operand buffer (four buffers would spill: 128 + 32 registers against the 128 that four
-      // workgroups per CU allow)
+      // h_{t-1} of the (<= 2) items: ONE L1-bypassing load per 16 bytes and workgroup into LDS (every thread loading its own k segment
+      // past the L1 was 128-fold redundant L2 traffic on sixteen hot lines: 8.4 us per step), then broadcast reads
+      const float* hp = hbuf + (size_t)((t + 1) & 1) * 32 * H;
+      if (tid < B * (H / 4)) {
+        const int b = tid / (H / 4), v = tid % (H / 4);
+        f32x4 hv;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(hv) : "v"(hp + (size_t)b * H + 4 * v) : "memory");
+        *reinterpret_cast<f32x4*>(&sh[b][4 * v + KPAD * ((4 * v) / KS)]) = hv;
+      }
+      __syncthreads();
+      if (rec) st2 = __builtin_amdgcn_s_memtime();
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < 2; ++b)
         if (b < B) {
-          f32x4 hreg[NV];
-#pragma unroll
-          for (int v = 0; v < NV; ++v)
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hreg[v]) : "v"(hp + (size_t)b * H + 4 * v) : "memory");   // past the L1, from this XCD's L2
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
           for (int v = 0; v < NV; ++v) {
-            asm volatile("" : "+v"(hreg[v]));
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(&sh[b][g * (KS + KPAD) + 4 * v]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dot[b] = fmaf(hreg[v][e], wreg[v][e], dot[b]);
+            for (int q = 0; q < RPT; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dot[b][q] = fmaf(hv[e], wreg[q][v][e], dot[b][q]);
           }
         }
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < 2; ++b)
+        if (b < B) {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) dot[b] += __shfl_xor(dot[b], o);
+          for (int q = 0; q < RPT; ++q) dot[b][q] = dpp_sum_group<KSEG>(dot[b][q]);
+        }
     }
     if (g == 0) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) sgate[b][r] = dot[b];
+      for (int q = 0; q < RPT; ++q) {
+        sgate[0][rg * RPT + q] = dot[0][q];
+        sgate[1][rg * RPT + q] = dot[1][q];
+      }
     }
     __syncthreads();
+    if (rec) st3 = __builtin_amdgcn_s_memtime();
     if (owner) {
       float gates[4];
 #pragma unroll
-      for (int gg = 0; gg < 4; ++gg) gates[gg] = pnext[gg] + sgate[ob][gg * 4 + ou];
+      for (int gg = 0; gg < 4; ++gg) gates[gg] = pnext[gg] + sgate[ob][gg * U + ou];
       const float ig = sigmoid_acc(gates[0]), fg = sigmoid_acc(gates[1]);
       const float gv = tanhf(gates[2]), og = sigmoid_acc(gates[3]);
       c_state = fg * c_state + ig * gv;
       const float h = og * tanhf(c_state);
       // plain store: the line stays in this XCD's L2, where the team's sc1 loads find it
-      asm volatile("global_store_dword %0, %1, off" ::"v"(hbuf + (size_t)(t & 1) * 32 * H + (size_t)ob * H + 4 * j + ou), "v"(h) : "memory");
-      const size_t o = ((size_t)ob * T_len + t) * H + 4 * j + ou;
-      const float sk = skip ? sld<T>(skip, o) : 0.f;
+      asm volatile("global_store_dword %0, %1, off" ::"v"(hbuf + (size_t)(t & 1) * 32 * H + (size_t)ob * H + j * U + ou), "v"(h) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (only the h store is outstanding here: the flag may follow it at once)
+      if (rec) st4 = __builtin_amdgcn_s_memtime();
+      const size_t o = ((size_t)ob * T_len + t) * H + j * U + ou;
+      sst<T>(out, o, h + sknext);
       if (t + 1 < T_len) {
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) pnext[gg] = sld<T>(pre, ((size_t)ob * T_len + t + 1) * (4 * H) + gg * H + 4 * j + ou);
+        for (int gg = 0; gg < 4; ++gg) pnext[gg] = sld<T>(pre, ((size_t)ob * T_len + t + 1) * (4 * H) + gg * H + j * U + ou);
+        if (skip) sknext = sld<T>(skip, o + H);
       }
-      sst<T>(out, o, h + sk);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && t + 1 < T_len) {
       asm volatile("global_store_dword %0, %1, off" ::"v"(flags + j), "v"((unsigned)(t + 1)) : "memory");
     }
+    if (rec) { st5 = __builtin_amdgcn_s_memtime(); unsigned long long* o = dbg + (size_t)(t - 16) * 6; o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = st5; }
   }
   if (dead && owner) {
-    for (int tt = t; tt < T_len; ++tt) sst<T>(out, ((size_t)ob * T_len + tt) * H + 4 * j + ou, __builtin_nanf(""));
+    for (int tt = t; tt < T_len; ++tt) sst<T>(out, ((size_t)ob * T_len + tt) * H + j * U + ou, __builtin_nanf(""));
   }
   if (dead && tid == 0 && host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -507,9 +549,25 @@ static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out
     const void* pp = p; void* oo = o; const void* kk = k; int nbv = nb, tl = T_len;
     void* args[] = {&pp, &w_rm, &oo, &kk, &nbv, &tl, &hbuf, &sync, &host_flag};
     const void* fn = H == 512 ? reinterpret_cast<const void*>(lstm_coop_kernel<T, 512>) : reinterpret_cast<const void*>(lstm_coop_kernel<T, 256>);
-    if (coop_launch == 2 && nb <= 4) {   // few items: XCD-local exchange, 8 x H/4 workgroups, the ones on XCC 0 form the team
+    if (coop_launch == 2 && nb <= 2) {   // one or two items: XCD-local exchange, 8 x 16 workgroups of 1024 threads, the ones on XCC 0 form the team
       const void* fx = H == 512 ? reinterpret_cast<const void*>(lstm_xcd_kernel<T, 512>) : reinterpret_cast<const void*>(lstm_xcd_kernel<T, 256>);
-      e = hipLaunchKernel(fx, dim3(8 * (H / 4)), dim3(256), args, 0, s);
+      static unsigned long long* dbg = nullptr;
+      static int dbg_n = 0;
+      if (getenv("LDC_LSTM_STAMPS") && !dbg) (void)hipMalloc((void**)&dbg, 32 * 6 * 8);
+      void* args2[] = {&pp, &w_rm, &oo, &kk, &nbv, &tl, &hbuf, &sync, &host_flag, &dbg};
+      e = hipLaunchKernel(fx, dim3(8 * 16), dim3(1024), args2, 0, s);
+      if (dbg && ++dbg_n == 20) {   // tuning aid: one launch's per-step phase stamps (shader cycles) of workgroup 3
+        (void)hipStreamSynchronize(s);
+        unsigned long long hb[32 * 6];
+        (void)hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost);
+        double acc[6] = {0};
+        for (int i = 1; i < 32; ++i) {
+          acc[0] += (double)(hb[i * 6 + 1] - hb[i * 6 + 0]); acc[1] += (double)(hb[i * 6 + 2] - hb[i * 6 + 1]); acc[2] += (double)(hb[i * 6 + 3] - hb[i * 6 + 2]);
+          acc[3] += (double)(hb[i * 6 + 4] - hb[i * 6 + 3]); acc[4] += (double)(hb[i * 6 + 5] - hb[i * 6 + 4]); acc[5] += (double)(hb[i * 6 + 0] - hb[(i - 1) * 6 + 0]);
+        }
+        fprintf(stderr, "[lstm_xcd] cycles per step: poll %.0f | h load %.0f | dot+reduce %.0f | gates+h store %.0f | rest+flag %.0f | step %.0f\n", acc[0] / 31, acc[1] / 31,
+                acc[2] / 31, acc[3] / 31, acc[4] / 31, acc[5] / 31);
+      }
     } else if (coop_launch == 1) e = hipLaunchCooperativeKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
     else e = hipLaunchKernel(fn, dim3(H / 4), dim3(256), args, 0, s);
     if (e != hipSuccess) return e;
@@ -518,19 +576,17 @@ static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out
 }
 
 bool lstm_coop_eligible(int H) { return H == 256 || H == 512; }
-// the XCD-local form needs the team's H/4 workgroups on the 32 CUs of one XCD
+// the XCD-local form needs its sixteen 1024-thread workgroups resident on one XCD (32 CUs)
 bool lstm_xcd_resident(int H) {
   if (!lstm_coop_eligible(H)) return false;
   const void* fn = H == 512 ? reinterpret_cast<const void*>(lstm_xcd_kernel<float, 512>) : reinterpret_cast<const void*>(lstm_xcd_kernel<float, 256>);
   int per_cu = 0, cus = 0, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 1024, 0) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  // (no margin to give: 128 workgroups on 32 CUs is exactly the four per CU that 110 registers allow; the kernel uses 80 SGPRs, inside the
-  // range where the occupancy query is exact -- MI355X_MICROARCH.md -- and a team that does not fill ends in the bounded spin)
-  return cus % 8 == 0 && (long long)per_cu * (cus / 8) >= H / 4;
+  return cus % 8 == 0 && per_cu >= 1 && cus / 8 >= 16;
 }
 
 // Can the H/4 workgroups of the cooperative kernel be resident together on the current device?  Asked once per context

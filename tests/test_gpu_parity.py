@@ -55,7 +55,7 @@ def test_sconvtranspose1d_against_reference_vectors():
         assert rel(y.cpu().numpy(), g[n + ".y"]) < 1e-5, n
 
 
-@pytest.mark.parametrize("H,Tn,Bn", [(16, 11, 3), (64, 300, 3), (128, 160, 3), (512, 24, 3), (512, 120, 1), (256, 33, 4), (512, 130, 32), (512, 40, 37),
+@pytest.mark.parametrize("H,Tn,Bn", [(16, 11, 3), (64, 300, 3), (128, 160, 3), (512, 24, 3), (512, 120, 1), (256, 33, 2), (512, 17, 2), (512, 130, 32), (512, 40, 37),
                                      (256, 50, 20), (192, 9, 2)])
 def test_slstm_all_kernel_variants(H, Tn, Bn):
     """H=64/128 take the register-resident kernel, H=256/512 the cooperative weight-stationary one (one or two
@@ -73,15 +73,15 @@ def test_slstm_all_kernel_variants(H, Tn, Bn):
     y = e.slstm(x.cuda(), ws, 2)
     assert rel(y.cpu().numpy(), ref.numpy()) < 2e-5
     if H in (256, 512):
-        # round 5: the few-item form with the hidden-state exchange inside one XCD (lstm_xcd_kernel, B <= 4; opt-in: measured slower) and the
-        # streamed kernel give the same sequence as the default cooperative kernel
+        # round 5: one or two items take the XCD-local form by default (sixteen 1024-thread workgroups of one XCD, lstm_xcd_kernel); the
+        # placement-independent cooperative kernel and the streamed one give the same sequence
         try:
-            for opt, val in (("lstm_xcd", 1), ("lstm_stream", 1)):
+            for opt, val in (("lstm_xcd", 0), ("lstm_stream", 1)):
                 e.set_option(opt, val)
                 y2 = e.slstm(x.cuda(), ws, 2)
                 assert rel(y2.cpu().numpy(), ref.numpy()) < 2e-5, (opt, val)
         finally:
-            e.set_option("lstm_xcd", 0)
+            e.set_option("lstm_xcd", 1)
             e.set_option("lstm_stream", 0)
     if H == 16:
         gold = load_golden("primitives")
