@@ -121,48 +121,81 @@ hipError_t launch_conv_cin1(int dt, const float* x, void* y, const float* w, con
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoid_acc(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// One thread per gate row (4H threads), W_hh row in registers, h broadcast from LDS.
+// 4H threads, W_hh in registers, h in LDS.  Thread (row group rg, k segment g) holds four consecutive gate rows x H/4 weights: it reads
+// its QUARTER of h once for four rows and the four segments meet in a two-step DPP reduction.  (Round 1-4: one thread per gate row, every
+// thread reading all of h -- 4H x H x 4 bytes of LDS reads per step: half of the step's 2 050 cycles at H = 128.)
 template <typename T, int H>
 __global__ __launch_bounds__(4 * H) void lstm_reg_kernel(const void* pre, const float* w_hh, void* out, const void* skip,
                                                          int T_len) {
-  __shared__ __attribute__((aligned(16))) float sh[H];
+  constexpr int KS = H / 4;          // k range of a thread
+  constexpr int KP = KS + 4;         // LDS pitch of a segment: the four segments a quad reads at once sit in different banks
+  __shared__ __attribute__((aligned(16))) float sh[4 * KP];
   __shared__ float sg[4 * H];
-  const int b = blockIdx.x, row = threadIdx.x;
-  float w[H];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int rg = tid >> 2, g = tid & 3;
+  float w[4][KS];
 #pragma unroll
-  for (int k = 0; k < H; k += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(w_hh + (size_t)row * H + k);
-    w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
-  }
-  if (row < H) sh[row] = 0.f;
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int k = 0; k < KS; k += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(w_hh + (size_t)(rg * 4 + q) * H + g * KS + k);
+      w[q][k] = v.x; w[q][k + 1] = v.y; w[q][k + 2] = v.z; w[q][k + 3] = v.w;
+    }
+  const int row = tid;               // gate phase: one thread per hidden unit (tid < H); it fetches the unit's four pre-activations a step ahead
+  if (row < H) sh[row + 4 * (row / KS)] = 0.f;
   float c = 0.f;
-  float p_next = sld<T>(pre, ((size_t)b * T_len) * (4 * H) + row);
+  float p_next[4] = {0.f, 0.f, 0.f, 0.f};
+  if (row < H) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) p_next[gq] = sld<T>(pre, ((size_t)b * T_len) * (4 * H) + gq * H + row);
+  }
+  // the skip input of the coming step, fetched a step ahead like the gate pre-activation (loaded inside the step its latency sat on the
+  // recurrence's critical path: the wave waited for it before the h + skip store, in front of the barrier)
+  float sk_next = (skip && row < H) ? sld<T>(skip, ((size_t)b * T_len) * H + row) : 0.f;
   __syncthreads();
   for (int t = 0; t < T_len; ++t) {
-    float g = p_next;
-    if (t + 1 < T_len) p_next = sld<T>(pre, ((size_t)b * T_len + t + 1) * (4 * H) + row);
-    // packed fp32 FMAs (v_pk_fma_f32): the 4H x H mat-vec is VALU-issue-bound, one instruction per two products
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+    const float p_cur[4] = {p_next[0], p_next[1], p_next[2], p_next[3]};
+    const float sk = sk_next;
+    if (t + 1 < T_len && row < H) {
 #pragma unroll
-    for (int k = 0; k < H; k += 4) {
-      const float4 hv = *reinterpret_cast<const float4*>(&sh[k]);
-      const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
-      const f32x2 w01 = {w[k], w[k + 1]}, w23 = {w[k + 2], w[k + 3]};
-      a01 = __builtin_elementwise_fma(w01, h01, a01);
-      a23 = __builtin_elementwise_fma(w23, h23, a23);
+      for (int gq = 0; gq < 4; ++gq) p_next[gq] = sld<T>(pre, ((size_t)b * T_len + t + 1) * (4 * H) + gq * H + row);
+      if (skip) sk_next = sld<T>(skip, ((size_t)b * T_len + t + 1) * H + row);
     }
-    g += (a01[0] + a01[1]) + (a23[0] + a23[1]);
-    sg[row] = g;
+    // packed fp32 FMAs (v_pk_fma_f32): the mat-vec is VALU-issue-bound, one instruction per two products
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 a01[4], a23[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a01[q] = f32x2{0.f, 0.f}; a23[q] = f32x2{0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < KS; k += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(&sh[g * KP + k]);
+      const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 w01 = {w[q][k], w[q][k + 1]}, w23 = {w[q][k + 2], w[q][k + 3]};
+        a01[q] = __builtin_elementwise_fma(w01, h01, a01[q]);
+        a23[q] = __builtin_elementwise_fma(w23, h23, a23[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = (a01[q][0] + a01[q][1]) + (a23[q][0] + a23[q][1]);
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1, 0, 3, 2]
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2, 3, 0, 1]
+      if (g == q) sg[rg * 4 + q] = v;       // (every lane of the quad holds the sum: lane q stores row q)
+    }
     __syncthreads();
     if (row < H) {
-      const float ig = sigmoid_acc(sg[row]), fg = sigmoid_acc(sg[H + row]);
-      const float gg = tanhf(sg[2 * H + row]), og = sigmoid_acc(sg[3 * H + row]);
+      // v_exp_f32 / v_rcp_f32 forms (absolute error < 2e-7, ldc_math.h): the gate arithmetic of H threads is the serial part of a
+      // step, libm's expf / tanhf were ~40 % of it.  (This kernel serves the H <= 128 LSTMs of the main codec, which feed no RVQ:
+      // the cond codec's H = 512 kernels keep the libm forms so that no code index can move.)
+      const float ig = fast_sigmoid(sg[row] + p_cur[0]), fg = fast_sigmoid(sg[H + row] + p_cur[1]);
+      const float gg = fast_tanh(sg[2 * H + row] + p_cur[2]), og = fast_sigmoid(sg[3 * H + row] + p_cur[3]);
       c = fg * c + ig * gg;
-      const float h = og * tanhf(c);
-      sh[row] = h;
+      const float h = og * fast_tanh(c);
+      sh[row + 4 * (row / KS)] = h;
       const size_t o = ((size_t)b * T_len + t) * H + row;
-      sst<T>(out, o, skip ? h + sld<T>(skip, o) : h);
+      sst<T>(out, o, h + sk);
     }
     __syncthreads();
   }
