@@ -111,7 +111,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
 
   const int nchunks = (a.C1 + a.C2) / BKE;
   const int khalf = (lane >> 5) * 16;
-  for (int c = 0; c < nchunks; ++c) {
+  int c_lo = 0, c_hi = nchunks;
+  if (a.ksplit > 1) {   // split-K slice blockIdx.z of the channel chunks (generic_splitk below)
+    const int per = (nchunks + a.ksplit - 1) / a.ksplit;
+    c_lo = min(nchunks, (int)blockIdx.z * per);
+    c_hi = min(nchunks, c_lo + per);
+  }
+  for (int c = c_lo; c < c_hi; ++c) {
     const char* src;
     int ld, coff;
     if (c * BKE < a.C1) {
@@ -204,6 +210,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
 
   const int mrow0 = m0 + wm * TM * 32 + 4 * (lane >> 5);
   const int col0 = n0 + wn * TN * 32 + (lane & 31);
+  if (a.ksplit > 1) {   // raw fp32 partial sums [slice][M][n_pad]; conv_splitk_reduce_kernel adds them in slice order and runs the epilogue
+    float* part = a.sk_part + (size_t)blockIdx.z * M * a.n_pad;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (m < M) part[(size_t)m * a.n_pad + col0 + j * 32] = acc[i][j][r];
+        }
+    return;
+  }
   if (!a.tr_stride) {
     epilogue_dispatch<T, TM, TN>(a, acc, mrow0, col0, M, m0, BM);
     return;
@@ -228,6 +247,43 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvKArgs 
         const float v = act_apply(acc[i][j][r] + bv, a.post_act);
         store_out<T>(a.y, ((size_t)b * a.L_final + pos) * a.y_ld + tr_co, v);
       }
+    }
+  }
+}
+
+// Split-K of the generic kernel (few-tile, long-K layers: the SEANet stacks' last strided convs, k=7 bottleneck convs and first
+// transposed convs put 4..64 workgroups on the chip and walk 32..256 channel chunks each, one exposed load latency per chunk):
+// the slices' partial sums are added in slice order (deterministic), then bias (+ residual) (+ activation) / the transposed
+// conv's scatter exactly as the unsplit epilogues above do
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKArgs a, int M) {
+  const int n4 = a.n_pad >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * n4) return;
+  const int m = (int)(idx / n4), c4 = (int)(idx - (long)m * n4) * 4;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < a.ksplit; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(a.sk_part + ((size_t)z * M + m) * a.n_pad + c4);
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+  int b = 0, q = 0;
+  if (a.tr_stride) {
+    b = (int)fdiv((unsigned)m, a.lrows_div);
+    q = m - b * a.L_rows;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int col = c4 + e;
+    if (col >= a.n) continue;
+    float v = sv[e] + (a.bias ? a.bias[col] : 0.0f);
+    if (!a.tr_stride) {
+      if (a.residual) v += load_in<T>(a.residual, (size_t)m * a.n + col);
+      store_out<T>(a.y, (size_t)m * a.y_ld + col, act_apply(v, a.post_act));
+    } else {
+      const int tr_p = col / a.tr_cout, tr_co = col - tr_p * a.tr_cout;
+      const int pos = q * a.tr_stride + tr_p - a.tr_trim_left;
+      if (pos >= 0 && pos < a.L_final) store_out<T>(a.y, ((size_t)b * a.L_final + pos) * a.y_ld + tr_co, act_apply(v, a.post_act));
     }
   }
 }
@@ -370,7 +426,7 @@ void pack_convtr_weights(const ConvLayer& ly, const float* w, int cin, int cout,
 template <typename T, int WM, int WN, int TM, int TN>
 static hipError_t launch_cfg(const ConvKArgs& a, int M, size_t lds, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  dim3 grid((M + BM - 1) / BM, a.n_pad / BN);
+  dim3 grid((M + BM - 1) / BM, a.n_pad / BN, std::max(1, a.ksplit));
   auto kern = conv_gemm_kernel<T, WM, WN, TM, TN>;
   static bool lds_opt_in = false;   // one-off, outside any stream capture (launch_conv is first called eagerly)
   if (!lds_opt_in) {
@@ -440,6 +496,30 @@ static hipError_t conv_kargs(const ConvLayer& ly, const ConvCall& c, ConvKArgs& 
   return hipSuccess;
 }
 
+// split-K factor of the generic kernel for this call (1: none): only where the caller opted in (ConvCall::generic_split with a
+// workspace), for the 64 x 64-tile launches that leave most of the chip idle and have at least 8 channel chunks to share out
+static int generic_splitk(const ConvLayer& ly, const ConvCall& c, int M) {
+  if (!c.generic_split || !c.sk_part || ly.w8 || ly.dt == DT_FP8 || c.gn_sum || c.colmax || (ly.n_pad & 63)) return 1;
+  const int bke = kRowBytes / (int)dt_size(ly.dt);
+  const int nchunks = (ly.cin1 + ly.cin2) / bke;
+  const long tiles = (long)((M + 63) / 64) * (ly.n_pad / 64);
+  if (tiles >= 128 || nchunks < 8) return 1;
+  long ks = std::min<long>(nchunks / 2, (256 + tiles - 1) / tiles);
+  ks = std::min<long>(ks, c.sk_part_cap / std::max<long>(1, (long)M * ly.n_pad));
+  return ks >= 2 ? (int)ks : 1;
+}
+
+long long conv_generic_splitk_floats(const ConvLayer& ly, const ConvCall& c) {
+  if ((c.tune && c.tune->force_generic ? false : conv_fast_eligible(ly))) return 0;
+  ConvCall cc = c;
+  cc.generic_split = 1; cc.sk_part = reinterpret_cast<float*>(16); cc.sk_part_cap = 1ll << 50;
+  const int M = c.B * c.L_rows;
+  const int bn = ly.bn;
+  if (M <= 0 || (long)((M + 127) / 128) * (ly.n_pad / bn) >= 128 || ly.n_pad % 64 != 0 || bn < 64) return 0;
+  const int ks = generic_splitk(ly, cc, M);
+  return ks > 1 ? (long long)ks * M * ly.n_pad : 0;
+}
+
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   ConvKArgs a;
   int M = 0, span = 0;
@@ -458,12 +538,24 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
   // few-tile GEMMs with a long K (the SEANet encoder's last strided / k=7 convs: 3 840 rows x 3 584..4 096 deep, 30
   // tiles of 128 x 128 took 0.5 ms each on 30 CUs): 64 x 64 tiles put 4x the workgroups on the chip
   const long tiles128 = (long)((M + 127) / 128) * (ly.n_pad / bn);
-  const bool small = !ly.tr_stride && tiles128 < 128 && ly.n_pad % 64 == 0 && bn >= 64;
+  const bool small = tiles128 < 128 && ly.n_pad % 64 == 0 && bn >= 64;
   if (small) bn = 64;
   a.tg = std::max(1, std::min(ly.taps, (40 * 1024) / (bn * kPitch)));
   const size_t lds = (size_t)(a.win_rows + 1) * kPitch + (size_t)a.tg * bn * kPitch;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (small) return ly.dt == DT_F32 ? launch_cfg<float, 2, 2, 1, 1>(a, M, lds, s) : launch_cfg<__bf16, 2, 2, 1, 1>(a, M, lds, s);
+  if (small) {
+    const int ks = generic_splitk(ly, c, M);
+    if (ks > 1) {
+      a.ksplit = ks;
+      hipError_t e = ly.dt == DT_F32 ? launch_cfg<float, 2, 2, 1, 1>(a, M, lds, s) : launch_cfg<__bf16, 2, 2, 1, 1>(a, M, lds, s);
+      if (e != hipSuccess) return e;
+      const long n4 = (long)M * (a.n_pad / 4);
+      if (ly.dt == DT_F32) hipLaunchKernelGGL(conv_splitk_reduce_kernel<float>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a, M);
+      else hipLaunchKernelGGL(conv_splitk_reduce_kernel<__bf16>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a, M);
+      return hipGetLastError();
+    }
+    return ly.dt == DT_F32 ? launch_cfg<float, 2, 2, 1, 1>(a, M, lds, s) : launch_cfg<__bf16, 2, 2, 1, 1>(a, M, lds, s);
+  }
   if (ly.dt == DT_F32) {
     if (bn == 128) return launch_cfg<float, 2, 2, 2, 2>(a, M, lds, s);
     if (bn == 64) return launch_cfg<float, 2, 2, 2, 1>(a, M, lds, s);

@@ -704,6 +704,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
   c->split_ends = getenv("LDC_NO_SPLIT_ENDS") ? 0 : 1;
   c->split_init = getenv("LDC_NO_SPLIT_INIT") ? 0 : 1;
+  c->sea_splitk = getenv("LDC_NO_SEA_SPLITK") ? 0 : 1;
   c->xcd_teams = env_int("LDC_TEAMS", c->xcd_teams);
   c->teams_min_b = std::max(1, env_int("LDC_TEAMS_MINB", c->teams_min_b));
   c->teams_parts = std::max(1, env_int("LDC_TEAMS_PARTS", c->teams_parts));
@@ -842,6 +843,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
   if (n == "lstm_stream") { c->lstm_stream_only = value ? 1 : 0; return LDC_OK; }
   if (n == "lstm_xcd") { c->lstm_xcd = value ? 1 : 0; return LDC_OK; }
   if (n == "split_ends") { c->split_ends = value ? 1 : 0; return LDC_OK; }
+  if (n == "sea_splitk") { c->sea_splitk = value ? 1 : 0; return LDC_OK; }
   if (n == "split_init") {
     if ((value ? 1 : 0) != c->split_init) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->split_init = value ? 1 : 0; }
     return LDC_OK;
@@ -884,7 +886,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | split_init | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | split_init | sea_splitk | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
@@ -1002,6 +1004,14 @@ static int sea_conv(SeaRun& R, const ConvLayer& ly, const void* x, const void* r
   }
   *y = R.ar->alloc((size_t)R.B * (*L_out) * cc.y_ld * 4);
   cc.y = *y;
+  if (R.c->sea_splitk) {   // few-tile long-K layers: split-K partial sums in the run's arena
+    const long long fl = conv_generic_splitk_floats(ly, cc);
+    if (fl > 0) {
+      cc.sk_part = (float*)R.ar->alloc((size_t)fl * 4);
+      cc.sk_part_cap = fl;
+      cc.generic_split = 1;
+    }
+  }
   if (!R.dry) HIPCHK(launch_conv(ly, cc, R.s));
   return LDC_OK;
 }

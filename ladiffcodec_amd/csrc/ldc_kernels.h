@@ -87,6 +87,7 @@ struct ConvCall {
   unsigned* sk_count = nullptr;
   long long sk_part_cap = 0;  // floats
   int sk_count_cap = 0;       // tiles
+  int generic_split = 0;      // the generic kernel may split K through sk_part (conv_generic_splitk_floats floats; no counters: a reduce launch follows)
   // Fused GroupNorm apply in the conv epilogue (pipelined kernel only; needs gn_sum): y = SiLU(GN(conv) * (scale + 1) + shift)
   // (+ residual) (tanh).  gn_part: [B][gn_mslots][WM][n / 32] 16-byte granule pairs the waves exchange their partial statistics
   // through, zeroed before every launch (the step's first kernel does it); see ConvKArgs / epilogue_gn_fused in conv_device.h.
@@ -110,6 +111,7 @@ struct ConvCall {
 };
 
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
+long long conv_generic_splitk_floats(const ConvLayer& ly, const ConvCall& c);   // workspace floats a generic_split call of this shape uses (0: it would not split)
 // Two dependent convs (c1 reads c0.y as its input, optionally c0.y2 as its residual; both with the fused GroupNorm apply) as one
 // launch where the pipelined kernel allows it, else back to back.  pair_done: [pair_done_cap] counters on 64-byte lines (16 words each; one per 64 rows of c0's
 // output at least), zeroed before every launch (the step's first kernel does it).

@@ -133,6 +133,17 @@ def test_codec_round_trip_full_size_c1():
         assert rel(e.decode_latents(L.MODEL_COND, cu(g["quantized"])).cpu().numpy(), g["decoded"]) < 1e-4
     finally:
         e.set_option("lstm_stream", 0)
+    # round 5: the few-tile long-K convs (k16 s8 256 -> 512, k7 512 -> 128, the first transposed convs) split K on the generic
+    # kernel (conv_splitk_reduce_kernel adds the slices in order); the unsplit launches must agree with them and with the reference
+    e.set_option("sea_splitk", 0)
+    try:
+        z0 = e.encode(L.MODEL_COND, wav)
+        dec0 = e.decode_latents(L.MODEL_COND, cu(g["quantized"]))
+        assert rel(z0.cpu().numpy(), g["z"]) < 1e-4 and rel(dec0.cpu().numpy(), g["decoded"]) < 1e-4
+        assert not torch.equal(z0, z), "split-K did not engage (or the option is ignored)"
+        assert rel(z0.cpu().numpy(), z.cpu().numpy()) < 1e-5 and rel(dec0.cpu().numpy(), dec.cpu().numpy()) < 1e-5
+    finally:
+        e.set_option("sea_splitk", 1)
 
 
 def test_rvq_ties_take_first_index():
