@@ -844,6 +844,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
   if (n == "lstm_xcd") { c->lstm_xcd = value ? 1 : 0; return LDC_OK; }
   if (n == "split_ends") { c->split_ends = value ? 1 : 0; return LDC_OK; }
   if (n == "sea_splitk") { c->sea_splitk = value ? 1 : 0; return LDC_OK; }
+  if (n == "rvq_tiled") { c->rvq_tiled = value ? 1 : 0; return LDC_OK; }
   if (n == "split_init") {
     if ((value ? 1 : 0) != c->split_init) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->split_init = value ? 1 : 0; }
     return LDC_OK;
@@ -886,7 +887,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | split_init | sea_splitk | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | split_init | sea_splitk | rvq_tiled | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
@@ -1138,7 +1139,7 @@ static int rvq_rows(ldc_ctx* c, const float* z_rows, int rows, int n_q, int64_t*
   const Codec& cd = c->codec[LDC_MODEL_COND];
   int64_t* cw = codes;
   if (!cw) cw = (int64_t*)ar.alloc((size_t)n_q * rows * sizeof(int64_t));
-  if (!dry) HIPCHK(launch_rvq(z_rows, rows, c->cfg.rep_dims, cd.codebooks, cd.cb_sqnorm, cd.bins, n_q, cw, q_rows, s));
+  if (!dry) HIPCHK(launch_rvq(z_rows, rows, c->cfg.rep_dims, cd.codebooks, cd.cb_sqnorm, cd.bins, n_q, cw, q_rows, s, c->rvq_tiled));
   return LDC_OK;
 }
 

@@ -281,6 +281,7 @@ struct ldc_ctx {
   hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int split_batch = 2;
+  int rvq_tiled = 1;            // RVQ search on the LDS-tiled kernel (option "rvq_tiled"; 0: the round-1 kernel, same codes)
   int sea_splitk = 1;           // SEANet few-tile long-K convs split K on the generic kernel (LDC_NO_SEA_SPLITK / option "sea_splitk")
   int split_init = 1;           // init_conv's condition half hoisted out of the denoise loop (LDC_NO_SPLIT_INIT / option "split_init")
   int split_ends = 1;           // ldc_decode: the codec front / back ends per batch part on the parts' streams too (per-utterance normalisation only)

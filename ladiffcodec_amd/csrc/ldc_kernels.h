@@ -271,7 +271,7 @@ hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* ou
 // z_cl [B*F][D] fp32 rows; codebooks [n_q][bins][D] fp32 and their squared norms [n_q][bins].
 // codes [n_q][B*F] int64 (nullable), quantized_cl [B*F][D] fp32.
 hipError_t launch_rvq(const float* z_rows, int rows, int D, const float* codebooks, const float* cb_sqnorm, int bins,
-                      int n_q, int64_t* codes, float* quantized_rows, hipStream_t s);
+                      int n_q, int64_t* codes, float* quantized_rows, hipStream_t s, int variant = 1);   // variant 0: the round-1 kernel (same codes, bit for bit)
 hipError_t launch_rvq_decode(const int64_t* codes, int rows, int D, const float* codebooks, int bins, int n_q,
                              float* quantized_rows, hipStream_t s);
 hipError_t launch_sqnorm_rows(const float* x, int rows, int D, float* out, hipStream_t s);

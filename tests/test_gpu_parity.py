@@ -156,6 +156,27 @@ def test_rvq_ties_take_first_index():
     assert codes.cpu().numpy().reshape(-1).tolist() == [5, 900, 17]
 
 
+@pytest.mark.parametrize("Bn,Fn,n_q", [(1, 120, 6), (3, 121, 5), (16, 120, 6), (2, 7, 3)])
+def test_rvq_tiled_kernel_equals_the_round1_kernel_bit_for_bit(Bn, Fn, n_q):
+    """Round 5: the LDS-tiled search (rvq_tiled_kernel: lane = code, the rows' residual as v_readlane scalars; one or two rows per
+    wave by row count) keeps the arithmetic of the round-1 kernel per (row, code) -- same FMA chain, same distance expression, first
+    maximum -- so codes AND quantised rows are identical, ragged row counts included; and both follow the oracle where its margin
+    between the best two codes is not a rounding matter (core_vq.py:174-189, 324-342)."""
+    e = engine("r84", "f32")
+    gen = torch.Generator().manual_seed(100 + Bn * Fn)
+    z = torch.randn(Bn, 128, Fn, generator=gen) * 0.7
+    q1, c1 = e.rvq(z.cuda(), n_q)
+    e.set_option("rvq_tiled", 0)
+    try:
+        q0, c0 = e.rvq(z.cuda(), n_q)
+    finally:
+        e.set_option("rvq_tiled", 1)
+    assert torch.equal(c0, c1) and torch.equal(q0, q1)
+    qo, co, margins = O.rvq_forward(synth.to_torch(cond_sd_np()), z, n_q)
+    safe = np.logical_and.accumulate(margins.numpy() > 1e-3, axis=0)     # (a code picked differently changes every later stage of its row)
+    assert safe.mean() > 0.9 and np.array_equal(c1.cpu().numpy()[safe], co.numpy()[safe])
+
+
 # ------------------------------------------------------------------------------------------- UNet / diffusion
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("tag", ["r84", "r8"])
