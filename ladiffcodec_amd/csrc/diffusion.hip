@@ -334,24 +334,45 @@ __global__ void step_set_kernel(int* st, int t, int j, unsigned key_lo, unsigned
   st[2] = (int)key_lo;
   st[3] = (int)key_hi;
 }
-// Also clears the step's accumulator region (GroupNorm sums, split-K counters, k-max keys: until round 3 a memset node of its own
-// in front of every step): zero_n16 16-byte pieces starting at `zero`.
-// st[4]: epoch of the UNet pass, counted up here: the XCD-team chains tag their tile flags with it (never cleared, never 0)
-__global__ __launch_bounds__(256) void step_begin_kernel(const float* table, int stride, int* st, float* cur,
-                                                         unsigned long long* tl, uint4* zero, long long zero_n16) {
-  if (tl && blockIdx.x == 0 && threadIdx.x == 0) tl[2 * (st[1] & 2047)] = wall_clock64();
-  if (blockIdx.x == 0 && threadIdx.x == 0) st[4] = st[4] + 1;
-  const float* row = table + (size_t)st[0] * stride;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < stride; i += gridDim.x * 256) cur[i] = row[i];
+// First kernel of a denoise step.  Workgroup 0 owns the part's step state: with `advance` it first moves on from the previous step
+// (t - 1, iteration + 1: until round 5 a one-thread launch of its own behind p_sample_update; the timeline's end stamp of that step
+// is taken here), counts the UNet-pass epoch up (st[4]: the XCD-team chains tag their tile flags with it, never cleared, never 0)
+// and copies the timestep's (scale | shift) row; every other workgroup clears the step's accumulator region (GroupNorm sums,
+// split-K counters, k-max keys: until round 3 a memset node of its own): zero_n16 16-byte pieces starting at `zero`.
+__global__ __launch_bounds__(1024) void step_begin_kernel(const float* table, int stride, int* st, float* cur,
+                                                          unsigned long long* tl, uint4* zero, long long zero_n16, int advance) {
+  const int nthr = blockDim.x;
+  if (blockIdx.x == 0) {
+    __shared__ int sh_t;
+    if (threadIdx.x == 0) {
+      int t = st[0], j = st[1];
+      const unsigned long long now = tl ? wall_clock64() : 0ull;
+      if (advance) {
+        if (tl && j >= 0) tl[2 * (j & 2047) + 1] = now;
+        t -= 1;
+        j += 1;
+        st[0] = t;
+        st[1] = j;
+      }
+      if (tl) tl[2 * (j & 2047)] = now;
+      st[4] = st[4] + 1;
+      sh_t = t;
+    }
+    __syncthreads();
+    const float* row = table + (size_t)max(sh_t, 0) * stride;
+    for (int i = threadIdx.x; i < stride; i += nthr) cur[i] = row[i];
+    if (gridDim.x > 1) return;
+  }
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n16; i += (long long)gridDim.x * 256) zero[i] = z;
+  const long long nb = gridDim.x > 1 ? gridDim.x - 1 : 1, bi = gridDim.x > 1 ? blockIdx.x - 1 : 0;
+  for (long long i = bi * nthr + threadIdx.x; i < zero_n16; i += nb * nthr) zero[i] = z;
 }
 hipError_t launch_step_begin(const float* table, int stride, int* st, float* cur, unsigned long long* tl, hipStream_t s,
-                             void* zero, size_t zero_bytes) {
+                             void* zero, size_t zero_bytes, int advance) {
   const long long n16 = (long long)((zero_bytes + 15) / 16);
-  const long long want = std::max<long long>((stride + 255) / 256, (n16 + 1023) / 1024);
-  hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(256, want))), dim3(256), 0, s, table, stride, st, cur, tl,
-                     reinterpret_cast<uint4*>(zero), n16);
+  const long long want = n16 > 0 ? 1 + (n16 + 4095) / 4096 : 1;
+  hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)std::min<long long>(256, want)), dim3(1024), 0, s, table, stride, st, cur, tl,
+                     reinterpret_cast<uint4*>(zero), n16, advance);
   return hipGetLastError();
 }
 hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s) {

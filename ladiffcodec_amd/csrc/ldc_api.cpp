@@ -705,6 +705,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->split_ends = getenv("LDC_NO_SPLIT_ENDS") ? 0 : 1;
   c->split_init = getenv("LDC_NO_SPLIT_INIT") ? 0 : 1;
   c->sea_splitk = getenv("LDC_NO_SEA_SPLITK") ? 0 : 1;
+  c->merge_advance = getenv("LDC_STEP_ADVANCE_LAUNCH") ? 0 : 1;
   c->xcd_teams = env_int("LDC_TEAMS", c->xcd_teams);
   c->teams_min_b = std::max(1, env_int("LDC_TEAMS_MINB", c->teams_min_b));
   c->teams_parts = std::max(1, env_int("LDC_TEAMS_PARTS", c->teams_parts));
@@ -2167,11 +2168,18 @@ static int half_step(ldc_ctx* c, const Halves& h, int k, float* x, const float* 
   Plan* pl = h.p[k];
   const size_t off = (size_t)h.b0[k] * c->unet.channels * pl->L;
   unsigned long long* tl = c->timeline ? c->tl_buf + (size_t)k * 2048 * 2 : nullptr;
-  HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, tl, s, pl->zero_ptr, pl->zero_bytes));
+  // (the step state moves on in the step's FIRST kernel: the callers start a loop from (t + 1, iteration - 1), set_steps)
+  HIPCHK(launch_step_begin(c->unet.ss_table, c->unet.ss_stride, pl->step_state, pl->cur_ss, tl, s, pl->zero_ptr, pl->zero_bytes, c->merge_advance));
   LDCCHK(run_ops(c, pl, pl->step_ops, true, s));
   HIPCHK(launch_p_sample_update(c->dt, x + off, pl->eps_cl, noise ? noise + off : nullptr, noise_stride, pl->x_cl, pl->B,
                                 c->unet.channels, pl->L, c->sched, pl->step_state, (uint64_t)off, s));
-  HIPCHK(launch_step_advance(pl->step_state, tl, s));
+  if (!c->merge_advance) HIPCHK(launch_step_advance(pl->step_state, tl, s));   // (LDC_STEP_ADVANCE_LAUNCH: the round-4 structure, for A/B runs)
+  return LDC_OK;
+}
+// timeline runs: the end stamp of a loop's last step (every other step's is taken by the next step's first kernel)
+static int stamp_loop_end(ldc_ctx* c, const Halves& h, int k, hipStream_t s) {
+  if (!c->timeline || !c->merge_advance) return LDC_OK;
+  HIPCHK(launch_step_advance(h.p[k]->step_state, c->tl_buf + (size_t)k * 2048 * 2, s));
   return LDC_OK;
 }
 
@@ -2191,8 +2199,9 @@ static int join_parts(ldc_ctx* c, const Halves& h, hipStream_t s) {
   }
   return LDC_OK;
 }
+// the state BEFORE the first step of a loop that starts at timestep t, iteration j (half_step's first kernel advances)
 static int set_steps(ldc_ctx* c, const Halves& h, int t, int j, hipStream_t s) {
-  for (int k = 0; k < h.n; ++k) HIPCHK(launch_step_set(h.p[k]->step_state, t, j, c->cur_key, s));
+  for (int k = 0; k < h.n; ++k) HIPCHK(launch_step_set(h.p[k]->step_state, t + c->merge_advance, j - c->merge_advance, c->cur_key, s));
   return LDC_OK;
 }
 
@@ -2232,6 +2241,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   LDCCHK(set_steps(c, h, n_steps - 1, 0, s));
   if (c->profile || c->serial_parts || n_steps < 3) {
     for (int i = 0; i < n_steps; ++i) LDCCHK(one_step(c, h, x, noise, stride, s));
+    for (int k = 0; k < h.n; ++k) LDCCHK(stamp_loop_end(c, h, k, s));
     return LDC_OK;
   }
   StepGraph* sg = nullptr;
@@ -2390,12 +2400,15 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
         err = hipEventRecord(ev, sk);
         if (err != hipSuccess) what = "hipEventRecord";
       }
+    for (int k = 0; k < h.n && err == hipSuccess; ++k)
+      if (stamp_loop_end(c, h, k, k == 0 ? s : c->aux_stream[k]) != LDC_OK) { err = hipErrorUnknown; what = "the loop-end stamp"; }
     const int jr = join_parts(c, h, s);
     if (err != hipSuccess) return fail(LDC_E_HIP, "%s failed in the per-part graph replay: %s", what, hipGetErrorString(err));
     return jr;
   }
   for (; i + K <= n_steps; i += K) LDCCHK(replay(sg->exec[0]));
   for (; i < n_steps; ++i) LDCCHK(replay(sg->exec[K == 1 ? 0 : 1]));
+  for (int k = 0; k < h.n; ++k) LDCCHK(stamp_loop_end(c, h, k, s));
   return LDC_OK;
 }
 

@@ -281,6 +281,7 @@ struct ldc_ctx {
   hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
   int split_batch = 2;
+  int merge_advance = 1;        // the step state advances in the step's first kernel (0, LDC_STEP_ADVANCE_LAUNCH: a launch of its own behind p_sample_update)
   int rvq_tiled = 1;            // RVQ search on the LDS-tiled kernel (option "rvq_tiled"; 0: the round-1 kernel, same codes)
   int sea_splitk = 1;           // SEANet few-tile long-K convs split K on the generic kernel (LDC_NO_SEA_SPLITK / option "sea_splitk")
   int split_init = 1;           // init_conv's condition half hoisted out of the denoise loop (LDC_NO_SPLIT_INIT / option "split_init")

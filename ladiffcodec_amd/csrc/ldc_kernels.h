@@ -230,12 +230,13 @@ hipError_t launch_resample(const float* wav, int C, int64_t T, const float* bank
                            hipStream_t s);
 hipError_t launch_scale_copy(int dt, const void* x, void* y, int B, int64_t n_per_item, const float* maxabs, float eps,
                              hipStream_t s);
-hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s);      // t -= 1, j += 1 (tl: timeline slot or null)
+hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s);      // t -= 1, j += 1 (tl: timeline slot or null); behind the LAST step of a loop only (launch_step_begin advances)
 // cur[0..stride) = table[st[0]][0..stride): the current timestep's scale/shift row, so that consumers need no
 // dependent load through the step counter
 // also zeroes [zero, zero + zero_bytes) (rounded up to 16 bytes: the caller pads the region): the step's accumulators
+// advance = 1: first move the step state on from the previous step (t - 1, iteration + 1), i.e. a loop starts from (t + 1, -1)
 hipError_t launch_step_begin(const float* table, int stride, int* st, float* cur, unsigned long long* tl, hipStream_t s,
-                             void* zero = nullptr, size_t zero_bytes = 0);
+                             void* zero = nullptr, size_t zero_bytes = 0, int advance = 0);
 hipError_t launch_step_set(int* st, int t, int j, uint64_t noise_key, hipStream_t s);
 // output normalisation (sample.py:133-134); ws: double [B][2] + float [B] zeroed by the launcher
 hipError_t launch_output_normalise(float* x, int B, int64_t n_per_item, int per_item, void* ws, hipStream_t s);
