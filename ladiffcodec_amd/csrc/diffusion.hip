@@ -341,11 +341,12 @@ __global__ void step_set_kernel(int* st, int t, int j, unsigned key_lo, unsigned
 // split-K counters, k-max keys: until round 3 a memset node of its own): zero_n16 16-byte pieces starting at `zero`.
 __global__ __launch_bounds__(1024) void step_begin_kernel(const float* table, int stride, int* st, float* cur,
                                                           unsigned long long* tl, uint4* zero, long long zero_n16, int advance) {
-  const int nthr = blockDim.x;
+  constexpr int nthr = 1024;
   if (blockIdx.x == 0) {
     __shared__ int sh_t;
     if (threadIdx.x == 0) {
       int t = st[0], j = st[1];
+      const int epoch = st[4];
       const unsigned long long now = tl ? wall_clock64() : 0ull;
       if (advance) {
         if (tl && j >= 0) tl[2 * (j & 2047) + 1] = now;
@@ -355,12 +356,29 @@ __global__ __launch_bounds__(1024) void step_begin_kernel(const float* table, in
         st[1] = j;
       }
       if (tl) tl[2 * (j & 2047)] = now;
-      st[4] = st[4] + 1;
+      st[4] = epoch + 1;
       sh_t = t;
     }
     __syncthreads();
     const float* row = table + (size_t)max(sh_t, 0) * stride;
-    for (int i = threadIdx.x; i < stride; i += nthr) cur[i] = row[i];
+    const int n4 = stride >> 2;
+    if ((stride & 3) == 0 && n4 <= 8 * nthr) {   // eight 16-byte loads in flight per thread: one memory latency for a 100 KB row, not one per element
+      const float4* r4 = reinterpret_cast<const float4*>(row);
+      float4* c4 = reinterpret_cast<float4*>(cur);
+      const int i0 = threadIdx.x;
+      const float4 v0 = r4[min(i0, n4 - 1)], v1 = r4[min(i0 + nthr, n4 - 1)], v2 = r4[min(i0 + 2 * nthr, n4 - 1)], v3 = r4[min(i0 + 3 * nthr, n4 - 1)];
+      const float4 v4 = r4[min(i0 + 4 * nthr, n4 - 1)], v5 = r4[min(i0 + 5 * nthr, n4 - 1)], v6 = r4[min(i0 + 6 * nthr, n4 - 1)], v7 = r4[min(i0 + 7 * nthr, n4 - 1)];
+      if (i0 < n4) c4[i0] = v0;
+      if (i0 + nthr < n4) c4[i0 + nthr] = v1;
+      if (i0 + 2 * nthr < n4) c4[i0 + 2 * nthr] = v2;
+      if (i0 + 3 * nthr < n4) c4[i0 + 3 * nthr] = v3;
+      if (i0 + 4 * nthr < n4) c4[i0 + 4 * nthr] = v4;
+      if (i0 + 5 * nthr < n4) c4[i0 + 5 * nthr] = v5;
+      if (i0 + 6 * nthr < n4) c4[i0 + 6 * nthr] = v6;
+      if (i0 + 7 * nthr < n4) c4[i0 + 7 * nthr] = v7;
+    } else {
+      for (int i = threadIdx.x; i < stride; i += nthr) cur[i] = row[i];
+    }
     if (gridDim.x > 1) return;
   }
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session of round 5.  Everything lands in gpurun_out/r05/; the summaries to be judged are copied into profiles/.
-#   bash tools/run_r05.sh [probe|counters|test|benchq|bench|prof|timed|pmc|configs|final] ...
+#   bash tools/run_r05.sh [probe|counters|test|benchq|bench|prof|timed|pmc|configs|c1prof|final] ...
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r05; mkdir -p $O
 cd $R
@@ -64,6 +64,16 @@ for f in sorted(glob.glob("$O/bench_*.json")):
         print(f, "unreadable", e)
 PY
   ;;
+c1prof)   # kernel trace of the configs[0] round trip + dispatch listings of the codec ends
+  rm -rf $O/prof_c1 $O/ends16 $O/ends_c1
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -- python $R/bench.py --config c1 --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_c1.log 2>&1)
+  python tools/prof_summary.py $(find $O/prof_c1 -name "*.db" | head -1) > $O/c1_kernel_stats.md
+  find $O/prof_c1 -name "*.db" -size +30M -delete
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ends16 -- python $R/tools/codec_ends.py 16 > $O/ends16.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/ends_c1 -- python $R/tools/codec_ends.py 1 c1 > $O/ends_c1.log 2>&1)
+  python tools/codec_ends.py --summarise $O/ends16 > $O/codec_ends_b16.md
+  python tools/codec_ends.py --summarise $O/ends_c1 > $O/codec_ends_c1.md
+  head -12 $O/c1_kernel_stats.md; tail -1 $O/codec_ends_b16.md; tail -1 $O/codec_ends_c1.md ;;
 final)   # PMC traffic first (bench.py reports it while the kernel-source hash matches), then the c2 line of record
   bash $0 pmc
   cp $O/conv_traffic.json profiles/r05_conv_traffic.json
