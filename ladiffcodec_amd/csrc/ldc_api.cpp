@@ -683,6 +683,8 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->dt = cfg->compute_dtype == LDC_F32 ? DT_F32 : DT_BF16;
   c->w8 = cfg->compute_dtype == LDC_BF16_W8;
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  for (int k = 0; k < kMaxParts; ++k)
+    for (int e = 0; e <= ldc_ctx::kLstmChunks; ++e) HIPCHK(hipEventCreateWithFlags(&c->lstm_ev[k][e], hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   for (auto& e : c->flow_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (int k = 1; k < kMaxParts; ++k) {
@@ -706,6 +708,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->split_init = getenv("LDC_NO_SPLIT_INIT") ? 0 : 1;
   c->sea_splitk = getenv("LDC_NO_SEA_SPLITK") ? 0 : 1;
   c->merge_advance = getenv("LDC_STEP_ADVANCE_LAUNCH") ? 0 : 1;
+  c->lstm_pipe = env_int("LDC_LSTM_PIPE", c->lstm_pipe);
   c->xcd_teams = env_int("LDC_TEAMS", c->xcd_teams);
   c->teams_min_b = std::max(1, env_int("LDC_TEAMS_MINB", c->teams_min_b));
   c->teams_parts = std::max(1, env_int("LDC_TEAMS_PARTS", c->teams_parts));
@@ -799,6 +802,10 @@ extern "C" int ldc_destroy(ldc_ctx* c) {
   if (c->tl_buf) (void)hipFree(c->tl_buf);
   for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (int k = 0; k < kMaxParts; ++k) {
+    for (int e = 0; e <= ldc_ctx::kLstmChunks; ++e)
+      if (c->lstm_ev[k][e]) (void)hipEventDestroy(c->lstm_ev[k][e]);
+  }
   for (auto& e : c->flow_ev) if (e) (void)hipEventDestroy(e);
   for (int k = 1; k < kMaxParts; ++k) {
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
@@ -846,6 +853,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
   if (n == "split_ends") { c->split_ends = value ? 1 : 0; return LDC_OK; }
   if (n == "sea_splitk") { c->sea_splitk = value ? 1 : 0; return LDC_OK; }
   if (n == "rvq_tiled") { c->rvq_tiled = value ? 1 : 0; return LDC_OK; }
+  if (n == "lstm_pipe") { c->lstm_pipe = value ? 1 : 0; return LDC_OK; }
   if (n == "split_init") {
     if ((value ? 1 : 0) != c->split_init) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->split_init = value ? 1 : 0; }
     return LDC_OK;
@@ -888,7 +896,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | split_init | sea_splitk | rvq_tiled | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | split_init | sea_splitk | rvq_tiled | lstm_pipe | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
@@ -1050,6 +1058,49 @@ int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in, int L
       case SeaOp::LSTM: {
         const int H = op.cout;
         const void* in = x;
+        // Two-layer register LSTM (the main codec's decoder: 1 200 steps x 2 layers, one workgroup per item) as a TWO-STAGE PIPELINE over
+        // time chunks: layer 0 writes its chunk time-major, the side stream runs layer 1's input GEMM over exactly those rows (contiguous
+        // in that layout) and layer 1's chunk while layer 0 is on its next one; the recurrent state travels through [B][2H] buffers.
+        // 5 chunk times instead of 8 on paper; measured (tools/lstm_pipe_time.py) it does not pay on this runtime -- see ldc_ctx::lstm_pipe -- and is off.
+        const bool pipe = R.c->lstm_pipe && R.side >= 0 && R.side < 2 && R.c->aux_stream[2 + R.side] && op.lstm.size() == 2 && lstm_seq_supported(H) && !op.lstm[0].w_rm && !op.lstm[1].w_rm &&
+                          L >= 64 * ldc_ctx::kLstmChunks;
+        if (pipe) {
+          constexpr int NCH = ldc_ctx::kLstmChunks;
+          void* pre0 = R.ar->alloc((size_t)R.B * L * 4 * H * 4);
+          void* o0 = R.ar->alloc((size_t)R.B * L * H * 4);         // time-major [L][B][H]
+          void* pre1 = R.ar->alloc((size_t)R.B * L * 4 * H * 4);   // time-major [L][B][4H]
+          void* o1 = R.ar->alloc((size_t)R.B * L * H * 4);
+          float* st0 = (float*)R.ar->alloc((size_t)R.B * 2 * H * 4);
+          float* st1 = (float*)R.ar->alloc((size_t)R.B * 2 * H * 4);
+          if (!R.dry) {
+            hipStream_t s2 = R.c->aux_stream[2 + R.side];
+            hipEvent_t* ev = R.c->lstm_ev[R.side];
+            ConvCall cc;
+            cc.B = R.B; cc.L_in = L; cc.L_rows = L; cc.x1 = in; cc.y = pre0; cc.y_ld = 4 * H; cc.tune = &R.c->tune;
+            HIPCHK(launch_conv(op.lstm[0].in_proj, cc, R.s));
+            for (int k = 0; k < NCH; ++k) {
+              const int t0 = (int)((long long)L * k / NCH), t1 = (int)((long long)L * (k + 1) / NCH);
+              LstmSeq q0;
+              q0.t0 = t0; q0.t1 = t1; q0.pre_bs = L; q0.pre_ts = 1; q0.out_bs = 1; q0.out_ts = R.B; q0.state = st0;
+              HIPCHK(launch_lstm_seq(DT_F32, pre0, op.lstm[0].w_hh, o0, nullptr, R.B, H, q0, R.s));
+              HIPCHK(hipEventRecord(ev[k], R.s));
+              HIPCHK(hipStreamWaitEvent(s2, ev[k], 0));
+              ConvCall c1;
+              c1.B = 1; c1.L_in = (t1 - t0) * R.B; c1.L_rows = c1.L_in; c1.tune = &R.c->tune; c1.y_ld = 4 * H;
+              c1.x1 = (const char*)o0 + (size_t)t0 * R.B * H * 4;
+              c1.y = (char*)pre1 + (size_t)t0 * R.B * 4 * H * 4;
+              HIPCHK(launch_conv(op.lstm[1].in_proj, c1, s2));
+              LstmSeq q1;
+              q1.t0 = t0; q1.t1 = t1; q1.pre_bs = 1; q1.pre_ts = R.B; q1.out_bs = L; q1.out_ts = 1; q1.skip_bs = L; q1.skip_ts = 1; q1.state = st1;
+              HIPCHK(launch_lstm_seq(DT_F32, pre1, op.lstm[1].w_hh, o1, x, R.B, H, q1, s2));
+            }
+            HIPCHK(hipEventRecord(ev[NCH], s2));
+            HIPCHK(hipStreamWaitEvent(R.s, ev[NCH], 0));
+          }
+          y = o1;
+          C = H;
+          break;
+        }
         for (size_t n = 0; n < op.lstm.size(); ++n) {
           void* pre = R.ar->alloc((size_t)R.B * L * 4 * H * 4);
           void* o = R.ar->alloc((size_t)R.B * L * H * 4);
@@ -1120,6 +1171,7 @@ extern "C" int ldc_seanet_decode(ldc_ctx* c, int which, const float* z, int B, i
   const int D = c->cfg.rep_dims;
   LDCCHK(with_scratch(c, s, [&](Arena& ar, bool dry) -> int {
     SeaRun R{c, &ar, s, dry, B};
+    R.side = 0;
     void* zc = ar.alloc((size_t)B * L * D * 4);
     if (!dry) HIPCHK(launch_to_cl(DT_F32, z, zc, B, D, L, nullptr, 0, 0.f, s));
     void* y = nullptr;
@@ -2279,7 +2331,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   }
   const int K = std::min(k_want, std::max(1, n_steps - 1));
   int done = 0;
-  if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K + ((par && c->part_graphs && h.n == 2) ? 100000 : 0)) {
+  if (!sg->any() || sg->noise != noise || sg->x != x || sg->stream != s || sg->n != h.n * 100 + K + ((par && c->part_graphs && (h.n == 2 || c->part_graphs >= 2)) ? 100000 : 0)) {
     if (sg->any()) {
       // replays of the old executable graphs may still be in flight: drain before destroying (a re-capture is one of
       // the documented places where a call waits for the device)
@@ -2289,7 +2341,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
     // first step eagerly: loads code objects / sets function attributes outside of the capture
     LDCCHK(one_step(c, h, x, noise, stride, s));
     done = 1;
-    const bool per_part = par && c->part_graphs && h.n == 2;   // (three parts on per-part graphs measured 45 % slower than the fork/join graph)
+    const bool per_part = par && c->part_graphs && (h.n == 2 || c->part_graphs >= 2);   // (LDC_PART_GRAPHS=2: also for three / four parts)   // (three parts on per-part graphs measured 45 % slower than the fork/join graph)
     if (per_part) {
       // ONE SINGLE-STREAM graph per batch part, captured and replayed on the part's own stream.  ROCm 7.2 replays a
       // single-stream graph from AQL packets recorded at instantiation (~0.4 ms of host time for 1 500 kernel nodes); a graph
@@ -2583,6 +2635,7 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
       hipStream_t sk = (split_ends && k > 0) ? c->aux_stream[k] : s;
       const int b0 = split_ends ? h.b0[k] : 0, Bk = split_ends ? h.p[k]->B : B;
       SeaRun R{c, &ar, sk, dry, Bk};
+      R.side = h.n <= 2 ? k : -1;   // (aux_stream[2], [3] are free when the batch has at most two parts)
       void* zc = ar.alloc((size_t)Bk * L * D * 4);
       if (!dry) HIPCHK(launch_to_cl(DT_F32, x + (size_t)b0 * D * L, zc, Bk, D, L, nullptr, 0, 0.f, sk));
       void* y = nullptr;

@@ -280,6 +280,13 @@ struct ldc_ctx {
   Halves last_halves;
   hipStream_t aux_stream[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kLstmChunks = 4;
+  // second stage of the decoder LSTM's layer pipeline of batch part k: aux_stream[2 + k] (k < 2: idle whenever a batch has at most two parts).  NOT streams of
+  // their own: HIP maps streams onto 4 hardware queues in creation order, and four more streams in front of aux_stream[1] put the two parts'
+  // chains on ONE queue (measured: 143 -> 231 ms per decode)
+  hipEvent_t lstm_ev[kMaxParts][kLstmChunks + 1] = {};
+  int lstm_pipe = 0;            // two-layer register LSTMs as a two-stage pipeline over time chunks (LDC_LSTM_PIPE / option "lstm_pipe"): parity-tested, measured
+                                // 2.78 vs 2.63 ms per decoder pass of 16 on the default four hardware queues (the side stream shares one), 2.52 vs 2.62 with eight: off
   int split_batch = 2;
   int merge_advance = 1;        // the step state advances in the step's first kernel (0, LDC_STEP_ADVANCE_LAUNCH: a launch of its own behind p_sample_update)
   int rvq_tiled = 1;            // RVQ search on the LDS-tiled kernel (option "rvq_tiled"; 0: the round-1 kernel, same codes)
@@ -435,6 +442,7 @@ struct SeaRun {   // measures or runs a SEANet stack
   hipStream_t s;
   bool dry;
   int B;
+  int side = -1;   // 0 / 1: aux_stream[2 + side] and lstm_ev[side] may carry the second stage of the two-layer LSTM pipeline (run_seanet)
 };
 
 // ldc_api.cpp

@@ -250,6 +250,16 @@ hipError_t launch_conv_cin1(int dt, const float* x, void* y, const float* w, con
                             int k, hipStream_t s);
 // LSTM recurrence over T for one layer.  pre [B][T][4H] dt_pre (input GEMM + both biases), w_hh [4H][H]
 // fp32, out [B][T][H]; if skip != null: out = h + skip (SLSTM skip, lstm.py:25-26).
+// a stretch of time steps of one LSTM layer on the register kernel: rows are item * bs + t * ts (in rows of 4H / H values), the
+// recurrent state [B][2H] (h | c) is read when t0 > 0 and always written
+struct LstmSeq {
+  int t0 = 0, t1 = 0;
+  long long pre_bs = 0, pre_ts = 1, out_bs = 0, out_ts = 1, skip_bs = 0, skip_ts = 1;
+  float* state = nullptr;
+};
+bool lstm_seq_supported(int H);
+hipError_t launch_lstm_seq(int dt, const void* pre, const float* w_hh, void* out, const void* skip, int B, int H, const LstmSeq& q,
+                           hipStream_t s);
 hipError_t launch_lstm_layer(int dt, const void* pre, const float* w_hh, void* out, const void* skip, int B, int T,
                              int H, hipStream_t s);
 // Cooperative weight-stationary variant for H = 256 / 512 (H/4 workgroups exchange h through `ws`); w_rm is the

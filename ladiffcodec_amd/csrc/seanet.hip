@@ -124,9 +124,12 @@ __device__ __forceinline__ float sigmoid_acc(float v) { return 1.0f / (1.0f + ex
 // 4H threads, W_hh in registers, h in LDS.  Thread (row group rg, k segment g) holds four consecutive gate rows x H/4 weights: it reads
 // its QUARTER of h once for four rows and the four segments meet in a two-step DPP reduction.  (Round 1-4: one thread per gate row, every
 // thread reading all of h -- 4H x H x 4 bytes of LDS reads per step: half of the step's 2 050 cycles at H = 128.)
+// q (LstmSeq): the launch covers time steps [t0, t1) of a longer sequence -- the recurrent state (h | c per item) comes from / goes to
+// q.state when the chunk is not the first / always -- and addresses rows as item * bs + t * ts, so that a layer can write its output
+// time-major for the next layer's chunked input GEMM (run_seanet: the two layers of the decoder's LSTM as a two-stage pipeline).
 template <typename T, int H>
 __global__ __launch_bounds__(4 * H) void lstm_reg_kernel(const void* pre, const float* w_hh, void* out, const void* skip,
-                                                         int T_len) {
+                                                         const LstmSeq q) {
   constexpr int KS = H / 4;          // k range of a thread
   constexpr int KP = KS + 4;         // LDS pitch of a segment: the four segments a quad reads at once sit in different banks
   __shared__ __attribute__((aligned(16))) float sh[4 * KP];
@@ -142,24 +145,27 @@ __global__ __launch_bounds__(4 * H) void lstm_reg_kernel(const void* pre, const 
       w[q][k] = v.x; w[q][k + 1] = v.y; w[q][k + 2] = v.z; w[q][k + 3] = v.w;
     }
   const int row = tid;               // gate phase: one thread per hidden unit (tid < H); it fetches the unit's four pre-activations a step ahead
-  if (row < H) sh[row + 4 * (row / KS)] = 0.f;
-  float c = 0.f;
+  const bool resume = q.state && q.t0 > 0;
+  float c = (resume && row < H) ? q.state[(size_t)b * 2 * H + H + row] : 0.f;
+  float h_last = (resume && row < H) ? q.state[(size_t)b * 2 * H + row] : 0.f;
+  if (row < H) sh[row + 4 * (row / KS)] = h_last;
   float p_next[4] = {0.f, 0.f, 0.f, 0.f};
+  const size_t pre0 = (size_t)b * q.pre_bs, out0 = (size_t)b * q.out_bs, skip0 = (size_t)b * q.skip_bs;
   if (row < H) {
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) p_next[gq] = sld<T>(pre, ((size_t)b * T_len) * (4 * H) + gq * H + row);
+    for (int gq = 0; gq < 4; ++gq) p_next[gq] = sld<T>(pre, (pre0 + (size_t)q.t0 * q.pre_ts) * (4 * H) + gq * H + row);
   }
   // the skip input of the coming step, fetched a step ahead like the gate pre-activation (loaded inside the step its latency sat on the
   // recurrence's critical path: the wave waited for it before the h + skip store, in front of the barrier)
-  float sk_next = (skip && row < H) ? sld<T>(skip, ((size_t)b * T_len) * H + row) : 0.f;
+  float sk_next = (skip && row < H) ? sld<T>(skip, (skip0 + (size_t)q.t0 * q.skip_ts) * H + row) : 0.f;
   __syncthreads();
-  for (int t = 0; t < T_len; ++t) {
+  for (int t = q.t0; t < q.t1; ++t) {
     const float p_cur[4] = {p_next[0], p_next[1], p_next[2], p_next[3]};
     const float sk = sk_next;
-    if (t + 1 < T_len && row < H) {
+    if (t + 1 < q.t1 && row < H) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) p_next[gq] = sld<T>(pre, ((size_t)b * T_len + t + 1) * (4 * H) + gq * H + row);
-      if (skip) sk_next = sld<T>(skip, ((size_t)b * T_len + t + 1) * H + row);
+      for (int gq = 0; gq < 4; ++gq) p_next[gq] = sld<T>(pre, (pre0 + (size_t)(t + 1) * q.pre_ts) * (4 * H) + gq * H + row);
+      if (skip) sk_next = sld<T>(skip, (skip0 + (size_t)(t + 1) * q.skip_ts) * H + row);
     }
     // packed fp32 FMAs (v_pk_fma_f32): the mat-vec is VALU-issue-bound, one instruction per two products
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -193,11 +199,16 @@ __global__ __launch_bounds__(4 * H) void lstm_reg_kernel(const void* pre, const 
       const float gg = fast_tanh(sg[2 * H + row] + p_cur[2]), og = fast_sigmoid(sg[3 * H + row] + p_cur[3]);
       c = fg * c + ig * gg;
       const float h = og * fast_tanh(c);
+      h_last = h;
       sh[row + 4 * (row / KS)] = h;
-      const size_t o = ((size_t)b * T_len + t) * H + row;
+      const size_t o = (out0 + (size_t)t * q.out_ts) * H + row;
       sst<T>(out, o, h + sk);
     }
     __syncthreads();
+  }
+  if (q.state && row < H) {
+    q.state[(size_t)b * 2 * H + row] = h_last;
+    q.state[(size_t)b * 2 * H + H + row] = c;
   }
 }
 
@@ -645,15 +656,29 @@ hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* ou
 }
 
 // w_hh points at: [4H][H] row-major for the register variants (H = 64, 128), k-major [H/4][4H][4] otherwise.
+bool lstm_seq_supported(int H) { return H == 64 || H == 128; }
+
+// time steps [q.t0, q.t1) of one layer on the register kernel (H = 64 / 128), rows addressed through q (LstmSeq)
+hipError_t launch_lstm_seq(int dt, const void* pre, const float* w_hh, void* out, const void* skip, int B, int H, const LstmSeq& q,
+                           hipStream_t s) {
+  if (!lstm_seq_supported(H) || q.t1 <= q.t0) return hipErrorInvalidValue;
+  if (H == 64) {
+    if (dt == DT_F32) hipLaunchKernelGGL((lstm_reg_kernel<float, 64>), dim3(B), dim3(256), 0, s, pre, w_hh, out, skip, q);
+    else hipLaunchKernelGGL((lstm_reg_kernel<__bf16, 64>), dim3(B), dim3(256), 0, s, pre, w_hh, out, skip, q);
+  } else {
+    if (dt == DT_F32) hipLaunchKernelGGL((lstm_reg_kernel<float, 128>), dim3(B), dim3(512), 0, s, pre, w_hh, out, skip, q);
+    else hipLaunchKernelGGL((lstm_reg_kernel<__bf16, 128>), dim3(B), dim3(512), 0, s, pre, w_hh, out, skip, q);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_lstm_layer(int dt, const void* pre, const float* w_hh, void* out, const void* skip, int B, int T,
                              int H, hipStream_t s) {
   if (H % 8 || H > 4096) return hipErrorInvalidValue;
-  if (H == 64) {
-    if (dt == DT_F32) hipLaunchKernelGGL((lstm_reg_kernel<float, 64>), dim3(B), dim3(256), 0, s, pre, w_hh, out, skip, T);
-    else hipLaunchKernelGGL((lstm_reg_kernel<__bf16, 64>), dim3(B), dim3(256), 0, s, pre, w_hh, out, skip, T);
-  } else if (H == 128) {
-    if (dt == DT_F32) hipLaunchKernelGGL((lstm_reg_kernel<float, 128>), dim3(B), dim3(512), 0, s, pre, w_hh, out, skip, T);
-    else hipLaunchKernelGGL((lstm_reg_kernel<__bf16, 128>), dim3(B), dim3(512), 0, s, pre, w_hh, out, skip, T);
+  if (H == 64 || H == 128) {
+    LstmSeq q;
+    q.t0 = 0; q.t1 = T; q.pre_bs = q.out_bs = q.skip_bs = T; q.pre_ts = q.out_ts = q.skip_ts = 1; q.state = nullptr;
+    return launch_lstm_seq(dt, pre, w_hh, out, skip, B, H, q, s);
   } else {
     const size_t lds = (size_t)5 * H * sizeof(float);
     if (dt == DT_F32) hipLaunchKernelGGL(lstm_stream_kernel<float>, dim3(B), dim3(1024), lds, s, pre, w_hh, out, skip, T, H);

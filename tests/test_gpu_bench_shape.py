@@ -170,6 +170,14 @@ def test_c8_full_width_unet_and_decoder(dtype):
     wav = e.decode_latents(L.MODEL_MAIN, lat.cuda()).cpu()
     assert wav.shape == (B, 1, Lz * 8)
     assert bg.compare("c8.dec", wav.numpy()) < 1e-4     # the codec runs exact fp32 in both engines
+    # round 5 (opt-in, measured not faster): the decoder's two LSTM layers as a two-stage pipeline over four time chunks on two streams
+    # (state handed on through [B][2H] buffers, layer 0's output time-major); it must give the same audio as one launch per layer
+    e.set_option("lstm_pipe", 1)
+    try:
+        wav1 = e.decode_latents(L.MODEL_MAIN, lat.cuda()).cpu()
+    finally:
+        e.set_option("lstm_pipe", 0)
+    assert bg.compare("c8.dec", wav1.numpy()) < 1e-4 and float((wav1 - wav).abs().max()) < 1e-5 * float(wav.abs().max())
 
 
 # ------------------------------------------------------------------------------------------- C3: 1.5 kbps condition, 200 steps
