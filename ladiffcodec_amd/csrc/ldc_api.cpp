@@ -709,6 +709,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->sea_splitk = getenv("LDC_NO_SEA_SPLITK") ? 0 : 1;
   c->merge_advance = getenv("LDC_STEP_ADVANCE_LAUNCH") ? 0 : 1;
   c->lstm_pipe = env_int("LDC_LSTM_PIPE", c->lstm_pipe);
+  c->ends_join = getenv("LDC_ENDS_JOIN") ? 1 : 0;
   c->xcd_teams = env_int("LDC_TEAMS", c->xcd_teams);
   c->teams_min_b = std::max(1, env_int("LDC_TEAMS_MINB", c->teams_min_b));
   c->teams_parts = std::max(1, env_int("LDC_TEAMS_PARTS", c->teams_parts));
@@ -2287,7 +2288,9 @@ extern "C" int ldc_p_sample(ldc_ctx* c, float* x, int t, const float* cond, cons
 }
 
 // the denoise loop on prepared plans (cond already processed, x_cl already set)
-static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const float* noise, int n_steps, hipStream_t s) {
+// left_forked (optional): the caller continues per part on the parts' streams; the per-part replay path then leaves them un-joined and says so
+static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const float* noise, int n_steps, hipStream_t s, bool* left_forked = nullptr) {
+  if (left_forked) *left_forked = false;
   const int L = h.p[0]->L, F = h.p[0]->F;
   const int64_t stride = (int64_t)B * c->unet.channels * L;
   LDCCHK(set_steps(c, h, n_steps - 1, 0, s));
@@ -2454,6 +2457,10 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
       }
     for (int k = 0; k < h.n && err == hipSuccess; ++k)
       if (stamp_loop_end(c, h, k, k == 0 ? s : c->aux_stream[k]) != LDC_OK) { err = hipErrorUnknown; what = "the loop-end stamp"; }
+    if (err == hipSuccess && left_forked) {   // the caller's per-part work follows on the same streams and joins behind it
+      *left_forked = true;
+      return LDC_OK;
+    }
     const int jr = join_parts(c, h, s);
     if (err != hipSuccess) return fail(LDC_E_HIP, "%s failed in the per-part graph replay: %s", what, hipGetErrorString(err));
     return jr;
@@ -2624,10 +2631,16 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
       }
     }
     if (!dry) {
-      if (split_ends) LDCCHK(join_parts(c, h, s));
+      // The parts stay on their streams from the front end to the back end (no join in front of the loop: it forks the part streams behind
+      // part 0's front end itself; none behind it when the per-part replay path ran): they de-phase by the front ends' serialised pieces
+      // (the cooperative LSTMs), and one part's latency-bound back end then runs under the other's last denoise steps.
+      // (c->ends_join / LDC_ENDS_JOIN: both joins as before, for A/B runs)
+      if (split_ends && c->ends_join) LDCCHK(join_parts(c, h, s));
       next_noise_key(c, noise == nullptr);
-      LDCCHK(denoise_loop(c, h, B, x, noise, n_steps, s));
-      if (split_ends) LDCCHK(fork_parts(c, h, s));
+      bool forked = false;
+      const int dr = denoise_loop(c, h, B, x, noise, n_steps, s, (split_ends && !c->ends_join) ? &forked : nullptr);
+      if (dr != LDC_OK) { if (split_ends && !c->ends_join) (void)join_parts(c, h, s); return dr; }
+      if (split_ends && !forked) LDCCHK(fork_parts(c, h, s));
     }
     // decoder (quirk Q3: no x18 un-scaling on this path, sample.py:131)
     int Lo_all = T;
