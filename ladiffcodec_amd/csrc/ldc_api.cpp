@@ -696,6 +696,10 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_side_fork[k], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_side_join[k], hipEventDisableTiming));
   }
+  if (const char* mp = getenv("LDC_AUX_FROM_SIDE")) {   // diagnostics (hardware-queue mapping): part stream k = side stream digit k of the value ('-' keeps it)
+    for (int k = 1; k < kMaxParts && mp[k - 1]; ++k)
+      if (mp[k - 1] >= '0' && mp[k - 1] < '0' + kMaxParts) std::swap(c->aux_stream[k], c->side_stream[mp[k - 1] - '0']);
+  }
   // res_conv on a side stream (off the conv->norm->conv chain).  Only without the batch split: a fork inside an
   // already forked stream (or cross edges between sibling streams) crashes stream capture on ROCm 7.2, and the
   // two-way batch split is worth more (+9 % vs +3 %).
