@@ -393,6 +393,16 @@ hipError_t launch_step_begin(const float* table, int stride, int* st, float* cur
                      reinterpret_cast<uint4*>(zero), n16, advance);
   return hipGetLastError();
 }
+// one workgroup that holds its CU slot for `us` microseconds of the 100 MHz wall clock (bounded): the stream-overlap calibration of ldc_api.cpp
+__global__ void spin_us_kernel(unsigned us) {
+  const unsigned long long t0 = wall_clock64();
+  int guard = 0;
+  while (wall_clock64() - t0 < (unsigned long long)us * 100ull && guard < (1 << 20)) ++guard;
+}
+hipError_t launch_spin_us(unsigned us, hipStream_t s) {
+  hipLaunchKernelGGL(spin_us_kernel, dim3(1), dim3(64), 0, s, us);
+  return hipGetLastError();
+}
 hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s) {
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, st, tl);
   return hipGetLastError();

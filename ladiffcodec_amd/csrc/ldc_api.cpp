@@ -685,6 +685,9 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   for (int k = 0; k < kMaxParts; ++k)
     for (int e = 0; e <= ldc_ctx::kLstmChunks; ++e) HIPCHK(hipEventCreateWithFlags(&c->lstm_ev[k][e], hipEventDisableTiming));
+  if (const char* ex = getenv("LDC_TEST_EXTRA_STREAMS")) {   // test hook: shift the stream -> hardware-queue mapping the way other libraries' streams would
+    for (int i = 0; i < atoi(ex); ++i) { hipStream_t dummy = nullptr; HIPCHK(hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking)); }
+  }
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   for (auto& e : c->flow_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (int k = 1; k < kMaxParts; ++k) {
@@ -696,6 +699,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_side_fork[k], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_side_join[k], hipEventDisableTiming));
   }
+  c->calib = (getenv("LDC_NO_STREAM_CALIB") || getenv("LDC_AUX_FROM_SIDE")) ? 0 : 1;
   if (const char* mp = getenv("LDC_AUX_FROM_SIDE")) {   // diagnostics (hardware-queue mapping): part stream k = side stream digit k of the value ('-' keeps it)
     for (int k = 1; k < kMaxParts && mp[k - 1]; ++k)
       if (mp[k - 1] >= '0' && mp[k - 1] < '0' + kMaxParts) std::swap(c->aux_stream[k], c->side_stream[mp[k - 1] - '0']);
@@ -2076,6 +2080,53 @@ static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Pl
   return LDC_OK;
 }
 
+// The batch parts run as chains on streams of this context next to the caller's stream s.  HIP serves a process's streams from four
+// hardware queues and two streams that share one run their graphs back to back (measured: 229 instead of 143 ms per decode with part 1 on
+// such a stream; which streams share depends on what else the process created before -- torch's pool, RCCL, other contexts).  So the part
+// streams are CHOSEN, once per caller stream: a candidate is accepted when a 150 us single-workgroup spin on it and on every stream
+// accepted so far takes one spin, not two.  ~2 ms, the first time a batch is decoded in parts on a stream; never inside a capture.
+static int calibrate_part_streams(ldc_ctx* c, hipStream_t s) {
+  if (!c->calib || (c->calibrated && c->calib_stream == s)) return LDC_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return LDC_OK; }
+  std::vector<hipStream_t*> cand;
+  for (int k = 1; k < kMaxParts; ++k) cand.push_back(&c->aux_stream[k]);
+  for (int k = 0; k < kMaxParts; ++k) cand.push_back(&c->side_stream[k]);
+  std::vector<hipStream_t> chosen{s};
+  auto timed = [&](const std::vector<hipStream_t>& set, double* ms) -> int {
+    double best = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {
+      for (hipStream_t q : set) HIPCHK(hipStreamSynchronize(q));
+      const auto t0 = std::chrono::steady_clock::now();
+      for (hipStream_t q : set) HIPCHK(launch_spin_us(150, q));
+      for (hipStream_t q : set) HIPCHK(hipStreamSynchronize(q));
+      best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    *ms = best;
+    return LDC_OK;
+  };
+  double base = 0;
+  LDCCHK(timed(chosen, &base));   // (also loads the kernel)
+  LDCCHK(timed(chosen, &base));
+  std::vector<hipStream_t> good, rest;
+  for (hipStream_t* p : cand) {
+    if ((int)good.size() >= kMaxParts - 1) { rest.push_back(*p); continue; }
+    std::vector<hipStream_t> set = chosen;
+    set.push_back(*p);
+    double ms = 0;
+    LDCCHK(timed(set, &ms));
+    if (ms < base + 0.09) { good.push_back(*p); chosen.push_back(*p); }   // one 0.15 ms spin more = a shared queue
+    else rest.push_back(*p);
+  }
+  if (getenv("LDC_VERBOSE")) fprintf(stderr, "[ldc] part streams: %zu of %zu candidates overlap with the caller's stream and each other (one spin: %.3f ms)\n", good.size(), cand.size(), base);
+  std::vector<hipStream_t> order = good;
+  order.insert(order.end(), rest.begin(), rest.end());
+  for (size_t i = 0; i < cand.size(); ++i) *cand[i] = order[i];
+  c->calib_stream = s;
+  c->calibrated = true;
+  return LDC_OK;
+}
+
 static int get_halves(ldc_ctx* c, int B, int L, int F, hipStream_t s, Halves* h) {
   *h = Halves();
   c->call_tick = c->use_tick;   // plans touched from here on belong to the call being served (not evictable)
@@ -2088,6 +2139,7 @@ static int get_halves(ldc_ctx* c, int B, int L, int F, hipStream_t s, Halves* h)
   // concurrency the two batch parts bought comes from the teams and the items inside a team drifting out of phase instead
   const bool team = c->xcd_teams && c->dt == DT_BF16 && !c->w8 && c->fuse_gn_epi && !c->kstamps && !c->side_streams && B >= c->teams_min_b;
   if (team) h->n = std::max(1, std::min(c->teams_parts, std::min(kMaxParts, B / 8)));   // (LDC_TEAMS_PARTS: experiment -- one persistent chain kernel per batch part, each with its share of the workgroups)
+  if (h->n >= 2) LDCCHK(calibrate_part_streams(c, s));
   for (int k = 0; k < h->n; ++k) {
     const int lo = (int)((long long)B * k / h->n), hi = (int)((long long)B * (k + 1) / h->n);
     h->b0[k] = lo;

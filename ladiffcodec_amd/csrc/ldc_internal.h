@@ -285,6 +285,8 @@ struct ldc_ctx {
   // their own: HIP maps streams onto 4 hardware queues in creation order, and four more streams in front of aux_stream[1] put the two parts'
   // chains on ONE queue (measured: 143 -> 231 ms per decode)
   hipEvent_t lstm_ev[kMaxParts][kLstmChunks + 1] = {};
+  hipStream_t calib_stream = nullptr; bool calibrated = false;   // the caller's stream the part streams were last chosen against (calibrate_part_streams)
+  int calib = 1;                // choose the part streams by measured overlap with the caller's stream (LDC_NO_STREAM_CALIB / LDC_AUX_FROM_SIDE turn it off)
   int ends_join = 0;            // ldc_decode joins the parts between front end, denoise loop and back end (LDC_ENDS_JOIN: the structure before the parts ran through)
   int lstm_pipe = 0;            // two-layer register LSTMs as a two-stage pipeline over time chunks (LDC_LSTM_PIPE / option "lstm_pipe"): parity-tested, measured
                                 // 2.78 vs 2.63 ms per decoder pass of 16 on the default four hardware queues (the side stream shares one), 2.52 vs 2.62 with eight: off

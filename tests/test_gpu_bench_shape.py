@@ -444,3 +444,59 @@ def test_xcd_team_chains_equal_the_separate_launches():
     finally:
         e.set_option("xcd_teams", 0)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------- part streams chosen by measured overlap (round 5)
+def test_part_streams_are_chosen_by_overlap_and_the_decode_does_not_change(monkeypatch):
+    """HIP serves a process's streams from four hardware queues; two batch parts on streams that share one decode in 229 instead of 143 ms
+    (profiles/r05_team_chain_experiments.md).  A context therefore picks its part streams by a measured-overlap calibration the first time
+    a batch is decoded in parts on a caller stream (ldc_api.cpp: calibrate_part_streams).  Here three foreign streams are created in
+    front of the context's own (the case that breaks the uncalibrated order: 223 vs 139 ms at the bench size): the decode must equal the
+    one of a context created normally (the calibration only reorders streams), and the parts must really overlap -- two
+    chains on one queue run back to back and are SLOWER than the whole batch as one chain, two overlapping chains are not."""
+    import time
+    mc = CodecConfig(enc_ratios=(8, 4), quantization=False)
+    u = UnetConfig(dim=256, upsampling_ratios=(5, 2), unet_scale_cond=True)     # (full width: at dim 64 a decode is host-bound and shows nothing)
+    cc = CodecConfig(enc_ratios=(8, 5, 4, 2), quantization=True, bandwidth=3.0)
+    sd = synth.ladiff_state_dict(mc, u, seed=5)
+    sdc = synth.codec_state_dict(cc, seed=6)
+
+    def make():
+        e = Engine(mc, u, cc, dtype="bf16")
+        e.load_state_dict(L.MODEL_MAIN, {k: v for k, v in sd.items() if not k.startswith("diffusion.model.")})
+        e.load_state_dict(L.MODEL_COND, sdc)
+        e.finalize(strict=True)
+        return e
+
+    n_steps = 12
+    wav = torch.from_numpy(synth.synthetic_wav(8, 38400, seed=21)).cuda()
+    noise = torch.randn(n_steps, 8, 128, 38400 // mc.hop_length, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+
+    def run(e, reps=1):
+        out = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = e.decode(wav, n_steps, noise=noise, per_item=True)
+        torch.cuda.synchronize()
+        return out, (time.perf_counter() - t0) / reps
+
+    e0 = make()
+    ref, _ = run(e0)
+    e0.close()
+    # whichever offset the process's other streams (torch's pool, this test session's earlier contexts) have left the round-robin at,
+    # one of 1..4 foreign streams puts an uncalibrated part stream on the caller's queue
+    for extra in (1, 2, 3, 4):
+        monkeypatch.setenv("LDC_TEST_EXTRA_STREAMS", str(extra))
+        e1 = make()
+        monkeypatch.delenv("LDC_TEST_EXTRA_STREAMS")
+        got, _ = run(e1)
+        # (run-to-run differences: ~2e-5 -- float atomics in the output normalisation)
+        assert float((got - ref).abs().max()) < 2e-3
+        run(e1, 2)
+        _, t_two = run(e1, 4)
+        e1.set_option("split", 1)
+        run(e1, 2)
+        _, t_one = run(e1, 4)
+        assert t_two < 1.25 * t_one, (extra, t_two, t_one)    # (measured: 0.95 - 1.05 overlapping, 1.6 - 1.9 on a shared queue)
+        e1.close()
