@@ -743,6 +743,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->tune.gn_nap = env_int("LDC_GN_NAP", c->tune.gn_nap);
   c->tune.gn_nap0 = env_int("LDC_GN_NAP0", c->tune.gn_nap0);
   c->tune.force_tile = env_int("LDC_TILE_CFG", -1);
+  c->tune.tall_min = env_int("LDC_CONV_TALL_TILES", c->tune.tall_min);
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
   c->coop_launch = getenv("LDC_COOP_LAUNCH") ? 1 : 0;
   g_train_valu = getenv("LDC_TRAIN_VALU") ? 1 : 0;
@@ -1538,6 +1539,9 @@ struct PlanBuilder {
     if (epi_ok) {
       int t1[4], t2[4];
       conv_bm(r.c1, L, L, false, t1);
+      // (the tile shape of the layer that will be LAUNCHED: with res_conv folded in -- decided below by the same rule -- that is c1r,
+      // which the 256 x 64 tiles do not take)
+      if (r.has_res && c->fold_res && r.c1r.w && t1[0] > 0 && t1[2] == 1) conv_bm(r.c1r, L, L, false, t1);
       // Two gates on the tiles the dry run reports (BM x BN): (i) the launch as a whole stays within gn_epi_max_tiles (a performance gate:
       // beyond two rounds of workgroups the waiting tiles cost more than the gn_apply launch they replace); (ii) a SAFETY gate per item --
       // every tile spins until all tiles of its item(s) have published, and the dispatch order interleaves the items of a group of 8 M tiles,
@@ -2190,7 +2194,13 @@ static int run_ops(ldc_ctx* c, Plan* pl, const std::vector<std::function<hipErro
       HIPCHK(hipEventCreate(&e1));
       HIPCHK(hipEventRecord(e0, s));
     }
-    HIPCHK(ops[i]((use_side && where == 1) ? side : s));
+    {
+      const hipError_t oe = ops[i]((use_side && where == 1) ? side : s);
+      if (oe != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(LDC_E_HIP, "%s op %zu (%s) failed: %s", is_step ? "step" : "cond", i, (is_step && i < pl->step_info.size()) ? pl->step_info[i].c_str() : "-", hipGetErrorString(oe));
+      }
+    }
     if (prof) {
       HIPCHK(hipEventRecord(e1, s));
       c->prof_events.push_back({e0, e1});
