@@ -127,6 +127,8 @@ struct FastGeom {
   int debug;         // tuning aid (LDC_CONV_DEBUG) bits: 1 no copies after the prologue, 4 no output stores, 8 return at once, 16 one unit only
   int ntiles, ntn, ntm;                      // output tiles, tiles along N / along M (set by the launcher)
   FastDivU d_ntiles, d_ntn, d_ntm, d_ksplit; // divisions by them, prepared on the host
+  int sk_xcd;                                // split-K by 2 / 4: slice and N-tile parity follow the XCD (blockIdx & 7), see conv_fast_body
+  FastDivU d_skper;                          // ... division by ntn / (8 / ksplit)
   unsigned long long* stamps;   // tuning aid: per workgroup {start, prologue done, loop done, end} s_memtime
 };
 
