@@ -371,7 +371,9 @@ int ldc_conv_microbench(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin
                         int iters, double* ms_per_launch);
 /* Self-check: the same layer and pseudo-random operands through the pipelined conv-GEMM with tile shape `tile_cfg` forced
  * (-1: the launcher's choice) and through the generic kernel; largest output difference, largest |output|, largest relative
- * difference of the fused GroupNorm statistics / column maxima. */
+ * difference of the fused GroupNorm statistics / column maxima.  tile_cfg >= 100 (round 6): both passes on the pipelined path with tile
+ * shape tile_cfg - 100 (199: the launcher's choice) -- conv_fast_kernel, then conv_lean_kernel (csrc/conv_lean.inc): the outputs must be bit-identical
+ * (max_abs_diff == 0; pass with_gn = 0, the unfused statistics stay on conv_fast_kernel). */
 int ldc_conv_compare(ldc_ctx* ctx, int dtype, int B, int L, int cin1, int cin2, int cout, int k, int stride, int ups, int tile_cfg,
                      int with_gn, int with_colmax, int with_residual, double* max_abs_diff, double* max_abs_ref, double* max_rel_stat);
 /* Self-check of the LayerNorm folded into a 1x1 conv (the attention blocks' PreNorm in front of to_qkv) on rows x = dc + U(-1, 1):

@@ -558,6 +558,8 @@ __device__ __forceinline__ void load16_sc1_issue(u32x4_t& dst, const char* p) {
 __device__ __forceinline__ void store_plain_u32(unsigned* p, unsigned v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+struct GnStamp { unsigned long long t_pub, t_first, t_done; unsigned polls; };   // tuning aid: s_memtime after the publish / the first poll / the last; polls issued
+
 // Fused GroupNorm apply of a wave's TM x TN accumulators (ConvKArgs::gn_part != null).
 //
 // Statistics exchange WITHOUT atomics, counters or barriers: every wave publishes the (sum, sum of squares) of its rows x 32
@@ -574,7 +576,8 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 // The spin is bounded by the 100 MHz wall clock: tiles that are not all resident in time raise the host-mapped flag, never a hang.
 template <typename T, int TM, int TN, bool RES, typename KA>
 __device__ __forceinline__ void epilogue_gn_fused(const KA& a, f32x16 (&acc)[TM][TN], char* wave_lds, int m_wave0,
-                                                  int col_wave0, int M, int m0, int BM, int WM, int wm, int m_base = 0) {
+                                                  int col_wave0, int M, int m0, int BM, int WM, int wm, int m_base = 0,
+                                                  GnStamp* gst = nullptr) {   // (tuning aid)
   // m_base: first row of the M tiling this tile belongs to (0: the flat tiling of a launch of its own; an XCD team of a chain tiles
   // its own rows from its first item's first row, and M is then the team's last row + 1)
   const int lane = ldc_tid() & 63;
@@ -634,6 +637,7 @@ __device__ __forceinline__ void epilogue_gn_fused(const KA& a, f32x16 (&acc)[TM]
       }
     }
   }
+  if (gst) { gst->t_pub = __builtin_amdgcn_s_memtime(); gst->polls = 0; gst->t_first = 0; }
   // 2. gather the statistics of this wave's (item, group) pairs and build the per-column affine
   const float inv_n = 1.0f / ((float)a.L_rows * (float)cpg);
   float ca0[TN], cb0[TN], ca1[TN], cb1[TN], ca2[TN], cb2[TN];   // per-column affine for the (at most three) items of the tile
@@ -654,6 +658,7 @@ __device__ __forceinline__ void epilogue_gn_fused(const KA& a, f32x16 (&acc)[TM]
       for (unsigned spins = 0;; ++spins) {
         load16_sc1_issue(v, src);
         wait_vm0();
+        if (gst) { if (!gst->polls) gst->t_first = __builtin_amdgcn_s_memtime(); ++gst->polls; }
         if (__all(!mine || (v[0] == 1u && v[2] == 1u))) break;
         for (int z = 0; z < a.gn_nap; ++z) __builtin_amdgcn_s_sleep(1);
         // give up after 0.5 s -- or at once when an earlier launch of this call already has (the host-mapped flag is still up: the call's
@@ -709,6 +714,7 @@ __device__ __forceinline__ void epilogue_gn_fused(const KA& a, f32x16 (&acc)[TM]
       affine(mean, rstd, ca2[j], cb2[j]);
     }
   }
+  if (gst) gst->t_done = __builtin_amdgcn_s_memtime();
   typedef typename std::conditional<RES, float, T>::type TS;   // staging element
   constexpr int RBS = TN * 32 * (int)sizeof(TS);    // staged bytes per tile row
   constexpr int PITCH = RBS + 16;

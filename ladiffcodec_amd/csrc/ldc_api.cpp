@@ -744,6 +744,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   c->tune.gn_nap0 = env_int("LDC_GN_NAP0", c->tune.gn_nap0);
   c->tune.force_tile = env_int("LDC_TILE_CFG", -1);
   c->tune.tall_min = env_int("LDC_CONV_TALL_TILES", c->tune.tall_min);
+  c->tune.lean = env_int("LDC_CONV_LEAN", c->tune.lean);
   c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
   c->coop_launch = getenv("LDC_COOP_LAUNCH") ? 1 : 0;
   g_train_valu = getenv("LDC_TRAIN_VALU") ? 1 : 0;
@@ -861,6 +862,15 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
   if (n == "lstm_stream") { c->lstm_stream_only = value ? 1 : 0; return LDC_OK; }
   if (n == "lstm_xcd") { c->lstm_xcd = value ? 1 : 0; return LDC_OK; }
   if (n == "split_ends") { c->split_ends = value ? 1 : 0; return LDC_OK; }
+  if (n == "conv_lean") {   // the round-6 instruction-diet conv kernel on / off (same tiles, same results: nothing to re-plan; graphs are re-captured)
+    if ((value ? 1 : 0) != c->tune.lean) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->tune.lean = value ? 1 : 0; }
+    return LDC_OK;
+  }
+  if (n == "part_graphs") {   // 0: one fork / join graph for all parts; 1: one single-stream graph per part (two parts); 2: also for three / four parts
+    if (value < 0 || value > 2) return fail(LDC_E_INVALID, "part_graphs must be 0, 1 or 2");
+    c->part_graphs = value;   // (denoise_loop re-captures when the arrangement of a cached shape changes)
+    return LDC_OK;
+  }
   if (n == "sea_splitk") { c->sea_splitk = value ? 1 : 0; return LDC_OK; }
   if (n == "rvq_tiled") { c->rvq_tiled = value ? 1 : 0; return LDC_OK; }
   if (n == "lstm_pipe") { c->lstm_pipe = value ? 1 : 0; return LDC_OK; }
@@ -906,7 +916,7 @@ extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
     if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
     return LDC_OK;
   }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | split_init | sea_splitk | rvq_tiled | lstm_pipe | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | part_graphs | conv_lean | split_init | sea_splitk | rvq_tiled | lstm_pipe | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
 }
 
 // device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
@@ -2361,6 +2371,7 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
   const int64_t stride = (int64_t)B * c->unet.channels * L;
   LDCCHK(set_steps(c, h, n_steps - 1, 0, s));
   if (c->profile || c->serial_parts || n_steps < 3) {
+    if (left_forked && h.n >= 2) LDCCHK(join_parts(c, h, s));   // (the caller's per-part work is on the auxiliary streams; these steps may all run on s)
     for (int i = 0; i < n_steps; ++i) LDCCHK(one_step(c, h, x, noise, stride, s));
     for (int k = 0; k < h.n; ++k) LDCCHK(stamp_loop_end(c, h, k, s));
     return LDC_OK;
@@ -2531,6 +2542,11 @@ static int denoise_loop(ldc_ctx* c, const Halves& h, int B, float* x, const floa
     if (err != hipSuccess) return fail(LDC_E_HIP, "%s failed in the per-part graph replay: %s", what, hipGetErrorString(err));
     return jr;
   }
+  // The fork / join graph is launched on s ALONE: its part branches are graph nodes, not aux_stream[k].  A caller that arrives with the parts
+  // forked (ldc_decode's per-part front ends, left_forked != null) still has work of parts k >= 1 on the auxiliary streams that nothing
+  // orders in front of the replay unless the eager first step above ran (it joins): from the second decode of a shape on it does not
+  // (the replayed step kernels raced with part k's front end writing cond / x_cl / x).
+  if (left_forked && par) LDCCHK(join_parts(c, h, s));
   for (; i + K <= n_steps; i += K) LDCCHK(replay(sg->exec[0]));
   for (; i < n_steps; ++i) LDCCHK(replay(sg->exec[K == 1 ? 0 : 1]));
   for (int k = 0; k < h.n; ++k) LDCCHK(stamp_loop_end(c, h, k, s));
@@ -2671,6 +2687,15 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
     float* mx = (float*)ar.alloc((size_t)B * 4);
     if (!dry && split_ends) LDCCHK(fork_parts(c, h, s));
     const int n_front = split_ends ? h.n : 1;
+    // From here to the final join the parts' streams carry work that only join_parts orders against the caller's stream (and against the
+    // scratch arena the next call reuses): the forked regions collect their first error and the call joins before it reports it.
+    bool parts_open = !dry && split_ends;
+    auto bail = [&](int rc) -> int {
+      if (parts_open) (void)join_parts(c, h, s);
+      parts_open = false;
+      return rc;
+    };
+    auto front_end = [&]() -> int {
     for (int k = 0; k < n_front; ++k) {
       hipStream_t sk = (split_ends && k > 0) ? c->aux_stream[k] : s;
       const int b0 = split_ends ? h.b0[k] : 0, Bk = split_ends ? h.p[k]->B : B;
@@ -2696,20 +2721,25 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
         HIPCHK(launch_to_cl(c->dt, x + (size_t)h.b0[kk] * c->unet.channels * pl->L, pl->x_cl, pl->B, c->unet.channels, pl->L, nullptr, 0, 0.f, sk));
       }
     }
+    return LDC_OK;
+    };
+    { const int fr = front_end(); if (fr != LDC_OK) return bail(fr); }
     if (!dry) {
       // The parts stay on their streams from the front end to the back end (no join in front of the loop: it forks the part streams behind
       // part 0's front end itself; none behind it when the per-part replay path ran): they de-phase by the front ends' serialised pieces
       // (the cooperative LSTMs), and one part's latency-bound back end then runs under the other's last denoise steps.
       // (c->ends_join / LDC_ENDS_JOIN: both joins as before, for A/B runs)
-      if (split_ends && c->ends_join) LDCCHK(join_parts(c, h, s));
+      if (split_ends && c->ends_join) { parts_open = false; LDCCHK(join_parts(c, h, s)); }
       next_noise_key(c, noise == nullptr);
       bool forked = false;
       const int dr = denoise_loop(c, h, B, x, noise, n_steps, s, (split_ends && !c->ends_join) ? &forked : nullptr);
-      if (dr != LDC_OK) { if (split_ends && !c->ends_join) (void)join_parts(c, h, s); return dr; }
-      if (split_ends && !forked) LDCCHK(fork_parts(c, h, s));
+      if (dr != LDC_OK) return bail(dr);
+      if (split_ends && !forked) { parts_open = false; LDCCHK(fork_parts(c, h, s)); }   // (the loop joined, or never left s)
+      parts_open = split_ends;
     }
     // decoder (quirk Q3: no x18 un-scaling on this path, sample.py:131)
     int Lo_all = T;
+    auto back_end = [&]() -> int {
     for (int k = 0; k < n_front; ++k) {
       hipStream_t sk = (split_ends && k > 0) ? c->aux_stream[k] : s;
       const int b0 = split_ends ? h.b0[k] : 0, Bk = split_ends ? h.p[k]->B : B;
@@ -2723,8 +2753,11 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
       if (!dry) HIPCHK(hipMemcpyAsync(wav_out + (size_t)b0 * Lo, y, (size_t)Bk * Lo * 4, hipMemcpyDeviceToDevice, sk));
       Lo_all = Lo;
     }
+    return LDC_OK;
+    };
+    { const int br = back_end(); if (br != LDC_OK) return bail(br); }
     if (!dry) {
-      if (split_ends) LDCCHK(join_parts(c, h, s));
+      if (split_ends) { parts_open = false; LDCCHK(join_parts(c, h, s)); }
       HIPCHK(launch_output_normalise(wav_out, B, Lo_all, per_item ? 1 : 0, c->outnorm_ws, s));
     }
     return LDC_OK;

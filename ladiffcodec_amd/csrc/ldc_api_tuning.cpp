@@ -389,12 +389,41 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     cc.gn_sum = (float*)gs; cc.gn_groups = 8;
   }
   hipStream_t s = c->own_stream;
-  for (int i = 0; i < 3; ++i) HIPCHK(launch_conv(ly, cc, s));
+  // LDC_MB_GNEPI = 1 | 2 (round 6): the ResnetBlock form of the launch -- GroupNorm apply (8 groups, timestep scale / shift, SiLU) in the epilogue
+  // behind the in-launch statistics exchange; 2 = with the residual add and the row statistics for a following PreNorm.  The granule
+  // region is cleared in front of every launch (in the decode the step's first kernel does it): the memset is inside the timed loop.
+  void* gpart = nullptr;
+  size_t gpart_bytes = 0;
+  if (const char* ge = getenv("LDC_MB_GNEPI")) {
+    const int mode = atoi(ge);
+    if (mode >= 1 && cout % 256 == 0 && k == 3) {
+      const int mslots = (L_out + 63) / 64 + 1;
+      gpart_bytes = (size_t)B * mslots * 4 * (cout / 32) * 16;
+      LDCCHK(keep.alloc(&gpart, gpart_bytes));
+      void *gam = nullptr, *bet = nullptr, *ss = nullptr, *res = nullptr, *rst = nullptr;
+      LDCCHK(keep.alloc(&gam, (size_t)cout * 4)); LDCCHK(keep.alloc(&bet, (size_t)cout * 4)); LDCCHK(keep.alloc(&ss, (size_t)2 * cout * 4));
+      LDCCHK(fill_random(gam, cout, DT_F32, 31u)); LDCCHK(fill_random(bet, cout, DT_F32, 32u)); LDCCHK(fill_random(ss, (size_t)2 * cout, DT_F32, 33u));
+      cc.gn_part = gpart; cc.gn_mslots = mslots; cc.gn_groups = 8; cc.gn_gamma = (const float*)gam; cc.gn_beta = (const float*)bet; cc.gn_ss = (const float*)ss;
+      cc.fail_flag = c->dev_flag_dev;
+      if (mode >= 2) {
+        LDCCHK(keep.alloc(&res, (size_t)B * L_out * cout * es));
+        LDCCHK(fill_random(res, (size_t)B * L_out * cout, dt, 779u));
+        LDCCHK(keep.alloc(&rst, (size_t)B * L_out * (cout / 32) * 8));
+        cc.residual = res; cc.rowstat_out = (float*)rst; cc.gn_ss = nullptr;
+      }
+    }
+  }
+  auto one = [&]() -> int {
+    if (gpart) HIPCHK(hipMemsetAsync(gpart, 0, gpart_bytes, s));
+    HIPCHK(launch_conv(ly, cc, s));
+    return LDC_OK;
+  };
+  for (int i = 0; i < 3; ++i) LDCCHK(one());
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) HIPCHK(launch_conv(ly, cc, s));
+  for (int i = 0; i < iters; ++i) LDCCHK(one());
   HIPCHK(hipEventRecord(e1, s));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -408,13 +437,14 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     LDCCHK(keep.alloc(&st, (size_t)nblk * 8 * 8));
     HIPCHK(hipMemset(st, 0, (size_t)nblk * 8 * 8));
     ldc::g_conv_stamps = (unsigned long long*)st;
+    if (gpart) HIPCHK(hipMemsetAsync(gpart, 0, gpart_bytes, s));
     hipError_t le = launch_conv(ly, cc, s);
     ldc::g_conv_stamps = nullptr;
     HIPCHK(le);
     HIPCHK(hipStreamSynchronize(s));
     std::vector<unsigned long long> h((size_t)nblk * 8);
     HIPCHK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
-    double pro = 0, loop = 0, epi = 0, tab = 0, dma = 0; int n = 0;
+    double pro = 0, loop = 0, epi = 0, tab = 0, dma = 0, gath = 0, g_pub = 0, g_first = 0, g_polls = 0; int n = 0, n_g = 0;
     unsigned long long t_first = ~0ull, t_last = 0;
     int xcc_match = 0, xcc_hist[16] = {0}, xcc_of_class[8][16] = {};
     for (int b = 0; b < nblk; ++b) {
@@ -425,6 +455,11 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
       t_first = std::min(t_first, h[8 * b]); t_last = std::max(t_last, h[8 * b + 3]);
       pro += (double)(h[8 * b + 1] - h[8 * b]); loop += (double)(h[8 * b + 2] - h[8 * b + 1]); epi += (double)(h[8 * b + 3] - h[8 * b + 2]);
       tab += (double)(h[8 * b + 4] - h[8 * b]); dma += (double)(h[8 * b + 5] - h[8 * b + 4]);
+      if (h[8 * b + 7] >> 32) {   // (the lean kernel's fused GroupNorm epilogue: packed deltas from the loop's end, in units of 4 ticks)
+        const unsigned long long w = h[8 * b + 7];
+        g_pub += 4.0 * (double)(w & 0xffff); g_first += 4.0 * (double)((w >> 16) & 0xffff); gath += 4.0 * (double)((w >> 32) & 0xffff); g_polls += (double)(w >> 48);
+        ++n_g;
+      }
       ++n;
     }
     if (n) fprintf(stderr, "  XCC id == workgroup %% 8 for %d of %d workgroups; per-XCC counts %d %d %d %d %d %d %d %d\n", xcc_match, n, xcc_hist[0], xcc_hist[1],
@@ -439,6 +474,8 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     }
     if (n) fprintf(stderr, "  stamps (s_memtime ticks per workgroup): blocks=%d prologue=%.1f (tile+copy tables %.1f, first copies issued %.1f, fragment tables %.1f) loop=%.1f epilogue=%.1f | first start -> last end %.0f\n",
                    n, pro / n, tab / n, dma / n, (pro - tab - dma) / n, loop / n, epi / n, (double)(t_last - t_first));
+    if (n_g) fprintf(stderr, "  fused GroupNorm epilogue (wave 0): loop end -> published %.1f -> first poll back %.1f -> statistics gathered %.1f (%.2f polls), gathered -> stored %.1f ticks\n",
+                     g_pub / n_g, g_first / n_g, gath / n_g, g_polls / n_g, epi / n - gath / n_g);
   }
   return LDC_OK;
 }
@@ -498,8 +535,13 @@ extern "C" int ldc_conv_compare(ldc_ctx* c, int dtype, int B, int L, int cin1, i
     HIPCHK(hipMemset(y[v], 0, n_out * es));
     HIPCHK(hipMemset(st[v], 0, stat_n * 4));
     HIPCHK(hipMemset(cm[v], 0, cm_n * 4));
-    tune.force_generic = v == 0 ? 1 : 0;
-    tune.force_tile = tile_cfg;
+    // tile_cfg >= 100 (round 6): BOTH passes on the pipelined path with tile shape tile_cfg - 100, pass 0 on conv_fast_kernel (lean off), pass 1
+    // on conv_lean_kernel -- same tiles, same accumulation order: the caller expects max_abs_diff == 0
+    // (+200 / +300: conv_fast_kernel twice / conv_lean_kernel twice -- run-to-run determinism of either)
+    const bool lean_ab = tile_cfg >= 100;
+    tune.force_generic = lean_ab ? 0 : (v == 0 ? 1 : 0);
+    if (lean_ab) tune.lean = tile_cfg >= 300 ? 1 : (tile_cfg >= 200 ? 0 : v);
+    tune.force_tile = lean_ab ? (tile_cfg % 100 == 99 ? -1 : tile_cfg % 100) : tile_cfg;
     ConvCall cc;
     cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y[v]; cc.y_ld = cout; cc.residual = res;
     if (with_gn) { cc.gn_sum = (float*)st[v]; cc.gn_groups = groups; }

@@ -67,6 +67,7 @@ struct ConvTune {
   int gn_nap = 16, gn_nap0 = 0;  // LDC_GN_NAP / LDC_GN_NAP0: 64-clock naps between the polls of the fused GroupNorm exchange / before the first
   int force_tile = -1;          // self-check / tuning: 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 256x64 (bf16, k = 3, stride 1) tiles wherever the layer's N allows
   int tall_min = 0;             // 256 x 64 tiles for k = 3 layers of at least this many 128 x 128 tiles (0: never; LDC_CONV_TALL_TILES)
+  int lean = 1;                 // round 6: the instruction-diet kernel (conv_lean.inc) where its shapes allow; 0 = conv_fast_kernel everywhere (LDC_CONV_LEAN)
 };
 
 struct ConvCall {

@@ -36,6 +36,8 @@ def full_engine(layout: str, dtype: str, cond_bandwidth: float = 3.0):
     """diff_dims = 256 engines: 'c2' = enc_ratios [8,4] / upsampling [5,2] (BASELINE configs[1]), 'c8' = the released
     checkpoints' layout enc_ratios [8] / upsampling [5,4,2] (README.md:30,35)."""
     key = (layout, dtype, cond_bandwidth)
+    if key in _FULL and not _FULL[key][0]._ctx:   # (a test closed it to give its memory back)
+        del _FULL[key]
     if key not in _FULL:
         mc = CodecConfig(enc_ratios=(8, 4) if layout == "c2" else (8,), quantization=False)
         u = UnetConfig(dim=256, upsampling_ratios=(5, 2) if layout == "c2" else (5, 4, 2), unet_scale_cond=True)
@@ -500,3 +502,104 @@ def test_part_streams_are_chosen_by_overlap_and_the_decode_does_not_change(monke
         _, t_one = run(e1, 4)
         assert t_two < 1.25 * t_one, (extra, t_two, t_one)    # (measured: 0.95 - 1.05 overlapping, 1.6 - 1.9 on a shared queue)
         e1.close()
+
+
+# ------------------------------------------------------------------------------------------- per-part ends in front of a fork / join graph replay
+@pytest.mark.gpu
+@pytest.mark.parametrize("arrangement", ["split3", "fork_join_graph"])
+def test_repeated_decode_with_per_part_ends_on_the_fork_join_graph(arrangement):
+    """ldc_decode runs every part's codec front end on the part's own stream (split_ends).  Three / four parts, or two parts with
+    part_graphs 0, replay ONE graph on the caller's stream whose part branches are graph nodes: from the SECOND decode of a shape on no
+    eager step (which joins) runs in front of the replay, and the step kernels of parts k >= 1 used to race with those parts' front ends
+    still writing cond / x_cl / x on the auxiliary streams.  Decode three times in each arrangement and compare
+    with the whole-batch ends (split_ends 0), which never leave the caller's stream."""
+    e = engine("r84", "f32")
+    mc = CASES["r84"][0]
+    B, T, n_steps = 6, 10240, 7   # (T: a multiple of both hops and L = T / 32 divisible by 2^4)
+    wav = torch.from_numpy(synth.synthetic_wav(B, T, seed=77)).cuda()
+    noise = torch.randn(n_steps, B, 128, T // mc.hop_length, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    try:
+        if arrangement == "split3":
+            e.set_option("split", 3)
+        else:
+            e.set_option("part_graphs", 0)
+        e.set_option("split_ends", 0)
+        ref = e.decode(wav, n_steps, noise=noise, per_item=True).clone()
+        e.set_option("split_ends", 1)
+        for rep in range(3):
+            got = e.decode(wav, n_steps, noise=noise, per_item=True)
+            torch.cuda.synchronize()
+            # (run-to-run differences of one arrangement: float atomics in the output normalisation, ~2e-5)
+            assert float((got - ref).abs().max()) < 5e-4 * float(ref.abs().max()), (arrangement, rep)
+    finally:
+        e.set_option("split", 2)
+        e.set_option("part_graphs", 1)
+        e.set_option("split_ends", 1)
+
+
+# ------------------------------------------------------------------------------------------- the round-6 lean conv kernel vs conv_fast_kernel
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_lean_conv_kernel_single_convs_are_bit_identical_to_conv_fast_kernel(dtype):
+    """Round 6: conv_lean_kernel (csrc/conv_lean.inc) replaces conv_fast_kernel wherever its shapes allow -- host-built tile table, one
+    instruction per LDS-DMA copy, compile-time LDS layout, template-selected epilogues.  Tiles, MFMA order per accumulator, split-K
+    slice order and epilogue arithmetic are unchanged, so ONE conv on the same operands must come out bit for bit the same through both
+    kernels (ldc_conv_compare with tile_cfg + 100; 199 = the launcher's own tile choice): the UNet's k = 3 / k = 1 layer classes (srcs/modules/unet.py:67-80,137-222) incl.
+    concatenated inputs, folded nearest upsampling, the residual epilogue, the k column max, split-K (the L = 75 shapes), 64 x 64 and
+    128 x 64 tiles, ragged row counts (tiles straddling items and the end of the tensor, B * L not a multiple of any tile)."""
+    import ctypes as C
+    e = engine("r84", dtype)
+    lib, ctx = e.lib, e._ctx
+    dt = L.LDC_F32 if dtype == "f32" else L.LDC_BF16
+    shapes = [  # L, cin1, cin2, cout, k, stride, ups
+        (1200, 256, 0, 256, 3, 1, 0), (600, 512, 256, 512, 3, 1, 0), (150, 1024, 512, 1024, 3, 1, 0), (75, 1024, 1024, 1024, 3, 1, 0),
+        (75, 1024, 0, 1024, 3, 1, 0), (1200, 256, 0, 384, 1, 1, 0), (300, 512, 512, 512, 1, 1, 0), (75, 1024, 1024, 1024, 1, 1, 0),
+        (75, 1024, 0, 1024, 3, 1, 1), (300, 512, 0, 256, 3, 1, 1), (77, 256, 0, 128, 1, 1, 0), (53, 512, 0, 512, 3, 1, 0), (1200, 128, 0, 1024, 1, 1, 0),
+    ]
+    for Lx, c1, c2, co, k, st, ups in shapes:
+        for cfg in (-1, 0, 1):
+            for B in (3, 16):
+                if B == 16 and (cfg != -1 or Lx > 300):
+                    continue
+                for with_res in (0, 1):
+                    d, m, r = C.c_double(), C.c_double(), C.c_double()
+                    L.check(lib.ldc_conv_compare(ctx, dt, B, Lx, c1, c2, co, k, st, ups, 100 + (cfg if cfg >= 0 else 99), 0, 1 if k == 1 else 0, with_res, C.byref(d), C.byref(m), C.byref(r)))
+                    assert m.value > 0.1 and d.value == 0.0 and r.value == 0.0, (dtype, Lx, c1, c2, co, k, st, ups, cfg, B, with_res, d.value, m.value, r.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_lean_conv_kernel_gives_the_same_unet_as_conv_fast_kernel(dtype):
+    """The launches a single-conv check cannot set up -- the fused GroupNorm apply with its in-launch exchange, the folded res_conv and
+    PreNorm LayerNorm, split-K under a fused epilogue -- through the whole UNet at the bench grid (B = 32 as two parts; a ragged 13-item
+    batch): eps and the interior taps with conv_lean on against conv_lean off.  Not bit for bit: the LinearAttention context is
+    accumulated with fp32 atomics (attention.hip), so two runs of ONE arrangement already differ in the last bits (f32: 2e-6 of the
+    maximum measured; in bf16 such a difference flips a rounding here and there).  The reference-pinned tests above run with the lean
+    kernel on (the default)."""
+    e, mc, u, cc, sd, _ = full_engine("c2", dtype)
+    B, Lz, F = 32, 1200, 120
+    g = torch.Generator().manual_seed(53)
+    x = (torch.randn(B, 128, Lz, generator=g) * 0.7).cuda()
+    cond = torch.randn(B, 128, F, generator=g).cuda()
+    taps = ("down4", "mid", "up0", "up4")
+    # (bf16: 8e-3 measured between the two kernels, the same as between two runs of one -- the measured drift against the fp32 reference)
+    tol = 1e-5 if dtype == "f32" else 0.5 * TOL[dtype]["eps_bench"]
+    try:
+        for Bs, t in ((32, 211), (13, 37)):
+            e.set_option("conv_lean", 0)
+            ref = e.unet_forward(x[:Bs], t, cond[:Bs]).cpu().numpy()
+            ref_taps = {}
+            if Bs == 32:
+                bg = bench_golden()
+                for n in taps:
+                    shp = (Bs,) + tuple(int(v) for v in bg.g[f"tap.{n}.3.37.shape"][1:])
+                    ref_taps[n] = (shp, e.debug_tap(n, shp).cpu().numpy())
+            e.set_option("conv_lean", 1)
+            for rep in range(2):
+                got = e.unet_forward(x[:Bs], t, cond[:Bs]).cpu().numpy()
+                assert np.isfinite(got).all()
+                assert rel(got, ref) < tol, (dtype, Bs, rep, rel(got, ref))
+            for n, (shp, rt) in ref_taps.items():
+                assert rel(e.debug_tap(n, shp).cpu().numpy(), rt) < tol, (dtype, n)
+    finally:
+        e.set_option("conv_lean", 1)

@@ -13,10 +13,10 @@ def load(d, name):
     out = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != name or "conv_fast_kernel" not in r["Kernel_Name"]:
+            if r["Counter_Name"] != name or not ("conv_fast_kernel" in r["Kernel_Name"] or "conv_lean_kernel" in r["Kernel_Name"]):
                 continue
             k = r["Kernel_Name"]
-            m = re.search(r"conv_fast_kernel<(.*)>", k)
+            m = re.search(r"conv_(?:fast|lean)_kernel<(.*)>", k)
             args = [a.strip() for a in m.group(1).split(",")] if m else []
             ns = "f32" if "fast_f32" in k else ("bf16w8" if "w8" in k else "bf16")
             nums = [a for a in args if re.fullmatch(r"\d+", a)]

@@ -12,12 +12,12 @@ def collect(shape_dir):
     vals, dur = {}, []
     for f in glob.glob(shape_dir + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "conv_fast_kernel" not in r["Kernel_Name"]:
+            if not ("conv_fast_kernel" in r["Kernel_Name"] or "conv_lean_kernel" in r["Kernel_Name"]):
                 continue
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for f in glob.glob(shape_dir + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "conv_fast_kernel" in r["Kernel_Name"]:
+            if ("conv_fast_kernel" in r["Kernel_Name"] or "conv_lean_kernel" in r["Kernel_Name"]):
                 dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
     # drop the first (cold) launch of every counter
     out = {k: sum(v[1:]) / max(1, len(v) - 1) if len(v) > 1 else v[0] for k, v in vals.items()}

@@ -28,7 +28,7 @@ def mean_counter(d, name):
     vals = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == name and "conv_fast_kernel" in r["Kernel_Name"]:
+            if r["Counter_Name"] == name and ("conv_fast_kernel" in r["Kernel_Name"] or "conv_lean_kernel" in r["Kernel_Name"]):
                 vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (0.0, 0)
 
@@ -36,7 +36,7 @@ def mean_counter(d, name):
 if __name__ == "__main__":
     fetch, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
     write, nw = mean_counter(sys.argv[2], "WRITE_SIZE")
-    out = {"kernel": "conv_fast_kernel", "launches_sampled": [nf, nw], "fetch_kb_mean_raw": fetch, "write_kb_mean": write,
+    out = {"kernel": "conv_lean_kernel / conv_fast_kernel", "launches_sampled": [nf, nw], "fetch_kb_mean_raw": fetch, "write_kb_mean": write,
            "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "csrc_sha256_16": csrc_hash(),
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 0; FETCH_SIZE doubled (gfx950)"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
