@@ -599,7 +599,8 @@ def test_lean_conv_kernel_gives_the_same_unet_as_conv_fast_kernel(dtype):
                 got = e.unet_forward(x[:Bs], t, cond[:Bs]).cpu().numpy()
                 assert np.isfinite(got).all()
                 assert rel(got, ref) < tol, (dtype, Bs, rep, rel(got, ref))
+            tol_tap = 1e-5 if dtype == "f32" else 0.5 * TOL[dtype]["tap_bench"]
             for n, (shp, rt) in ref_taps.items():
-                assert rel(e.debug_tap(n, shp).cpu().numpy(), rt) < tol, (dtype, n)
+                assert rel(e.debug_tap(n, shp).cpu().numpy(), rt) < tol_tap, (dtype, n)
     finally:
         e.set_option("conv_lean", 1)
