@@ -1422,6 +1422,10 @@ struct PlanBuilder {
     long long need = 0;
     out[0] = out[1] = 0; out[2] = 1; out[3] = 0;
     d.sk_need = &need; d.bm_out = out;
+    // (a layer with a folded second conv is refused without its second output -- conv_kargs -- and the refusal reads as "generic kernel, no
+    // fused epilogue": since round 5 asked for the folded layer's own tile shape, the nine folded block1 convs of a step had silently gone
+    // back to conv + gn_apply pairs.  Nothing is written in a dry run.)
+    if (ly.wtaps) d.y2 = reinterpret_cast<void*>(16);
     (void)launch_conv(ly, d, nullptr);
   }
   // a granule region for a fused conv with tile height bm and wm wave rows; null when the pool is exhausted (first planning pass: sizes only)
