@@ -447,8 +447,13 @@ def main():
         # one process once the kernels get faster -- and how long it waited for its own look-ahead window (GPU-bound when > 0)
         "host": {"graph_launch_ms_per_step": sum(h[0] for h in hs) / args.steps, "lookahead_wait_ms_per_step": sum(h[1] for h in hs) / args.steps,
                  "graph_replays_per_step": sum(h[2] for h in hs) / args.steps,
-                 "device_side_failures": len(failures)},   # (raised flags of the bounded in-launch waits; a non-zero count aborts the run above)
+                 "device_side_failures": len(failures),    # (raised flags of the bounded in-launch waits; a non-zero count aborts the run above)
+                 # preconditions of the timed mode: the part streams the context chose by measured overlap -- accepted
+                 # candidates, one 150 us spin alone vs the caller's stream and all accepted streams spinning together (equal = they overlap) --
+                 # and the hardware-queue setting of the runtime
+                 "part_streams": eng.stream_info(), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default: 4)")},
     }
+    log("part streams: %s" % json.dumps(result["host"]["part_streams"]))
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the conv-GEMM family: per-launch hipEvents on the launch stream over one full
@@ -475,7 +480,7 @@ def main():
         traffic, traffic_src = None, None
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from pmc_traffic import csrc_hash            # the figure is reported only while it was measured on THESE kernel sources
-        for name in ("r05_conv_traffic.json", "r04_conv_traffic.json"):
+        for name in ("r06_conv_traffic.json", "r05_conv_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(tpath):
                 continue
@@ -488,7 +493,7 @@ def main():
                     traffic_src = f"profiles/{name} was measured on other kernel sources (hash mismatch): not reported"
                 break
         convs_per_step = launches / max(1, N)
-        result["roofline"] = {"bound": "mfma", "kernel": "conv_fast_kernel / conv_gemm_kernel (implicit-GEMM Conv1d on MFMA)",
+        result["roofline"] = {"bound": "mfma", "kernel": "conv_lean_kernel / conv_fast_kernel / conv_gemm_kernel (implicit-GEMM Conv1d on MFMA)",
                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                               "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                               "algorithmic_bytes_per_launch": step_bytes / max(1.0, convs_per_step),
@@ -497,12 +502,17 @@ def main():
                               "unet_step_gflop": step_flops / 1e9, "unet_step_conv_algorithmic_gb": step_bytes / 1e9}
         # matrix-pipe occupancy of the dominant kernel from the committed SQ counter passes (profiles/r05_conv_counters.md): busy cycles of
         # the MFMA pipes / (1024 SIMDs x launch duration), over the five top shape classes at the bench's per-part batch
-        cpath = os.path.join(ROOT, "profiles", "r05_conv_counters.json")
-        if os.path.exists(cpath) and args.dtype == "bf16":
+        # (like the traffic figure, reported only for the configuration and the kernel sources it was measured on)
+        cpath = os.path.join(ROOT, "profiles", "r06_conv_counters.json")
+        if os.path.exists(cpath) and args.dtype == "bf16" and B == 32 and N == 50 and args.config == "c2":
             crec = json.load(open(cpath))
-            result["roofline"]["mfma_busy_frac"] = crec["mfma_busy_frac"]
-            result["roofline"]["mfma_busy_frac_by_shape"] = {k: round(v["mfma_busy_frac_of_launch"], 4) for k, v in crec["shapes"].items()}
-            result["roofline"]["mfma_busy_source"] = "profiles/r05_conv_counters.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES over tools/conv_one.py, isolated launches)"
+            if crec.get("csrc_sha256_16") == csrc_hash():
+                result["roofline"]["mfma_busy_frac"] = crec["mfma_busy_frac"]
+                result["roofline"]["mfma_busy_frac_by_shape"] = {k: round(v["mfma_busy_frac_of_launch"], 4) for k, v in crec["shapes"].items()}
+                result["roofline"]["non_mfma_instructions_per_mfma_by_shape"] = {k: round(v["non_mfma_per_mfma"], 2) for k, v in crec["shapes"].items() if "non_mfma_per_mfma" in v}
+                result["roofline"]["mfma_busy_source"] = "profiles/r06_conv_counters.json (rocprofv3 --pmc SQ passes over tools/conv_one.py at the per-part batch, isolated launches, these kernel sources)"
+            else:
+                result["roofline"]["mfma_busy_source"] = "profiles/r06_conv_counters.json was measured on other kernel sources (hash mismatch): not reported"
         # the other kernel classes of the UNet step against the roof that bounds them (same profiling pass)
         other = []
         for name, cms, cn, cfl, cby in classes:
@@ -520,10 +530,14 @@ def main():
         eng.timeline_enable(True)
         eng.decode(wav, N, noise=None, per_item=True)     # re-captures the step graphs with the stamp pointer
         torch.cuda.synchronize(dev)
+        ck0 = eng.clock_sample()                          # (100 MHz wall ticks, shader cycles) around one decode: the shader clock it runs at
         t1 = time.perf_counter()
         eng.decode(wav, N, noise=None, per_item=True)
         torch.cuda.synchronize(dev)
         wall_ms = 1000.0 * (time.perf_counter() - t1)
+        ck1 = eng.clock_sample()
+        if ck1[0] > ck0[0]:
+            result["host"]["shader_mhz_during_decode"] = round(100.0 * (ck1[1] - ck0[1]) / (ck1[0] - ck0[0]), 1)
         tl = eng.timeline(N, nparts)
         eng.timeline_enable(False)
         span = max(float(a[:, 1].max()) for a in tl) - min(float(a[:, 0].min()) for a in tl)
@@ -584,7 +598,7 @@ def main():
                 ms2, launches2, flops2 = eng2[0].profile_read()
                 eng2[0].profile(False)
                 ach2 = flops2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0
-                pip["roofline"] = {"bound": "mfma", "kernel": "conv_fast_kernel / conv_gemm_kernel", "achieved": ach2, "peak": MFMA_PEAK_TFLOPS[args.dtype],
+                pip["roofline"] = {"bound": "mfma", "kernel": "conv_lean_kernel / conv_fast_kernel / conv_gemm_kernel", "achieved": ach2, "peak": MFMA_PEAK_TFLOPS[args.dtype],
                                    "unit": "TFLOP/s", "frac": ach2 / MFMA_PEAK_TFLOPS[args.dtype], "launches": launches2,
                                    "avg_launch_us": 1000.0 * ms2 / max(1, launches2), "traffic": None}
             result["pipelined"] = pip

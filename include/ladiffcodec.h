@@ -345,6 +345,13 @@ long long ldc_debug_sync_count(void);
 /* Host-side cost of the step-graph replays since the last reset: milliseconds spent inside hipGraphLaunch, milliseconds spent
  * waiting for the bounded look-ahead window (LDC_FLOW_DEPTH), number of replays. */
 int ldc_host_stats(ldc_ctx* ctx, int reset, double* graph_launch_ms, double* lookahead_wait_ms, int64_t* graph_launches);
+/* Preconditions of the timed mode (round 6): what the part-stream calibration measured -- streams of the context that overlap with the
+ * caller's stream and each other / candidates (good = -1: none has run), wall ms of one 150 us spin alone and of all accepted streams
+ * spinning together, parts a batch is decoded as. */
+int ldc_stream_info(ldc_ctx* ctx, int* good, int* candidates, double* one_spin_ms, double* all_spin_ms, int* parts);
+/* One sample of the device clocks behind everything queued on `stream` (synchronises it): out2[0] = 100 MHz wall clock,
+ * out2[1] = shader cycles (s_memtime).  Two samples around a region give the shader clock it ran at. */
+int ldc_clock_sample(ldc_ctx* ctx, uint64_t* out2, void* stream);
 
 /* Device-side timeline of the timed (graph-replayed, multi-stream) mode: every step of every batch part stamps a 100 MHz
  * clock at its first and last kernel.  ldc_timeline_read: ticks[2j], ticks[2j+1] = begin / end of step j of `part`. */

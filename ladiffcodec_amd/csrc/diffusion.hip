@@ -403,6 +403,14 @@ hipError_t launch_spin_us(unsigned us, hipStream_t s) {
   hipLaunchKernelGGL(spin_us_kernel, dim3(1), dim3(64), 0, s, us);
   return hipGetLastError();
 }
+__global__ void clock_sample_kernel(unsigned long long* out) {
+  out[0] = wall_clock64();
+  out[1] = __builtin_amdgcn_s_memtime();
+}
+hipError_t launch_clock_sample(unsigned long long* out2, hipStream_t s) {
+  hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(1), 0, s, out2);
+  return hipGetLastError();
+}
 hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s) {
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, st, tl);
   return hipGetLastError();

@@ -2110,10 +2110,17 @@ static int calibrate_part_streams(ldc_ctx* c, hipStream_t s) {
   std::vector<hipStream_t*> cand;
   for (int k = 1; k < kMaxParts; ++k) cand.push_back(&c->aux_stream[k]);
   for (int k = 0; k < kMaxParts; ++k) cand.push_back(&c->side_stream[k]);
+  for (const auto& e : c->calib_cache)
+    if (e.s == s && e.order.size() == cand.size()) {   // measured before against this caller stream: re-apply, no synchronisation
+      for (size_t i = 0; i < cand.size(); ++i) *cand[i] = e.order[i];
+      c->calib_good = e.good; c->calib_cand = e.cand; c->calib_one_ms = e.one_ms; c->calib_all_ms = e.all_ms;
+      c->calib_stream = s; c->calibrated = true;
+      return LDC_OK;
+    }
   std::vector<hipStream_t> chosen{s};
   auto timed = [&](const std::vector<hipStream_t>& set, double* ms) -> int {
     double best = 1e30;
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < 4; ++rep) {   // (best of four: host wall time, a loaded host inflates single samples)
       for (hipStream_t q : set) HIPCHK(hipStreamSynchronize(q));
       const auto t0 = std::chrono::steady_clock::now();
       for (hipStream_t q : set) HIPCHK(launch_spin_us(150, q));
@@ -2140,6 +2147,11 @@ static int calibrate_part_streams(ldc_ctx* c, hipStream_t s) {
   std::vector<hipStream_t> order = good;
   order.insert(order.end(), rest.begin(), rest.end());
   for (size_t i = 0; i < cand.size(); ++i) *cand[i] = order[i];
+  double all_ms = base;
+  if (!good.empty()) LDCCHK(timed(chosen, &all_ms));   // the caller's stream and every accepted stream spinning together: one spin when they overlap
+  c->calib_good = (int)good.size(); c->calib_cand = (int)cand.size(); c->calib_one_ms = base; c->calib_all_ms = all_ms;
+  if (c->calib_cache.size() >= 8) c->calib_cache.erase(c->calib_cache.begin());
+  c->calib_cache.push_back({s, order, c->calib_good, c->calib_cand, base, all_ms});
   c->calib_stream = s;
   c->calibrated = true;
   return LDC_OK;

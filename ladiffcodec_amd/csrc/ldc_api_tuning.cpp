@@ -189,6 +189,37 @@ extern "C" int ldc_host_stats(ldc_ctx* c, int reset, double* graph_launch_ms, do
   return LDC_OK;
 }
 
+// What the part-stream calibration measured (ldc_api.cpp: calibrate_part_streams): candidate streams that overlap with the caller's stream
+// and each other / candidates, wall milliseconds of one 150 us spin alone and of the caller's stream plus all accepted streams spinning
+// together (equal when they really run side by side), parts a batch is decoded as.  good = -1: no calibration has run.
+extern "C" int ldc_stream_info(ldc_ctx* c, int* good, int* candidates, double* one_spin_ms, double* all_spin_ms, int* parts) {
+  if (!c) return fail(LDC_E_INVALID, "null context");
+  if (good) *good = c->calib ? c->calib_good : -1;
+  if (candidates) *candidates = c->calib_cand;
+  if (one_spin_ms) *one_spin_ms = c->calib_one_ms;
+  if (all_spin_ms) *all_spin_ms = c->calib_all_ms;
+  if (parts) *parts = c->split_batch;
+  return LDC_OK;
+}
+
+// One sample of the device's two clocks behind everything queued on `stream`: out[0] = the 100 MHz wall clock, out[1] = s_memtime (shader
+// cycles).  Two samples around a region give the shader clock the region ran at: (d out[1] / d out[0]) x 100 MHz.  Synchronises the stream.
+extern "C" int ldc_clock_sample(ldc_ctx* c, uint64_t* out2, void* stream) {
+  if (!c || !out2) return fail(LDC_E_INVALID, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+  unsigned long long* dev = nullptr;
+  HIPCHK(hipMalloc((void**)&dev, 16));
+  hipError_t e = launch_clock_sample(dev, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  unsigned long long h[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpy(h, dev, 16, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  HIPCHK(e);
+  out2[0] = h[0]; out2[1] = h[1];
+  return LDC_OK;
+}
+
 extern "C" int ldc_timeline_enable(ldc_ctx* c, int on) {
   if (!c) return fail(LDC_E_INVALID, "null ctx");
   HIPCHK(hipSetDevice(c->device));

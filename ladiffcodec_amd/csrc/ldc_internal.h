@@ -286,6 +286,13 @@ struct ldc_ctx {
   // chains on ONE queue (measured: 143 -> 231 ms per decode)
   hipEvent_t lstm_ev[kMaxParts][kLstmChunks + 1] = {};
   hipStream_t calib_stream = nullptr; bool calibrated = false;   // the caller's stream the part streams were last chosen against (calibrate_part_streams)
+  // what the last calibration measured (ldc_stream_info): candidates that overlap with the caller's stream and each other, candidates, the
+  // wall time of one 150 us spin alone / of the caller's stream plus every accepted stream spinning together
+  int calib_good = -1, calib_cand = 0; double calib_one_ms = 0, calib_all_ms = 0;
+  // stream orders already measured, per caller stream (alternating between two caller streams re-ran the calibration -- host-blocking
+  // synchronisations -- on every call)
+  struct CalibOrder { hipStream_t s; std::vector<hipStream_t> order; int good, cand; double one_ms, all_ms; };
+  std::vector<CalibOrder> calib_cache;
   int calib = 1;                // choose the part streams by measured overlap with the caller's stream (LDC_NO_STREAM_CALIB / LDC_AUX_FROM_SIDE turn it off)
   int ends_join = 0;            // ldc_decode joins the parts between front end, denoise loop and back end (LDC_ENDS_JOIN: the structure before the parts ran through)
   int lstm_pipe = 0;            // two-layer register LSTMs as a two-stage pipeline over time chunks (LDC_LSTM_PIPE / option "lstm_pipe"): parity-tested, measured

@@ -240,6 +240,7 @@ hipError_t launch_step_advance(int* st, unsigned long long* tl, hipStream_t s); 
 hipError_t launch_step_begin(const float* table, int stride, int* st, float* cur, unsigned long long* tl, hipStream_t s,
                              void* zero = nullptr, size_t zero_bytes = 0, int advance = 0);
 hipError_t launch_step_set(int* st, int t, int j, uint64_t noise_key, hipStream_t s);
+hipError_t launch_clock_sample(unsigned long long* out2, hipStream_t s);   // out2[0] = 100 MHz wall clock, out2[1] = s_memtime (shader cycles)
 hipError_t launch_spin_us(unsigned us, hipStream_t s);   // one workgroup busy for `us` microseconds (stream-overlap calibration)
 // output normalisation (sample.py:133-134); ws: double [B][2] + float [B] zeroed by the launcher
 hipError_t launch_output_normalise(float* x, int B, int64_t n_per_item, int per_item, void* ws, hipStream_t s);

@@ -86,6 +86,22 @@ class Engine:
         L.check(self.lib.ldc_host_stats(self._ctx, int(reset), C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
 
+    def stream_info(self):
+        """What the part-stream calibration measured: {'overlapping': streams of the context that run side by side with the caller's stream
+        and each other (-1: no calibration yet), 'candidates', 'one_spin_ms', 'all_spin_ms', 'parts'}."""
+        g, n, p = C.c_int(), C.c_int(), C.c_int()
+        a, b = C.c_double(), C.c_double()
+        L.check(self.lib.ldc_stream_info(self._ctx, C.byref(g), C.byref(n), C.byref(a), C.byref(b), C.byref(p)))
+        return {"overlapping": g.value, "candidates": n.value, "one_spin_ms": a.value, "all_spin_ms": b.value, "parts": p.value}
+
+    def clock_sample(self):
+        """(100 MHz wall-clock ticks, shader cycles) behind everything queued on the current stream; synchronises it."""
+        buf = (C.c_uint64 * 2)()
+        s = self._enter()
+        L.check(self.lib.ldc_clock_sample(self._ctx, buf, s))
+        self._exit()
+        return int(buf[0]), int(buf[1])
+
     def reseed(self, seed: int) -> None:
         """torch.manual_seed counterpart for the device-drawn noise: sets the Philox seed and rewinds the call counter."""
         L.check(self.lib.ldc_reseed(self._ctx, int(seed)))

@@ -53,6 +53,31 @@ def main():
             ("%.1f / %.1f / %.1f" % (rows[s].get("SQ_INSTS_VALU", 0) / rows[s]["SQ_INSTS_MFMA"], rows[s].get("SQ_INSTS_SALU", 0) / rows[s]["SQ_INSTS_MFMA"],
                                        rows[s].get("SQ_INSTS_LDS", 0) / rows[s]["SQ_INSTS_MFMA"])) if rows[s].get("SQ_INSTS_MFMA") else "-" for s in shapes) + " |\n")
     print(open(out_md).read())
+    if len(sys.argv) > 3:   # machine-readable summary for bench.py (roofline.mfma_busy_frac), stamped with the hash of the kernel sources
+        import json
+        from pmc_traffic import csrc_hash
+        rec = {"kernel": "conv_lean_kernel / conv_fast_kernel", "csrc_sha256_16": csrc_hash(),
+               "how": "rocprofv3 --pmc passes over tools/conv_one.py (LDC_B=16), tools/run_r06.sh issue; launch fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel-trace duration x 2.4 GHz)",
+               "shapes": {}}
+        tot_busy = tot_cap = 0.0
+        for sname in shapes:
+            r = rows[sname]
+            if "SQ_VALU_MFMA_BUSY_CYCLES" not in r or "_dur_us_median" not in r:
+                continue
+            cap = 1024.0 * r["_dur_us_median"] * 2400.0
+            e = {"mfma_busy_cycles": r["SQ_VALU_MFMA_BUSY_CYCLES"], "dur_us": r["_dur_us_median"], "mfma_busy_frac_of_launch": r["SQ_VALU_MFMA_BUSY_CYCLES"] / cap}
+            if r.get("SQ_BUSY_CU_CYCLES"):
+                e["mfma_busy_frac_of_busy_cu"] = 0.25 * r["SQ_VALU_MFMA_BUSY_CYCLES"] / r["SQ_BUSY_CU_CYCLES"]
+            if r.get("SQ_INSTS_MFMA"):
+                # (VERDICT r5's formula: VALU + SALU + LDS instructions per MFMA; SQ_INSTS_VALU counts the MFMAs themselves too)
+                e["non_mfma_per_mfma"] = (r.get("SQ_INSTS_VALU", 0) + r.get("SQ_INSTS_SALU", 0) + r.get("SQ_INSTS_LDS", 0)) / r["SQ_INSTS_MFMA"]
+            if r.get("SQC_ICACHE_REQ"):
+                e["icache_hit"] = r.get("SQC_ICACHE_HITS", 0) / r["SQC_ICACHE_REQ"]
+            rec["shapes"][sname] = e
+            tot_busy += r["SQ_VALU_MFMA_BUSY_CYCLES"]
+            tot_cap += cap
+        rec["mfma_busy_frac"] = tot_busy / tot_cap if tot_cap else 0.0
+        json.dump(rec, open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -53,7 +53,7 @@ issue)   # instruction-issue / instruction-cache counters of the pipelined conv 
       p=$((p+1))
     done
   done
-  python tools/pmc_counters.py $O/iss $O/conv_issue_counters.md > /dev/null; head -70 $O/conv_issue_counters.md
+  python tools/pmc_counters.py $O/iss $O/conv_issue_counters.md $O/conv_counters.json > /dev/null; head -70 $O/conv_issue_counters.md
   find $O/iss -name "*.csv" -size +5M -delete ;;
 prof)
   rm -rf $O/prof
