@@ -351,11 +351,11 @@ def main():
     log(f"rank {rank}/{world}: checkpoints ready ({len(sd_main)} + {len(sd_cond)} tensors)")
     from ladiffcodec_amd.model import Engine
     n_fl = max(1, args.in_flight)
-    if n_fl > 1 and not os.environ.get("LDC_BENCH_KEEP_SPLIT"):
-        os.environ["LDC_NO_SPLIT"] = "1"      # read at ldc_create: with several batches in flight each batch is one chain
     engines, slot_streams = [], []
     for k in range(n_fl):
         e_k = Engine(mc, u, cc, dtype=args.dtype, device=local_rank, noise_seed=4321 + rank + 1000 * k)
+        if n_fl > 1:
+            e_k.set_option("split", 1)     # with several batches in flight each batch is one chain
         e_k.load_state_dict(L.MODEL_MAIN, sd_main)
         e_k.load_state_dict(L.MODEL_COND, sd_cond)
         e_k.finalize(strict=True)
@@ -465,9 +465,8 @@ def main():
         eng.profile(False)
         log(f"profile pass: {launches} conv launches, {ms:.1f} ms")
         # the engine decodes the batch as independent chains on their own streams (ldc_api.cpp get_halves: two by default;
-        # LDC_SPLIT / LDC_NO_SPLIT override): account the launches as they are issued
-        nparts = 1 if os.environ.get("LDC_NO_SPLIT") else (int(os.environ["LDC_SPLIT"]) if os.environ.get("LDC_SPLIT") else min(2, B))
-        nparts = max(1, min(nparts, B))
+        # option "split" overrides): account the launches as they are issued
+        nparts = max(1, min(eng.stream_info()["parts"], B))
         parts = [B * (k + 1) // nparts - B * k // nparts for k in range(nparts)]
         step_flops = step_bytes = 0.0
         for pb in parts:
@@ -563,15 +562,15 @@ def main():
             for k, a in enumerate(tl):
                 for j in range(a.shape[0]):
                     f.write(f"{k},{j},{a[j, 0]:.2f},{a[j, 1]:.2f}\n")
-    if rank == 0 and world == 1 and n_fl == 1 and not args.no_pipelined and not os.environ.get("LDC_NO_SPLIT") and not os.environ.get("LDC_SPLIT"):
+    if rank == 0 and world == 1 and n_fl == 1 and not args.no_pipelined and "split=" not in os.environ.get("LDC_OPTIONS", ""):
         # Supplementary (NOT `value`): the same K steps with TWO batches of the config's size in flight -- two more engines on
         # two streams, every batch decoded as ONE chain (kernels of 32 items instead of 16), steps dealt round-robin, all K
         # finished inside the timed region.  Per-batch latency doubles; throughput and per-launch efficiency rise.
-        os.environ["LDC_NO_SPLIT"] = "1"      # read at ldc_create
         try:
             eng2, st2 = [], []
             for k in range(2):
                 e_k = Engine(mc, u, cc, dtype=args.dtype, device=local_rank, noise_seed=8765 + k)
+                e_k.set_option("split", 1)
                 e_k.load_state_dict(L.MODEL_MAIN, sd_main)
                 e_k.load_state_dict(L.MODEL_COND, sd_cond)
                 e_k.finalize(strict=True)
@@ -604,7 +603,7 @@ def main():
             result["pipelined"] = pip
             log(f"pipelined (2 batches in flight): {pip['value']:.1f} audio-s/s, {pip['ms_per_step']:.1f} ms per batch")
         finally:
-            os.environ.pop("LDC_NO_SPLIT", None)
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cc, mc, u, sd_cond, sd_main, N, args.seconds, args.cpu_batch)
     if rank == 0:

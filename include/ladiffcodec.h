@@ -119,8 +119,12 @@ int ldc_destroy(ldc_ctx* ctx);
  * Launch structure of the UNet step (round 4; each keeps the reference's arithmetic, unet.py:137-246): "fuse_gn_epi" (default 1) = the
  * GroupNorm apply of a ResnetBlock's Block inside the producing conv, behind an in-launch exchange of per-wave statistics -- 0 restores
  * the conv + gn_apply launch pairs and is the fallback when a "[gn_wait]" device-side failure is reported; "fold_res" (1) = res_conv as a
- * fourth weight slab of block1's conv; "fold_ln" (1) = the attention blocks' PreNorm LayerNorm inside to_qkv; "chain_convs" (0) = block1's
- * and block2's convs as one launch with a per-M-tile hand-off (measured slower, kept for experiments).
+ * fourth weight slab of block1's conv; "fold_ln" (1) = the attention blocks' PreNorm LayerNorm inside to_qkv.
+ * Round 6: "conv_lean" (1) = the instruction-diet conv kernel (csrc/conv_lean.inc) where its shapes allow, 0 = conv_fast_kernel
+ * everywhere (same tiles, same results: for A/B runs); "part_graphs" (1) = one single-stream step graph per batch part (two parts),
+ * 0 = one fork / join graph, 2 = per-part graphs for three / four parts as well.  (Removed in round 6, measured slower in rounds 4-5:
+ * "chain_convs" -- block1's and block2's convs as one launch -- and "xcd_teams" -- runs of convs as persistent XCD-team launches;
+ * profiles/r04_fusion_experiments.md, profiles/r05_team_chain_experiments.md keep the numbers.)
  * Cached plans and graphs are dropped when a value changes. */
 int ldc_set_option(ldc_ctx* ctx, const char* name, int value);
 
@@ -365,11 +369,6 @@ int ldc_timeline_read(ldc_ctx* ctx, int part, int n, uint64_t* ticks);
 int ldc_kstamps_enable(ldc_ctx* ctx, int on);
 int ldc_kstamps_reset(ldc_ctx* ctx);
 int ldc_kstamps_read(ldc_ctx* ctx, int idx, int n_steps, int* n_ops, uint64_t* ticks, char* infos, int info_cap, int* classes);
-/* Tuning aid (LDC_CHAIN_STAMPS=1 in the environment before the plan is built): the per-tile s_memtime stamps of chain `chain` of the
- * last UNet call's XCD-team plan: out[8 teams][meta[0]][12] (0 body start, 1 prologue done, 2 K loop done, 3 tile end, 4 tile tables,
- * 5 first copies issued, 7 dependency wait over, 8 before the ticket pull, 9 ticket known, 10 after the tile, 11 conv index);
- * meta[1] = convs of the chain, meta[2 ...] = int[8][17] first ticket of every conv per team.  out == NULL: only *n_chains. */
-int ldc_chain_stamps(ldc_ctx* ctx, int chain, unsigned long long* out, long long cap_u64, int* meta, int* n_chains, char* info, int info_cap);
 /* Tuning aid: times the GroupNorm-apply kernel on [B,L,C] (random data, fixed statistics). */
 int ldc_gn_microbench(ldc_ctx* ctx, int dtype, int B, int L, int C, int with_residual, int iters, double* ms_per_launch);
 /* Tuning aid: times `iters` launches of one conv-GEMM (random weights/inputs) of the given shape with

@@ -10,17 +10,7 @@ namespace ldc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Thread index of the epilogue / prologue helpers.  In the chain kernel (LDC_OPAQUE_TID) the tile body sits inside a persistent loop and
-// everything that depends on the lane alone (LDS staging offsets of the epilogues, swizzles, fragment offsets: ~55 registers) would be
-// hoisted out of the loop and stay live across the whole tile (168 registers + 34 spilled instead of ~150); an opaque copy per use
-// keeps those values where they are consumed.  Costs no instruction.
-__device__ __forceinline__ int ldc_tid() {
-  int t = (int)threadIdx.x;
-#ifdef LDC_OPAQUE_TID
-  asm volatile("" : "+v"(t));
-#endif
-  return t;
-}
+__device__ __forceinline__ int ldc_tid() { return (int)threadIdx.x; }
 
 static constexpr int kRowBytes = 64;   // bytes of K (channels) per LDS row per chunk: 32 bf16 or 16 f32
 
@@ -37,7 +27,6 @@ inline FastDivU make_fastdiv(unsigned d) {
   r.m = (unsigned)m; r.sh1 = l < 1 ? l : 1u; r.sh2 = l > 0 ? l - 1 : 0u;
   return r;
 }
-// (D: FastDivU in any address space -- the chain kernel reads its descriptors through the constant address space)
 template <typename D>
 __device__ __forceinline__ unsigned fdiv(unsigned n, const D& d) {
   const unsigned t = __umulhi(d.m, n);
@@ -84,8 +73,6 @@ struct ConvKArgs {
   const float* gn_ss;      // [2 n]: (scale | shift) of the current timestep, or null
   int gn_out;              // bit 2: tanh after the residual add (the final ResnetBlock feeds torch.tanh alone, unet.py:467); bit 0: the output
                            // is written as OCP fp8 e4m3 (its only consumer is an fp8 x fp8 conv; bf16 kernels only)
-  int io_sc1;              // bit 0: the output is read inside this launch (write-through stores); bit 1: the residual was
-                           // produced inside this launch (agent-scope loads); bit 2: so was the input window (x1)
   unsigned* fail_flag;     // host-mapped word raised when a bounded spin gives up (the output is then wrong, never a hang)
   // Timed-mode stamps (ldc_kstamps_enable): every launch records the earliest workgroup start and the latest workgroup end on
   // the 100 MHz wall clock in its own slot kst[(step index & 2047) * kst_stride + {0, 1}] (atomicMin of t / of ~t), so that
@@ -101,8 +88,6 @@ struct ConvKArgs {
   char* y2;                // folded 1x1 conv (ConvLayer::wtaps): second output [rows][n], or null
   const float* bias2;
   int wtaps;               // weight slabs per channel chunk in the packed image (taps, or taps + 1 with the folded conv)
-  int m_decide;            // host-only: GEMM rows the tile-shape / split-K decisions are made for (0: the call's own B * L_rows).  The XCD-team
-                           // chains (conv_chain_kernel) process the whole batch in one launch but keep the shapes tuned for half of it
   const ConvTune* tune;    // host-only (never read on the device)
   long long* sk_need;      // host-only: dry run
   int* bm_out;             // host-only: dry run -- rows per tile the fast kernel would use (0: generic kernel); bm_out[1] = wave rows WM, bm_out[2] = split-K factor, bm_out[3] = columns per tile
@@ -119,76 +104,12 @@ struct FastGeom {
   FastDivU d_grp, d_rem, d_per;   // item_major: divisions by 8 * ntn, by ntm % 8 and by ntn / 8
   int grid;          // workgroups of this conv (tiles x split-K slices)
   int ln_off;        // folded LayerNorm: LDS byte offset of the tile's (mean, rstd) table, behind the ring and the epilogue staging
-  // chained pair (conv_fast_pair_kernel): the producer's waves count their finished, drained stores per M tile in pair_done
-  // (zeroed by the step's first kernel); a consumer tile starts its window copies once the M tiles under its window show
-  // pair_expect arrivals each
-  unsigned* pair_done;
-  unsigned pair_expect;
   int debug;         // tuning aid (LDC_CONV_DEBUG) bits: 1 no copies after the prologue, 4 no output stores, 8 return at once, 16 one unit only
   int ntiles, ntn, ntm;                      // output tiles, tiles along N / along M (set by the launcher)
   FastDivU d_ntiles, d_ntn, d_ntm, d_ksplit; // divisions by them, prepared on the host
   int sk_xcd;                                // split-K by 2 / 4: slice and N-tile parity follow the XCD (blockIdx & 7), see conv_fast_body
   FastDivU d_skper;                          // ... division by ntn / (8 / ksplit)
   unsigned long long* stamps;   // tuning aid: per workgroup {start, prologue done, loop done, end} s_memtime
-};
-
-// what the launcher of the pipelined kernel decided for one conv, captured instead of launched (chained pair, XCD-team chains)
-struct FastPrep {
-  ConvKArgs a;
-  FastGeom gm;
-  int wm, wn, tm, tn, tg, kc, na, rf;
-  size_t lds;
-  bool set = false;
-};
-
-// ---- XCD-team chains (conv_chain_kernel, round 5) ------------------------------------------------------------------------------
-// A run of consecutive convs of the denoise step as ONE persistent launch.  The batch items are pinned to the eight XCDs (team x
-// owns items [B x / 8, B (x + 1) / 8) of EVERY conv of the chain), a workgroup reads its XCC id, joins that XCD's team and pulls
-// tiles from the team's ticket head (conv-major: all tiles of conv 0, then conv 1, ...; N tile fastest inside an M tile).  A
-// consumer tile waits only for the producer tiles under its window -- flags the producers plain-store into their XCD's L2 once
-// their output rows have drained (the reader polls and reads its window past the L1: sc1) -- so a layer boundary inside a team
-// costs a 0.4 us hand-off instead of a 2.6 us kernel boundary plus a chip-wide cold first-unit burst, the activations between
-// two convs of a chain never leave the XCD's L2, and the eight teams and the items inside a team drift out of phase
-// (profiles/r05_xcd_team_probe.md).  Flags carry the epoch of the UNet pass (step state word 4), never cleared.
-static constexpr int kChainMax = 16;    // convs per chain
-struct ChainDep {
-  int prod;            // index of the producing conv inside the chain, -1: the tensor was written before the launch
-  int bm_shift;        // log2 of the producer's tile height
-  int ntn;             // producer tiles along N (flags per M tile)
-  int lrows;           // rows per item of the producer's output
-  unsigned flag_off;   // the producer's flag region (words from ChainHead::flags)
-  unsigned team_words; // ... stride between teams
-};
-struct ChainConv {
-  ConvKArgs a;
-  FastGeom gm;
-  int variant;         // kernel shape index (conv_chain_kernel's switch)
-  int bm, bn;
-  unsigned flag_off;   // this conv's flags: [team][M tile of the team][N tile] words from ChainHead::flags + flag_off
-  unsigned team_words;
-  int sk_team_tiles;   // split-K: tile slots per team in this conv's own workspace (a.sk_part / a.sk_count)
-  ChainDep dep[3];     // producers of x1 (and its row statistics), x2, residual
-};
-struct ChainHead {
-  int nconv, B;
-  unsigned* heads;         // [8][16] ticket heads, one 64-byte line per team, zeroed by the step's first kernel
-  unsigned* flags;
-  const int* step_state;   // [4] = epoch of the UNet pass (incremented by launch_step_begin)
-  unsigned* fail_flag;
-  unsigned long long* stamps;    // tuning aid (LDC_CHAIN_STAMPS): 12 s_memtime stamps per tile at [(team * stamp_team_stride + ticket) * 12], or null
-  int stamp_team_stride;
-  int first[8][kChainMax + 1];   // per team: first ticket of every conv; [nconv] = tickets of the team
-};
-struct ChainCtx {          // what a tile of a chained conv knows about its team (registers of conv_chain_kernel)
-  int m_lo, m_hi;          // the team's rows of this conv's output
-  int b_lo;                // the team's first item
-  unsigned epoch;
-  unsigned* my_flags;      // this conv's flags of this team
-  const unsigned* dep_flags[3];
-  int dep_shift[3], dep_ntn[3], dep_base[3];   // producer's tile-height shift, N tiles, first row of its tiling for this team
-  int sk_tile_base;
-  unsigned* fail_flag;
-  unsigned long long t_dep;   // tuning aid: s_memtime after the dependency wait
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -736,23 +657,17 @@ __device__ __forceinline__ void epilogue_gn_fused(const KA& a, f32x16 (&acc)[TM]
   // same wave wrote and reads: LDS executes a wave's operations in order
   const int rsub = lane / LPR, chunk = lane % LPR;
   const int col = col_wave0 + chunk * EPL;
-  const bool wt = (a.io_sc1 & 1) != 0;
   if (!RES) {
 #pragma unroll
     for (int sw = 0; sw < TM * 32 / RPS; ++sw) {
       const int row = sw * RPS + rsub;
       const int m = m_wave0 + row;
       const uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * PITCH + chunk * 16);
-      if (m < M && col < a.n) {
-        char* dst = a.y + ((size_t)m * a.y_ld + col) * sizeof(T);
-        if (wt) store16_wt(dst, v);
-        else *reinterpret_cast<uint4*>(dst) = v;
-      }
+      if (m < M && col < a.n) *reinterpret_cast<uint4*>(a.y + ((size_t)m * a.y_ld + col) * sizeof(T)) = v;
     }
   } else {
     constexpr int NSW = TM * 32 / RPS;
     u32x4_t rres[NSW];
-    const bool res_sc1 = (a.io_sc1 & 2) != 0;
     const bool has_res = a.residual != nullptr;   // (this staged-fp32 form also serves the fp8 output of a conv without residual)
     const bool out8 = (a.gn_out & 1) != 0;
 #pragma unroll
@@ -761,12 +676,10 @@ __device__ __forceinline__ void epilogue_gn_fused(const KA& a, f32x16 (&acc)[TM]
       const bool ok = m < M && col < a.n;
       rres[sw] = u32x4_t{0u, 0u, 0u, 0u};
       if (has_res) {
-        const char* src = a.residual + ((size_t)(ok ? m : 0) * a.n + (ok ? col : 0)) * sizeof(T);
-        if (res_sc1) load16_sc1_issue(rres[sw], src);
-        else { const uint4 t = *reinterpret_cast<const uint4*>(src); rres[sw] = u32x4_t{t.x, t.y, t.z, t.w}; }
+        const uint4 t = *reinterpret_cast<const uint4*>(a.residual + ((size_t)(ok ? m : 0) * a.n + (ok ? col : 0)) * sizeof(T));
+        rres[sw] = u32x4_t{t.x, t.y, t.z, t.w};
       }
     }
-    if (res_sc1 && has_res) wait_vm0();
 #pragma unroll
     for (int sw = 0; sw < NSW; ++sw) {
       const int row = sw * RPS + rsub;
@@ -834,14 +747,9 @@ __device__ __forceinline__ void epilogue_gn_fused(const KA& a, f32x16 (&acc)[TM]
           continue;
         }
       }
-      if (m < M && col < a.n) {
-        char* dst = a.y + ((size_t)m * a.y_ld + col) * sizeof(T);
-        if (wt) store16_wt(dst, v);
-        else *reinterpret_cast<uint4*>(dst) = v;
-      }
+      if (m < M && col < a.n) *reinterpret_cast<uint4*>(a.y + ((size_t)m * a.y_ld + col) * sizeof(T)) = v;
     }
   }
-  if (wt) wait_vm0();   // write-through stores have reached memory before anything signals them
 }
 
 // Second output of a launch with a folded 1x1 conv (ConvKArgs::y2): acc + bias2, whole-row stores through the same LDS staging.
@@ -872,11 +780,7 @@ __device__ __forceinline__ void epilogue_rows_second(const KA& a, f32x16 (&acc)[
     const int row = sw * RPS + rsub;
     const int m = m_wave0 + row;
     const uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * PITCH + chunk * 16);
-    if (m < M && col < a.n) {
-      char* dst = a.y2 + ((size_t)m * a.n + col) * sizeof(T);
-      if (a.io_sc1 & 1) store16_wt(dst, v);   // read by the second conv of a chained pair: write-through (drained by the caller)
-      else *reinterpret_cast<uint4*>(dst) = v;
-    }
+    if (m < M && col < a.n) *reinterpret_cast<uint4*>(a.y2 + ((size_t)m * a.n + col) * sizeof(T)) = v;
   }
 }
 
@@ -906,13 +810,5 @@ bool conv_fast_eligible(const ConvLayer& ly);
 hipError_t launch_conv_fast(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, hipStream_t s, bool* launched);
 hipError_t launch_conv_fast_fp8(const ConvLayer& ly, const ConvKArgs& a_in, int M, int span_rows, hipStream_t s, bool* launched);
 hipError_t launch_conv_fast_bf16w8(const ConvLayer& ly, const ConvKArgs& a_in, int M, int span_rows, hipStream_t s, bool* launched);
-// two dependent ResnetBlock convs as one launch (conv_fast.inc: conv_fast_pair_kernel); bf16 / f32 weights only
-// XCD-team chains (bf16 engine): decisions of the pipelined kernel for one conv (prep), then the persistent launch (conv_chain_bf16.hip)
-hipError_t prep_conv_fast_bf16(const ConvLayer& ly, const ConvKArgs& a, int M, int span_rows, FastPrep* out, bool* ok);
-int conv_chain_variant(const FastPrep& p);   // -1: this kernel shape is not in the chain kernel
-hipError_t launch_conv_chain_bf16(const ChainHead* head_dev, const ChainConv* convs_dev, size_t lds_bytes, int grid, hipStream_t s);
-int conv_chain_max_blocks_per_cu(size_t lds_bytes);
-hipError_t launch_conv_fast_pair(const ConvLayer& ly0, const ConvKArgs& a0, int M0, int span0, const ConvLayer& ly1, const ConvKArgs& a1, int M1,
-                                 int span1, unsigned* pair_done, int pair_done_cap, hipStream_t s, bool* launched);
 
 }  // namespace ldc

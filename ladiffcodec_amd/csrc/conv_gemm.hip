@@ -453,9 +453,9 @@ static hipError_t conv_kargs(const ConvLayer& ly, const ConvCall& c, ConvKArgs& 
   a.colmax = c.colmax; a.colmax_lo = c.colmax_lo; a.colmax_hi = c.colmax_hi; a.colmax_stride = c.colmax_stride;
   if (ly.tr_stride) a.colmax = nullptr;
   a.ksplit = 1; a.sk_part = c.sk_part; a.sk_count = c.sk_count; a.sk_part_cap = c.sk_part_cap; a.sk_count_cap = c.sk_count_cap;
-  a.tune = c.tune; a.sk_need = c.sk_need; a.bm_out = c.bm_out; a.m_decide = c.m_decide;
+  a.tune = c.tune; a.sk_need = c.sk_need; a.bm_out = c.bm_out;
   if (c.bm_out) { c.bm_out[0] = 0; c.bm_out[1] = 0; c.bm_out[2] = 1; c.bm_out[3] = 0; }
-  a.gn_part = (char*)c.gn_part; a.gn_mslots = c.gn_mslots; a.gn_gamma = c.gn_gamma; a.gn_beta = c.gn_beta; a.gn_ss = c.gn_ss; a.gn_out = c.gn_out; a.io_sc1 = c.io_sc1;
+  a.gn_part = (char*)c.gn_part; a.gn_mslots = c.gn_mslots; a.gn_gamma = c.gn_gamma; a.gn_beta = c.gn_beta; a.gn_ss = c.gn_ss; a.gn_out = c.gn_out;
   a.fail_flag = c.fail_flag;
   a.kst = c.kst; a.kst_step = c.kst_step; a.kst_stride = c.kst_stride;
   a.ln_s = ly.ln_s; a.ln_rowstat = c.ln_rowstat; a.rowstat_out = c.rowstat_out;
@@ -566,124 +566,5 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     return launch_cfg<__bf16, 4, 1, 1, 1>(a, M, lds, s);
   }
 }
-
-// block1's conv [+ folded res_conv] and block2's conv of a ResnetBlock as ONE launch when both run on the pipelined kernel with the same
-// tile shape (conv_fast.inc: conv_fast_pair_kernel); otherwise one after the other
-hipError_t launch_conv_pair(const ConvLayer& ly0, const ConvCall& c0, const ConvLayer& ly1, const ConvCall& c1, unsigned* pair_done,
-                            int pair_done_cap, hipStream_t s) {
-  if (pair_done && !(c0.tune && c0.tune->force_generic) && !c0.sk_need && !c1.sk_need) {
-    ConvKArgs a0, a1;
-    int M0 = 0, M1 = 0, sp0 = 0, sp1 = 0;
-    hipError_t e = conv_kargs(ly0, c0, a0, &M0, &sp0);
-    if (e == hipSuccess) e = conv_kargs(ly1, c1, a1, &M1, &sp1);
-    if (e != hipSuccess) return e;
-    if (M0 > 0 && M1 > 0) {
-      bool launched = false;
-      e = launch_conv_fast_pair(ly0, a0, M0, sp0, ly1, a1, M1, sp1, pair_done, pair_done_cap, s, &launched);
-      if (e != hipSuccess || launched) return e;
-    }
-  }
-  hipError_t e = launch_conv(ly0, c0, s);
-  if (e != hipSuccess) return e;
-  return launch_conv(ly1, c1, s);
-}
-
-// ------------------------------------------------------------------------------------------------
-// XCD-team chains: host side (decisions, device table, launch)
-// ------------------------------------------------------------------------------------------------
-static int ilog2_exact(int v) {
-  int s = 0;
-  while ((1 << s) < v) ++s;
-  return (1 << s) == v ? s : -1;
-}
-
-static hipError_t chain_prep(const ConvLayer& ly, const ConvCall& c, FastPrep* P, bool* ok) {
-  *ok = false;
-  if (ly.dt != DT_BF16 || ly.w8 || ly.tr_stride || (c.tune && c.tune->force_generic) || !conv_fast_eligible(ly)) return hipSuccess;
-  ConvKArgs a;
-  int M = 0, span = 0;
-  ConvCall cc = c;
-  cc.sk_need = nullptr; cc.bm_out = nullptr; cc.kst = nullptr;
-  hipError_t e = conv_kargs(ly, cc, a, &M, &span);
-  if (e != hipSuccess || M <= 0) return e;
-  if (a.gn_sum) return hipSuccess;   // (statistics atomics of the unfused path: their consumer is a gn_apply launch, nothing to chain)
-  return prep_conv_fast_bf16(ly, a, M, span, P, ok);
-}
-
-hipError_t conv_chain_info(const ConvLayer& ly, const ConvCall& c, ChainInfo* out) {
-  *out = ChainInfo();
-  FastPrep P;
-  bool ok = false;
-  ConvCall cc = c;
-  // let the split-K decision be made on the shape alone: the planner gives a chained conv its own workspace afterwards
-  cc.sk_part = reinterpret_cast<float*>(16); cc.sk_count = reinterpret_cast<unsigned*>(16); cc.sk_part_cap = 1ll << 50; cc.sk_count_cap = 1 << 30;
-  hipError_t e = chain_prep(ly, cc, &P, &ok);
-  if (e != hipSuccess || !ok) return e;
-  const int v = conv_chain_variant(P);
-  if (v < 0) return hipSuccess;
-  out->ok = true; out->variant = v; out->bm = P.wm * P.tm * 32; out->bn = P.wn * P.tn * 32; out->ks = P.a.ksplit; out->ntn = P.gm.ntn; out->lds = P.lds;
-  return hipSuccess;
-}
-
-size_t conv_chain_table_bytes(int nconv) { return sizeof(ChainHead) + (size_t)std::max(1, nconv) * sizeof(ChainConv) + 256; }
-
-hipError_t conv_chain_build(const ChainConvDesc* convs, int n, int B, unsigned* heads, unsigned* flags_base, const int* step_state, unsigned* fail_flag,
-                            void* table_dev, size_t* lds_out, unsigned long long* stamps, int stamp_team_stride, int* first_out) {
-  if (n < 1 || n > kChainMax || !table_dev) return hipErrorInvalidValue;
-  std::vector<char> img(conv_chain_table_bytes(n), 0);
-  ChainHead* hd = reinterpret_cast<ChainHead*>(img.data());
-  ChainConv* cv = reinterpret_cast<ChainConv*>(img.data() + sizeof(ChainHead));
-  hd->nconv = n; hd->B = B; hd->heads = heads; hd->flags = flags_base; hd->step_state = step_state; hd->fail_flag = fail_flag;
-  hd->stamps = stamps; hd->stamp_team_stride = stamp_team_stride;
-  size_t lds = 0;
-  for (int k = 0; k < n; ++k) {
-    FastPrep P;
-    bool ok = false;
-    hipError_t e = chain_prep(*convs[k].ly, convs[k].cc, &P, &ok);
-    if (e != hipSuccess) return e;
-    const int v = ok ? conv_chain_variant(P) : -1;
-    if (v < 0) return hipErrorInvalidValue;   // (the planner asked conv_chain_info first)
-    ChainConv& E = cv[k];
-    E.a = P.a; E.gm = P.gm; E.variant = v; E.bm = P.wm * P.tm * 32; E.bn = P.wn * P.tn * 32;
-    E.a.kst = nullptr; E.gm.stamps = stamps; E.gm.debug = 0;
-    E.flag_off = (unsigned)(convs[k].flags - flags_base); E.team_words = convs[k].team_words; E.sk_team_tiles = convs[k].sk_team_tiles;
-    if (E.a.ksplit > 1 && (!convs[k].cc.sk_part || !convs[k].cc.sk_count)) return hipErrorInvalidValue;
-    for (int d = 0; d < 3; ++d) {
-      ChainDep& D = E.dep[d];
-      D.prod = convs[k].dep[d];
-      if (D.prod >= k) return hipErrorInvalidValue;
-      if (D.prod >= 0) {
-        const ChainConv& Pc = cv[D.prod];
-        D.bm_shift = ilog2_exact(Pc.bm); D.ntn = Pc.gm.ntn; D.lrows = Pc.a.L_rows; D.flag_off = Pc.flag_off; D.team_words = Pc.team_words;
-        if (D.bm_shift < 0) return hipErrorInvalidValue;
-        // an input window / a residual lives in the producer's output rows
-        if (d < 2 ? Pc.a.L_rows != E.a.L_in : Pc.a.L_rows != E.a.L_rows) return hipErrorInvalidValue;
-      }
-    }
-    if (E.dep[2].prod >= 0) E.a.io_sc1 |= 2;   // the residual was written inside this launch: L1-bypassing loads
-    lds = std::max(lds, P.lds);
-    for (int x = 0; x < 8; ++x) {
-      const int items = (int)(((long long)B * (x + 1)) / 8 - ((long long)B * x) / 8);
-      const long long rows = (long long)items * E.a.L_rows;
-      const long long tickets = ((rows + E.bm - 1) / E.bm) * E.gm.ntn * E.a.ksplit;
-      hd->first[x][k + 1] = hd->first[x][k] + (int)tickets;
-      if (((rows + E.bm - 1) / E.bm) * E.gm.ntn > (long long)E.team_words) return hipErrorInvalidValue;
-      if (E.a.ksplit > 1 && ((rows + E.bm - 1) / E.bm) * E.gm.ntn > (long long)E.sk_team_tiles) return hipErrorInvalidValue;
-    }
-  }
-  *lds_out = lds;
-  for (int x = 0; x < 8; ++x) {
-    if (stamps && hd->first[x][n] > stamp_team_stride) return hipErrorInvalidValue;
-    if (first_out) for (int k = 0; k <= n; ++k) first_out[x * (kChainMax + 1) + k] = hd->first[x][k];
-  }
-  return hipMemcpy(table_dev, img.data(), sizeof(ChainHead) + (size_t)n * sizeof(ChainConv), hipMemcpyHostToDevice);
-}
-
-hipError_t launch_conv_chain(const void* table_dev, size_t lds, int grid, hipStream_t s) {
-  const ChainHead* hd = reinterpret_cast<const ChainHead*>(table_dev);
-  const ChainConv* cv = reinterpret_cast<const ChainConv*>(reinterpret_cast<const char*>(table_dev) + sizeof(ChainHead));
-  return launch_conv_chain_bf16(hd, cv, lds, grid, s);
-}
-int conv_chain_blocks_per_cu(size_t lds) { return conv_chain_max_blocks_per_cu(lds); }
 
 }  // namespace ldc

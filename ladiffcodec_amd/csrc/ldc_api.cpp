@@ -699,68 +699,36 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_side_fork[k], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_side_join[k], hipEventDisableTiming));
   }
-  c->calib = (getenv("LDC_NO_STREAM_CALIB") || getenv("LDC_AUX_FROM_SIDE")) ? 0 : 1;
-  if (const char* mp = getenv("LDC_AUX_FROM_SIDE")) {   // diagnostics (hardware-queue mapping): part stream k = side stream digit k of the value ('-' keeps it)
-    for (int k = 1; k < kMaxParts && mp[k - 1]; ++k)
-      if (mp[k - 1] >= '0' && mp[k - 1] < '0' + kMaxParts) std::swap(c->aux_stream[k], c->side_stream[mp[k - 1] - '0']);
-  }
-  // res_conv on a side stream (off the conv->norm->conv chain).  Only without the batch split: a fork inside an
-  // already forked stream (or cross edges between sibling streams) crashes stream capture on ROCm 7.2, and the
-  // two-way batch split is worth more (+9 % vs +3 %).
-  auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-  c->split_batch = getenv("LDC_NO_SPLIT") ? 1 : std::max(1, std::min(kMaxParts, env_int("LDC_SPLIT", 2)));
-  c->side_streams = (getenv("LDC_SIDE") && c->split_batch == 1) ? 1 : 0;
-  c->fuse_gn_stats = getenv("LDC_NO_GN_FUSE") ? 0 : 1;
-  c->fuse_gn_epi = getenv("LDC_NO_GN_EPI") ? 0 : 1;
-  c->split_ends = getenv("LDC_NO_SPLIT_ENDS") ? 0 : 1;
-  c->split_init = getenv("LDC_NO_SPLIT_INIT") ? 0 : 1;
-  c->sea_splitk = getenv("LDC_NO_SEA_SPLITK") ? 0 : 1;
-  c->merge_advance = getenv("LDC_STEP_ADVANCE_LAUNCH") ? 0 : 1;
-  c->lstm_pipe = env_int("LDC_LSTM_PIPE", c->lstm_pipe);
-  c->ends_join = getenv("LDC_ENDS_JOIN") ? 1 : 0;
-  c->xcd_teams = env_int("LDC_TEAMS", c->xcd_teams);
-  c->teams_min_b = std::max(1, env_int("LDC_TEAMS_MINB", c->teams_min_b));
-  c->teams_parts = std::max(1, env_int("LDC_TEAMS_PARTS", c->teams_parts));
-  c->teams_max_chain = std::max(1, std::min(kConvChainMax, env_int("LDC_TEAMS_MAXCHAIN", c->teams_max_chain)));
-  c->gn_epi_min_l = env_int("LDC_GN_EPI_MINL", c->gn_epi_min_l);
-  c->gn_epi_max_tiles = env_int("LDC_GN_EPI_MAXTILES", c->gn_epi_max_tiles);
-  c->fold_res = getenv("LDC_NO_RES_FOLD") ? 0 : 1;
-  c->chain_convs = env_int("LDC_CHAIN", c->chain_convs);
-  c->fold_ln = getenv("LDC_NO_LN_FOLD") ? 0 : 1;
-  c->fuse_kmax = getenv("LDC_NO_KMAX_FUSE") ? 0 : 1;
-  c->fuse_ln = getenv("LDC_NO_LN_FUSE") ? 0 : 1;
-  c->fuse_attn_tail = getenv("LDC_NO_TAIL_FUSE") ? 0 : 1;
-  c->flow_depth = std::max(0, std::min((int)ldc_ctx::kFlowRing - 1, env_int("LDC_FLOW_DEPTH", c->flow_depth)));
-  c->tune.force_generic = getenv("LDC_CONV_V1") ? 1 : 0;
-  c->tune.small_max = env_int("LDC_CONV_SMALL_TILES", c->tune.small_max);
-  c->tune.medium_max = env_int("LDC_CONV_MEDIUM_TILES", c->tune.medium_max);
-  c->tune.splitk = env_int("LDC_CONV_SPLITK", c->tune.splitk);
-  c->tune.sk_tiles = env_int("LDC_SK_TILES", c->tune.sk_tiles);
-  c->tune.sk_u2 = env_int("LDC_SK_U2", c->tune.sk_u2);
-  c->tune.sk_u3 = env_int("LDC_SK_U3", c->tune.sk_u3);
-  c->tune.m_fastest = env_int("LDC_CONV_MFAST", c->tune.m_fastest);
-  c->tune.debug = env_int("LDC_CONV_DEBUG", 0);
-  c->tune.gn_nap = env_int("LDC_GN_NAP", c->tune.gn_nap);
-  c->tune.gn_nap0 = env_int("LDC_GN_NAP0", c->tune.gn_nap0);
-  c->tune.force_tile = env_int("LDC_TILE_CFG", -1);
-  c->tune.tall_min = env_int("LDC_CONV_TALL_TILES", c->tune.tall_min);
-  c->tune.lean = env_int("LDC_CONV_LEAN", c->tune.lean);
-  c->lstm_stream_only = getenv("LDC_LSTM_STREAM") ? 1 : 0;
-  c->coop_launch = getenv("LDC_COOP_LAUNCH") ? 1 : 0;
-  g_train_valu = getenv("LDC_TRAIN_VALU") ? 1 : 0;
-  if (getenv("LDC_TRAIN_BF16")) g_train_bf16 = 1;
-  if (getenv("LDC_TRAIN_FP32_MFMA")) g_train_fp32_mfma = 1;   // (process-wide; ldc_set_option("train_fp32_mfma") changes it later)
-  c->lstm_xcd = env_int("LDC_LSTM_XCD", c->lstm_xcd);
+  // Every knob of the library is an OPTION (one table: find_option below; tools/README.md lists them): ldc_set_option at run time, or
+  // LDC_OPTIONS="name=value,name=value" in the environment at ldc_create (round 6: ~50 separate LDC_* variables before).
   c->xcd_resident[0] = lstm_xcd_resident(256) ? 1 : 0;
   c->xcd_resident[1] = lstm_xcd_resident(512) ? 1 : 0;
   c->coop_resident[0] = lstm_coop_resident(256) ? 1 : 0;
   c->coop_resident[1] = lstm_coop_resident(512) ? 1 : 0;
-  c->serial_parts = getenv("LDC_SERIAL") ? 1 : 0;
-  c->part_graphs = env_int("LDC_PART_GRAPHS", 1);
-  c->fp8_act = env_int("LDC_FP8_ACT", 1);
-  c->graph_steps = std::max(0, env_int("LDC_GRAPH_STEPS", 0));   // 0 = by chain count (denoise_loop)
-  c->plan_bytes_cap = (size_t)std::max(1, env_int("LDC_PLAN_CACHE_GB", 48)) << 30;
-  c->plan_count_cap = std::max(2 * kMaxParts, env_int("LDC_PLAN_CACHE_N", 24));
+  c->plan_bytes_cap = (size_t)48 << 30;
+  c->plan_count_cap = 24;
+  if (const char* mp = getenv("LDC_AUX_FROM_SIDE")) {   // diagnostics (hardware-queue mapping): part stream k = side stream digit k of the value ('-' keeps it)
+    c->calib = 0;
+    for (int k = 1; k < kMaxParts && mp[k - 1]; ++k)
+      if (mp[k - 1] >= '0' && mp[k - 1] < '0' + kMaxParts) std::swap(c->aux_stream[k], c->side_stream[mp[k - 1] - '0']);
+  }
+  if (const char* ov = getenv("LDC_OPTIONS")) {
+    std::string all(ov);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find_first_of(",; ", pos);
+      if (end == std::string::npos) end = all.size();
+      const std::string kv = all.substr(pos, end - pos);
+      pos = end + 1;
+      if (kv.empty()) continue;
+      const size_t eq = kv.find('=');
+      const std::string name = kv.substr(0, eq);
+      const int value = eq == std::string::npos ? 1 : atoi(kv.c_str() + eq + 1);
+      std::unique_ptr<ldc_ctx>& cc = c;
+      const int rc = ldc_set_option(cc.get(), name.c_str(), value);
+      if (rc != LDC_OK) return fail(LDC_E_INVALID, "LDC_OPTIONS: %s", ldc_last_error());
+    }
+  }
   switch (cfg->final_activation) {
     case LDC_ACT_NONE: c->enc_final_act = ACT_NONE; break;
     case LDC_ACT_TANH: c->enc_final_act = ACT_TANH; break;
@@ -841,82 +809,81 @@ extern "C" void ldc_quantize_e4m3(const float* in, int64_t n, uint8_t* out_codes
   }
 }
 
-// Per-context knobs that the host side used to pass through the process environment (mutating os.environ around
-// ldc_create changes every other engine created in that window).  "split": independent chains a batch is decoded as (1..4;
-// plans and graphs are cached per chain count, so it may change between calls); "lstm_stream": 1 = never take the cooperative
-// LSTM kernel (the streamed one needs no co-residency: the fallback after a device-side failure, or when several contexts or
-// processes share the device); "side_streams": 1 = res_conv on a side stream (single chain only).
+// ---- options: ONE table for ldc_set_option and LDC_OPTIONS (no os.environ mutation around ldc_create; VERDICT r5: ~70 LDC_* switches) ----
+// replan: cached plans / graphs depend on the value and are dropped when it changes.  tools/README.md documents every name.
+struct OptRef { int* p; bool replan; int lo, hi; };
+static bool find_option(ldc_ctx* c, const std::string& n, OptRef* r) {
+#define LDC_OPT(NAME, FIELD, REPLAN, LO, HI) if (n == NAME) { r->p = &(FIELD); r->replan = REPLAN; r->lo = LO; r->hi = HI; return true; }
+  // launch structure of a decode
+  LDC_OPT("split", c->split_batch, true, 1, kMaxParts)            // independent chains a batch is decoded as
+  LDC_OPT("part_graphs", c->part_graphs, false, 0, 2)             // 0 one fork / join graph | 1 one single-stream graph per part (two parts) | 2 also for 3 / 4 parts
+  LDC_OPT("graph_steps", c->graph_steps, false, 0, 1000)          // steps per replayed graph (0: by chain count)
+  LDC_OPT("flow_depth", c->flow_depth, false, 0, (int)ldc_ctx::kFlowRing - 1)
+  LDC_OPT("split_ends", c->split_ends, false, 0, 1)               // codec front / back ends per batch part on the parts' streams
+  LDC_OPT("ends_join", c->ends_join, false, 0, 1)
+  LDC_OPT("split_init", c->split_init, true, 0, 1)                // init_conv's condition half once per sampler call
+  LDC_OPT("side_streams", c->side_streams, true, 0, 1)            // res_conv on a side stream (single chain only)
+  LDC_OPT("serial_parts", c->serial_parts, false, 0, 1)           // diagnostics: parts back to back, eager
+  LDC_OPT("stream_calib", c->calib, false, 0, 1)                  // choose the part streams by measured overlap
+  LDC_OPT("merge_advance", c->merge_advance, true, 0, 1)          // the step state advances in the step's first kernel
+  // fusions of the UNet step
+  LDC_OPT("fuse_gn_stats", c->fuse_gn_stats, true, 0, 1)
+  LDC_OPT("fuse_gn_epi", c->fuse_gn_epi, true, 0, 1)              // GroupNorm apply in the conv epilogue; 0 is the fallback after a [gn_wait] failure
+  LDC_OPT("gn_epi_min_l", c->gn_epi_min_l, true, 0, 1 << 30)
+  LDC_OPT("gn_epi_max_tiles", c->gn_epi_max_tiles, true, 0, 1 << 30)
+  LDC_OPT("fold_res", c->fold_res, true, 0, 1)
+  LDC_OPT("fold_ln", c->fold_ln, true, 0, 1)
+  LDC_OPT("fuse_kmax", c->fuse_kmax, true, 0, 1)
+  LDC_OPT("fuse_ln", c->fuse_ln, true, 0, 1)
+  LDC_OPT("fuse_attn_tail", c->fuse_attn_tail, true, 0, 1)
+  // conv launchers (ConvTune)
+  LDC_OPT("conv_lean", c->tune.lean, true, 0, 1)                  // conv_lean_kernel where its shapes allow; 0 = conv_fast_kernel (A/B)
+  LDC_OPT("conv_generic", c->tune.force_generic, true, 0, 1)      // every conv on the generic kernel
+  LDC_OPT("conv_small_tiles", c->tune.small_max, true, 0, 1 << 30)
+  LDC_OPT("conv_medium_tiles", c->tune.medium_max, true, 0, 1 << 30)
+  LDC_OPT("conv_splitk", c->tune.splitk, true, 0, 4)
+  LDC_OPT("sk_tiles", c->tune.sk_tiles, true, 0, 1 << 30)
+  LDC_OPT("sk_u2", c->tune.sk_u2, true, 0, 1 << 30)
+  LDC_OPT("sk_u3", c->tune.sk_u3, true, 0, 1 << 30)
+  LDC_OPT("conv_mfast", c->tune.m_fastest, true, 0, 2)
+  LDC_OPT("conv_debug", c->tune.debug, true, 0, 255)              // ablation bits (conv_lean.inc / conv_fast.inc)
+  LDC_OPT("conv_tile", c->tune.force_tile, true, -1, 2)
+  LDC_OPT("gn_nap", c->tune.gn_nap, true, 0, 4096)
+  LDC_OPT("gn_nap0", c->tune.gn_nap0, true, 0, 4096)
+  // codec ends
+  LDC_OPT("lstm_stream", c->lstm_stream_only, false, 0, 1)        // never the cooperative LSTM kernel
+  LDC_OPT("lstm_xcd", c->lstm_xcd, false, 0, 1)
+  LDC_OPT("lstm_pipe", c->lstm_pipe, false, 0, 1)
+  LDC_OPT("coop_launch", c->coop_launch, false, 0, 1)
+  LDC_OPT("sea_splitk", c->sea_splitk, false, 0, 1)
+  LDC_OPT("rvq_tiled", c->rvq_tiled, false, 0, 1)
+  // process-wide training switches
+  LDC_OPT("train_bf16", g_train_bf16, false, 0, 1)
+  LDC_OPT("train_fp32_mfma", g_train_fp32_mfma, false, 0, 1)
+  LDC_OPT("train_valu", g_train_valu, false, 0, 1)
+#undef LDC_OPT
+  return false;
+}
+
 extern "C" int ldc_set_option(ldc_ctx* c, const char* name, int value) {
   if (!c || !name) return fail(LDC_E_INVALID, "null context or option name");
   const std::string n(name);
-  if (n == "split") {
-    if (value < 1 || value > kMaxParts) return fail(LDC_E_INVALID, "split must be in 1..%d", kMaxParts);
-    if (value != c->split_batch) {
-      HIPCHK(hipSetDevice(c->device));
-      drop_plans(c);                 // plans of one shape differ by part size: start clean
-      c->split_batch = value;
-      if (value != 1) c->side_streams = 0;
-    }
-    return LDC_OK;
-  }
-  if (n == "lstm_stream") { c->lstm_stream_only = value ? 1 : 0; return LDC_OK; }
-  if (n == "lstm_xcd") { c->lstm_xcd = value ? 1 : 0; return LDC_OK; }
-  if (n == "split_ends") { c->split_ends = value ? 1 : 0; return LDC_OK; }
-  if (n == "conv_lean") {   // the round-6 instruction-diet conv kernel on / off (same tiles, same results: nothing to re-plan; graphs are re-captured)
-    if ((value ? 1 : 0) != c->tune.lean) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->tune.lean = value ? 1 : 0; }
-    return LDC_OK;
-  }
-  if (n == "part_graphs") {   // 0: one fork / join graph for all parts; 1: one single-stream graph per part (two parts); 2: also for three / four parts
-    if (value < 0 || value > 2) return fail(LDC_E_INVALID, "part_graphs must be 0, 1 or 2");
-    c->part_graphs = value;   // (denoise_loop re-captures when the arrangement of a cached shape changes)
-    return LDC_OK;
-  }
-  if (n == "sea_splitk") { c->sea_splitk = value ? 1 : 0; return LDC_OK; }
-  if (n == "rvq_tiled") { c->rvq_tiled = value ? 1 : 0; return LDC_OK; }
-  if (n == "lstm_pipe") { c->lstm_pipe = value ? 1 : 0; return LDC_OK; }
-  if (n == "split_init") {
-    if ((value ? 1 : 0) != c->split_init) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->split_init = value ? 1 : 0; }
-    return LDC_OK;
-  }
   if (n == "fp8_act") {   // fp8-weight contexts: fp8 x fp8 MFMA where a tensor's only consumer is a conv (decided when the weights are packed)
     if (c->finalized) return fail(LDC_E_STATE, "fp8_act must be set before ldc_finalize_weights");
     c->fp8_act = value ? 1 : 0;
     return LDC_OK;
   }
-  if (n == "train_bf16") {   // process-wide: plain bf16 products in the training GEMMs (opt-in; the default keeps fp32-class accuracy)
-    g_train_bf16 = value ? 1 : 0;
-    return LDC_OK;
-  }
-  if (n == "train_fp32_mfma") {   // process-wide, like LDC_TRAIN_FP32_MFMA: training GEMMs on the exact-fp32 MFMA instead of split-bf16
-    g_train_fp32_mfma = value ? 1 : 0;
-    return LDC_OK;
-  }
-  if (n == "fuse_gn_epi") {   // GroupNorm apply in the conv epilogue (in-launch per-item wait) on / off: plans are rebuilt
-    if ((value ? 1 : 0) != c->fuse_gn_epi) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fuse_gn_epi = value ? 1 : 0; }
-    return LDC_OK;
-  }
-  if (n == "xcd_teams") {   // XCD-team chains on / off (plans are rebuilt); off = the round-4 launch structure (two batch parts, one launch per conv)
-    if ((value ? 1 : 0) != c->xcd_teams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->xcd_teams = value ? 1 : 0; }
-    return LDC_OK;
-  }
-  if (n == "fold_ln") {
-    if ((value ? 1 : 0) != c->fold_ln) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fold_ln = value ? 1 : 0; }
-    return LDC_OK;
-  }
-  if (n == "chain_convs") {
-    if ((value ? 1 : 0) != c->chain_convs) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->chain_convs = value ? 1 : 0; }
-    return LDC_OK;
-  }
-  if (n == "fold_res") {
-    if ((value ? 1 : 0) != c->fold_res) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->fold_res = value ? 1 : 0; }
-    return LDC_OK;
-  }
-  if (n == "side_streams") {
-    if (value && c->split_batch != 1) return fail(LDC_E_INVALID, "side streams need a single chain (split 1)");
-    if ((value ? 1 : 0) != c->side_streams) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); c->side_streams = value ? 1 : 0; }
-    return LDC_OK;
-  }
-  return fail(LDC_E_INVALID, "unknown option '%s' (split | split_ends | part_graphs | conv_lean | split_init | sea_splitk | rvq_tiled | lstm_pipe | lstm_stream | lstm_xcd | side_streams | xcd_teams | fuse_gn_epi | fold_res | fold_ln | chain_convs | fp8_act | train_fp32_mfma | train_bf16)", name);
+  if (n == "plan_cache_gb") { c->plan_bytes_cap = (size_t)std::max(1, value) << 30; return LDC_OK; }
+  if (n == "plan_cache_n") { c->plan_count_cap = std::max(2 * kMaxParts, value); return LDC_OK; }
+  OptRef r;
+  if (!find_option(c, n, &r)) return fail(LDC_E_INVALID, "unknown option '%s' (tools/README.md lists the options)", name);
+  if (value < r.lo || value > r.hi) return fail(LDC_E_INVALID, "option %s must be in %d..%d", name, r.lo, r.hi);
+  if (n == "side_streams" && value && c->split_batch != 1) return fail(LDC_E_INVALID, "side streams need a single chain (split 1)");
+  if (value == *r.p) return LDC_OK;
+  if (r.replan && !c->plans.empty()) { HIPCHK(hipSetDevice(c->device)); drop_plans(c); }   // plans of one shape differ by the value: start clean
+  *r.p = value;
+  if (n == "split" && value != 1) c->side_streams = 0;
+  return LDC_OK;
 }
 
 // device-wide synchronisations issued by this library in this process so far (documented cold paths only: plan eviction, re-capture,
@@ -1370,12 +1337,8 @@ struct PlanBuilder {
     pl->act_bytes += (double)rows * C * es;
     return ar->alloc((size_t)rows * C * es);
   }
-  bool team = false;   // XCD-team plan: tile shapes decided for half the batch, every conv op recorded for build_chains
-  int m_decide(int L_out) const { return team ? (c->teams_parts > 1 ? B : (B + 1) / 2) * L_out : 0; }
   int where = 0;   // stream selector for the ops being added (0 main, 1 side)
   void mark(int kind) {   // 2 = fork (side waits for main), 3 = join (main waits for side)
-    pl->step_chain.push_back(Plan::ChainSlot());
-    pl->step_chain.back().marker = true;
     pl->step_ops.push_back([](hipStream_t) { return hipSuccess; });
     pl->step_is_conv.push_back(0);
     pl->step_where.push_back(kind);
@@ -1386,9 +1349,8 @@ struct PlanBuilder {
   }
   void add(std::function<hipError_t(hipStream_t)> f, bool is_conv = false, double flops = 0, int cls = LDC_CLASS_OTHER,
            double bytes = 0) {
-    pl->step_chain.push_back(Plan::ChainSlot());
     pl->step_ops.push_back(std::move(f));
-    pl->step_where.push_back(team ? 0 : where);
+    pl->step_where.push_back(where);
     pl->step_is_conv.push_back(is_conv ? 1 : 0);
     pl->step_flops.push_back(flops);
     pl->step_class.push_back(is_conv ? LDC_CLASS_CONV : cls);
@@ -1402,8 +1364,6 @@ struct PlanBuilder {
   const float* ln_rowstat_next = nullptr;   // row-statistics partials of the next (LayerNorm-folded) conv's input
   bool want_rowstat = false;                // the next resnet()'s fused block2 conv leaves those partials of its output ...
   float* last_rowstat = nullptr;            // ... here (null when it could not)
-  struct Captured { const ConvLayer* ly = nullptr; ConvCall cc; double flops = 0, bytes = 0; std::string info; };
-  Captured* capture = nullptr;   // when set, conv() hands the call back instead of adding an op (chained pairs)
   // fused GroupNorm apply of a conv (see ConvCall::gn_cnt)
   struct GnEpi {
     void* part = nullptr;          // granule region of this conv
@@ -1416,7 +1376,7 @@ struct PlanBuilder {
   // (out[0] = rows per tile, out[1] = wave rows, out[2] = split-K factor)
   void conv_bm(const ConvLayer& ly, int L_in, int L_out, bool with_stats, int* out) {   // out: int[4]
     ConvCall d;
-    d.B = B; d.L_in = L_in; d.L_rows = L_out; d.y_ld = ly.n; d.tune = &c->tune; d.m_decide = m_decide(L_out);
+    d.B = B; d.L_in = L_in; d.L_rows = L_out; d.y_ld = ly.n; d.tune = &c->tune;
     d.sk_part = sk_part; d.sk_count = sk_count; d.sk_part_cap = sk_part_cap; d.sk_count_cap = sk_count_cap;
     if (with_stats) { d.gn_sum = stats_pool; d.gn_groups = c->unet.groups; }
     long long need = 0;
@@ -1458,7 +1418,6 @@ struct PlanBuilder {
     cc.colmax = colmax; cc.colmax_lo = cm_lo; cc.colmax_hi = cm_hi; cc.colmax_stride = cm_stride;
     cc.sk_part = sk_part; cc.sk_count = sk_count; cc.sk_part_cap = sk_part_cap; cc.sk_count_cap = sk_count_cap;
     cc.tune = &c->tune;
-    cc.m_decide = m_decide(L_out);
     {   // dry run of the launcher: how much split-K workspace would this conv use?
       ConvCall d = cc;
       long long need = 0;
@@ -1475,42 +1434,7 @@ struct PlanBuilder {
     }
     const double cbytes = ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n * (((ge && ge->part && residual) ? 2 : 1) + (ly.wtaps ? 1 : 0))) * es + (double)conv_packed_weight_bytes(ly);
     pl->conv_bytes += cbytes;
-    if (capture) {
-      capture->ly = lp; capture->cc = cc; capture->flops = ly.flops_per_row * (double)B * L_out; capture->bytes = cbytes; capture->info = info;
-      info.clear();
-      return;
-    }
     add([lp, cc](hipStream_t s) { return launch_conv(*lp, cc, s); }, true, ly.flops_per_row * (double)B * L_out, LDC_CLASS_CONV, cbytes);
-    if (team) chain_slot(ly, cc, L_out);
-  }
-  // XCD-team plan: what this conv needs as a member of a chain -- its tile flags (epoch-tagged, cleared once), its own team-major split-K
-  // workspace (the convs of a chain overlap in time: the plan-wide workspace of the stand-alone launches cannot be shared) -- allocated in
-  // every planning pass from the shapes alone; whether it ends up in a chain is decided by build_chains in the final pass
-  void chain_slot(const ConvLayer& ly, const ConvCall& cc_in, int L_out) {
-    Plan::ChainSlot& sl = pl->step_chain.back();
-    sl.is_conv = true; sl.ly = &ly; sl.cc = cc_in;
-    sl.cc.kst = nullptr;
-    if (cc_in.gn_sum) return;
-    ChainInfo info;
-    if (conv_chain_info(ly, sl.cc, &info) != hipSuccess || !info.ok) return;
-    const int team_items = (B + 7) / 8;
-    const int max_mt = (team_items * L_out + info.bm - 1) / info.bm;
-    sl.info = info;
-    sl.team_words = (unsigned)(max_mt * info.ntn);
-    const size_t flag_bytes = (size_t)8 * sl.team_words * 4;
-    sl.flags = (unsigned*)ar->alloc(flag_bytes);
-    if (ar->base) pl->zero_once.push_back({sl.flags, flag_bytes});
-    if (!pl->chain_flags_base && ar->base) pl->chain_flags_base = sl.flags;
-    sl.chainable = true;
-    if (info.ks > 1) {
-      sl.sk_team_tiles = max_mt * info.ntn;
-      const long long floats = (long long)8 * sl.sk_team_tiles * info.ks * info.bm * info.bn;
-      sl.cc.sk_part = (float*)ar->alloc((size_t)floats * 4);
-      sl.cc.sk_part_cap = floats;
-      sl.cc.sk_count = (unsigned*)take_raw((size_t)8 * sl.sk_team_tiles * 4);   // (cleared every step with the granules; null while the pool is being sized)
-      sl.cc.sk_count_cap = 8 * sl.sk_team_tiles;
-      if (!sl.cc.sk_count) sl.chainable = false;
-    }
   }
   // zeroed-every-step bytes from the granule pool (nullptr while the pool is being sized)
   void* take_raw(size_t bytes) {
@@ -1568,7 +1492,7 @@ struct PlanBuilder {
       auto few_tiles = [&](const int* t) {
         if (t[0] <= 0 || t[3] <= 0) return false;
         const long ntn = (r.cout + t[3] - 1) / t[3];
-        const long launch_tiles = (long)(((team ? m_decide(L) : rows) + t[0] - 1) / t[0]) * ntn;   // (team plans keep the half-batch decisions)
+        const long launch_tiles = (long)((rows + t[0] - 1) / t[0]) * ntn;
         const long item_tiles = (long)((L + t[0] - 1) / t[0] + 1) * ntn;
         return launch_tiles <= c->gn_epi_max_tiles && (launch_tiles <= resident_slots || item_tiles + 16 * ntn <= resident_slots);
       };
@@ -1597,42 +1521,6 @@ struct PlanBuilder {
     if (r.has_res) res = rr;
     const ConvLayer& c1 = folded ? r.c1r : r.c1;
     const ResnetW* rp = &r;
-    // both convs as ONE launch (conv_fast_pair_kernel): block2's tiles sit behind block1's in dispatch order and wait per M tile
-    unsigned* pair_done = nullptr;
-    const int pair_cap = rows / 64 + 2;
-    if (epi_ok && c->chain_convs && !f8 && !c->w8) {
-      unsigned* pd = (unsigned*)take_raw((size_t)pair_cap * 64);   // one 64-byte line per M-tile counter
-      if (epi1 && epi2) pair_done = pd;
-    }
-    if (pair_done) {
-      Captured k1, k2;
-      ge1.gamma = r.g1; ge1.beta = r.b1; ge1.ss = cur_ss + r.ss_off;
-      if (folded) y2_next = rr;
-      capture = &k1;
-      conv(c1, x1, x2, b, nullptr, L, L, nullptr, nullptr, 0, 0, 0, &ge1);
-      void* xn = nullptr;
-      if (ln_g && xn_out && c->fuse_ln && gn_apply_ln_fusable(r.cout)) {
-        xn = xn_fp8 ? ar->alloc((size_t)rows * r.cout) : act(rows, r.cout);
-        *xn_out = xn;
-      }
-      ge2.gamma = r.g2; ge2.beta = r.b2; ge2.ss = nullptr; ge2.out = out_mode & 4;
-      if (rowstat_wanted) ge2.rowstat = last_rowstat = (float*)ar->alloc((size_t)rows * (r.cout / 32) * 8);
-      if (r.has_res && !folded) mark(3);
-      capture = &k2;
-      conv(r.c2, b, nullptr, out, res, L, L, nullptr, nullptr, 0, 0, 0, &ge2);
-      capture = nullptr;
-      info = k1.info + " >> " + k2.info;
-      const ConvLayer *l1 = k1.ly, *l2 = k2.ly;
-      const ConvCall cc1 = k1.cc, cc2 = k2.cc;
-      add([=](hipStream_t s) { return launch_conv_pair(*l1, cc1, *l2, cc2, pair_done, pair_cap, s); }, true, k1.flops + k2.flops, LDC_CLASS_CONV,
-          k1.bytes + k2.bytes);
-      if (xn) {
-        const int C = r.cout;
-        add([=](hipStream_t s) { return launch_ln_rows(dt, out, xn, nullptr, ln_g, rows, C, s, xn_fp8 ? 1 : 0); }, false, 0, LDC_CLASS_LAYERNORM,
-            (xn_fp8 ? 1.5 : 2.0) * rows * C * es);
-      }
-      return out;
-    }
     if (epi1) {   // block1: conv -> GroupNorm -> (scale + 1, shift) -> SiLU, one launch, one store
       ge1.gamma = r.g1; ge1.beta = r.b1; ge1.ss = cur_ss + r.ss_off; ge1.out = f8 ? 1 : 0;
       if (folded) y2_next = rr;
@@ -1740,111 +1628,6 @@ struct PlanBuilder {
   }
 };
 
-// XCD-team plan, final pass: runs of consecutive chainable convs of the step list become ONE persistent launch each
-// (conv_fast.inc: conv_chain_kernel).  A conv joins the run in front of it unless
-//   * its residual is produced inside the run and it has no fused GroupNorm epilogue (only that epilogue reads the residual past the L1),
-//   * it folds a LayerNorm and would have to re-read rows produced inside the run (no row statistics handed over),
-//   * a fused GroupNorm exchange could not be guaranteed its workgroups: the tiles of two adjacent items of the conv (a straddling tile
-//     waits for both) + 1 must fit a team's resident workgroups (occupancy of the chain kernel with the run's LDS x 32 CUs).
-// Markers of the (disabled) side stream inside a run are dropped.
-static int build_chains(ldc_ctx* c, Plan* pl) {
-  const size_t n = pl->step_ops.size();
-  std::vector<std::function<hipError_t(hipStream_t)>> ops;
-  std::vector<int> is_conv, where, cls;
-  std::vector<double> flops, bytes;
-  std::vector<std::string> info;
-  std::vector<Plan::ChainSlot> slots;
-  auto keep = [&](size_t i) {
-    ops.push_back(pl->step_ops[i]); is_conv.push_back(pl->step_is_conv[i]); where.push_back(pl->step_where[i]); cls.push_back(pl->step_class[i]);
-    flops.push_back(pl->step_flops[i]); bytes.push_back(pl->step_bytes[i]); info.push_back(pl->step_info[i]); slots.push_back(pl->step_chain[i]);
-  };
-  size_t table_off = 0;
-  int n_chains = 0, n_chained = 0;
-  const int cus = 256;
-  size_t i = 0;
-  while (i < n) {
-    const Plan::ChainSlot& s0 = pl->step_chain[i];
-    if (!(s0.is_conv && s0.chainable) || c->teams_max_chain < 2 || n_chains >= kChainHeads) { keep(i); ++i; continue; }
-    // grow the run
-    std::vector<size_t> run;          // op indices of the member convs
-    std::vector<ChainConvDesc> desc;
-    size_t lds = 0;
-    size_t j = i;
-    auto producer = [&](const void* p) -> int {
-      if (!p) return -1;
-      for (int k = (int)desc.size() - 1; k >= 0; --k)
-        if (desc[k].cc.y == p || desc[k].cc.y2 == p) return k;
-      return -1;
-    };
-    while (j < n && (int)run.size() < c->teams_max_chain) {
-      const Plan::ChainSlot& sl = pl->step_chain[j];
-      if (sl.marker) { ++j; continue; }
-      if (!(sl.is_conv && sl.chainable)) break;
-      ChainConvDesc d;
-      d.ly = sl.ly; d.cc = sl.cc; d.flags = sl.flags; d.team_words = sl.team_words; d.sk_team_tiles = sl.sk_team_tiles;
-      d.dep[0] = producer(sl.cc.x1); d.dep[1] = producer(sl.cc.x2); d.dep[2] = producer(sl.cc.residual);
-      if (d.dep[2] >= 0 && !sl.cc.gn_part) break;
-      if (sl.ly->ln_s && d.dep[0] >= 0) {
-        if (!sl.cc.ln_rowstat || desc[d.dep[0]].cc.rowstat_out != sl.cc.ln_rowstat) break;
-      }
-      const size_t lds_try = std::max(lds, sl.info.lds);
-      if (sl.cc.gn_part) {
-        const int slots_team = conv_chain_blocks_per_cu(lds_try) * (cus / 8) / std::max(1, c->teams_parts);
-        const int need = (2 * ((sl.cc.L_rows + sl.info.bm - 1) / sl.info.bm) + 1) * sl.info.ntn + 1;
-        if (need > slots_team) break;
-        // (the members already in the run were admitted with a smaller or equal LDS footprint: re-check them against the new occupancy)
-        bool all_ok = true;
-        for (const ChainConvDesc& e : desc)
-          if (e.cc.gn_part) {
-            ChainInfo ei;
-            (void)conv_chain_info(*e.ly, e.cc, &ei);
-            if ((2 * ((e.cc.L_rows + ei.bm - 1) / ei.bm) + 1) * ei.ntn + 1 > slots_team) all_ok = false;
-          }
-        if (!all_ok) break;
-      }
-      lds = lds_try;
-      desc.push_back(d);
-      run.push_back(j);
-      ++j;
-    }
-    // trailing markers stay outside the run
-    while (j > i && !run.empty() && j - 1 > run.back()) --j;
-    if (run.size() < 2) { keep(i); ++i; continue; }
-    const size_t tb = conv_chain_table_bytes((int)run.size());
-    if (table_off + tb > pl->chain_table_bytes) { keep(i); ++i; continue; }
-    void* table = pl->chain_tables + table_off;
-    table_off += (tb + 255) / 256 * 256;
-    size_t lds_out = 0;
-    unsigned* heads = pl->chain_heads + (size_t)n_chains * 8 * 16;
-    Plan::ChainDbg dbg;
-    dbg.stamps = pl->chain_stamps ? pl->chain_stamps + (size_t)n_chains * 8 * kChainStampStride * 12 : nullptr;
-    dbg.nconv = (int)desc.size();
-    hipError_t e = conv_chain_build(desc.data(), (int)desc.size(), pl->B, heads, pl->chain_flags_base, pl->step_state, c->dev_flag_dev, table, &lds_out,
-                                    dbg.stamps, kChainStampStride, dbg.first);
-    if (e != hipSuccess) return fail(LDC_E_HIP, "conv_chain_build failed: %s", hipGetErrorString(e));
-    const int blocks = std::max(1, conv_chain_blocks_per_cu(lds_out));
-    const int grid = blocks * cus / std::max(1, c->teams_parts);
-    double fl = 0, by = 0;
-    std::string inf = "chain" + std::to_string(run.size()) + ":";
-    for (size_t r : run) { fl += pl->step_flops[r]; by += pl->step_bytes[r]; inf += " " + pl->step_info[r]; }
-    dbg.info = inf;
-    pl->chain_dbg.push_back(dbg);
-    ops.push_back([table, lds_out, grid](hipStream_t st) { return launch_conv_chain(table, lds_out, grid, st); });
-    is_conv.push_back(1); where.push_back(0); cls.push_back(LDC_CLASS_CONV); flops.push_back(fl); bytes.push_back(by); info.push_back(inf);
-    slots.push_back(Plan::ChainSlot());
-    ++n_chains; n_chained += (int)run.size();
-    i = j;
-  }
-  pl->step_ops.swap(ops); pl->step_is_conv.swap(is_conv); pl->step_where.swap(where); pl->step_class.swap(cls);
-  pl->step_flops.swap(flops); pl->step_bytes.swap(bytes); pl->step_info.swap(info); pl->step_chain.swap(slots);
-  pl->n_chains = n_chains; pl->n_chained_convs = n_chained;
-  if (getenv("LDC_TEAMS_VERBOSE")) {
-    fprintf(stderr, "[ldc] XCD-team plan B=%d L=%d: %zu launches per step (%d chains holding %d convs)\n", pl->B, pl->L, pl->step_ops.size(), n_chains, n_chained);
-    for (size_t k = 0; k < pl->step_ops.size(); ++k) fprintf(stderr, "[ldc]   %3zu %s\n", k, pl->step_info[k].c_str());
-  }
-  return LDC_OK;
-}
-
 int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const UnetW& u = c->unet;
   pl->B = B; pl->L = L; pl->F = F;
@@ -1854,8 +1637,7 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   const size_t es = dt_size(dt);
   const int Cc = u.cond_channels, Cx = u.channels;
   PlanBuilder pb{c, pl, &ar, B, es};
-  pb.team = pl->team_mode;
-  pl->step_chain.clear(); pl->zero_once.clear(); pl->chain_flags_base = nullptr; pl->n_chains = 0; pl->n_chained_convs = 0; pl->chain_dbg.clear();
+  pl->zero_once.clear();
   const int n_gn = 2 * (int)(2 * u.downs.size() + 2 + 2 * u.ups.size() + 1);
   const size_t gn_bytes = (size_t)n_gn * B * u.groups * kGnPad * 4;
   const size_t n_lin = c->fuse_kmax ? u.downs.size() + u.ups.size() : 1;
@@ -1878,7 +1660,6 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
   pl->maxabs = (float*)ar.alloc((size_t)B * 4);
   pl->step_state = (int*)ar.alloc(64);
   if (ar.base) pl->zero_once.push_back({pl->step_state, 64});   // [4] = the epoch of the UNet pass (launch_step_begin counts it up)
-  pl->chain_heads = pl->team_mode ? (unsigned*)pb.take_raw((size_t)kChainHeads * 8 * 64) : nullptr;
   pl->kst = c->kstamps ? (unsigned long long*)ar.alloc((size_t)2048 * kKstOps * 2 * 8) : nullptr;
   pl->cur_ss = (float*)ar.alloc((size_t)std::max(1, u.ss_stride) * 4);
   pl->x_cl = ar.alloc((size_t)B * L * Cx * es);
@@ -2010,14 +1791,6 @@ int build_plan(ldc_ctx* c, Plan* pl, Arena& ar, int B, int L, int F) {
     }
     pb.conv(f8 ? u.final_conv_f8 : u.final_conv, th, nullptr, pl->eps_cl, nullptr, L, L);
   }
-  if (pl->team_mode) {
-    int n_conv = 0;
-    for (const auto& sl : pl->step_chain) n_conv += sl.is_conv ? 1 : 0;
-    pl->chain_table_bytes = (size_t)n_conv * conv_chain_table_bytes(1) + 4096;   // (a head per conv at worst)
-    pl->chain_tables = (char*)ar.alloc(pl->chain_table_bytes);
-    pl->chain_stamps = getenv("LDC_CHAIN_STAMPS") ? (unsigned long long*)ar.alloc((size_t)kChainHeads * 8 * kChainStampStride * 12 * 8) : nullptr;
-    if (ar.base) LDCCHK(build_chains(c, pl));
-  }
   return LDC_OK;
 }
 
@@ -2041,22 +1814,21 @@ static void evict_plan(ldc_ctx* c, size_t idx) {
   c->plans.erase(c->plans.begin() + idx);
 }
 
-static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Plan** out, bool team = false) {
+static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Plan** out) {
   for (auto& p : c->plans)
-    if (p->B == B && p->L == L && p->F == F && p->slot == slot && p->team_mode == team) {
+    if (p->B == B && p->L == L && p->F == F && p->slot == slot) {
       p->last_use = ++c->use_tick;
       *out = p.get();
       return LDC_OK;
     }
   std::unique_ptr<Plan> pl(new Plan());
-  pl->team_mode = team;
   {   // pass 1: what do the convs of this plan need as split-K workspace?
     Arena dry;
     LDCCHK(build_plan(c, pl.get(), dry, B, L, F));
     pl->sk_floats = pl->sk_need_max;
     pl->part_bytes = pl->part_need;
-    // once more with those sizes: convs that fuse their GroupNorm apply only once the granule pool exists ask for more of it (an XCD-team
-    // plan also keeps the split-K counters of its chained convs there), and the split-K decisions feed back into what is folded
+    // once more with those sizes: convs that fuse their GroupNorm apply only once the granule pool exists ask for more of it, and
+    // the split-K decisions feed back into what is folded
     Arena dry2;
     LDCCHK(build_plan(c, pl.get(), dry2, B, L, F));
     pl->sk_floats = std::max(pl->sk_floats, pl->sk_need_max);
@@ -2083,7 +1855,7 @@ static int get_plan(ldc_ctx* c, int B, int L, int F, int slot, hipStream_t s, Pl
   real.cap = want;
   int rc = build_plan(c, pl.get(), real, B, L, F);
   if (rc != LDC_OK) { (void)hipFree(base); return rc; }
-  for (const auto& z : pl->zero_once) {   // tile flags of the chains, the epoch word: cleared once, before the plan's first use
+  for (const auto& z : pl->zero_once) {   // the step state's epoch word: cleared once, before the plan's first use
     hipError_t ez = hipMemsetAsync(z.first, 0, z.second, s);
     if (ez != hipSuccess) { (void)hipFree(base); return fail(LDC_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(ez)); }
   }
@@ -2165,15 +1937,11 @@ static int get_halves(ldc_ctx* c, int B, int L, int F, hipStream_t s, Halves* h)
   // other's floors.  Measured on one box (32 x 2.4 s): 2 x 16 items 503 audio-s/s, 3 chains 505, 4 x 8 items 510 -- but
   // the convs of a 4 x 8 decode run at 209 instead of 344 TFLOP/s per launch, so two chains stay the default (LDC_SPLIT).
   h->n = std::max(1, std::min(c->split_batch, B));
-  // XCD-team chains: the whole batch is ONE chain of launches (runs of convs as persistent launches with the items pinned to XCDs); the
-  // concurrency the two batch parts bought comes from the teams and the items inside a team drifting out of phase instead
-  const bool team = c->xcd_teams && c->dt == DT_BF16 && !c->w8 && c->fuse_gn_epi && !c->kstamps && !c->side_streams && B >= c->teams_min_b;
-  if (team) h->n = std::max(1, std::min(c->teams_parts, std::min(kMaxParts, B / 8)));   // (LDC_TEAMS_PARTS: experiment -- one persistent chain kernel per batch part, each with its share of the workgroups)
   if (h->n >= 2) LDCCHK(calibrate_part_streams(c, s));
   for (int k = 0; k < h->n; ++k) {
     const int lo = (int)((long long)B * k / h->n), hi = (int)((long long)B * (k + 1) / h->n);
     h->b0[k] = lo;
-    LDCCHK(get_plan(c, hi - lo, L, F, k, s, &h->p[k], team));
+    LDCCHK(get_plan(c, hi - lo, L, F, k, s, &h->p[k]));
   }
   c->last_halves = *h;
   return LDC_OK;

@@ -747,7 +747,7 @@ extern "C" int ldc_gn_microbench(ldc_ctx* c, int dtype, int B, int L, int C, int
   float* g = (float*)gb;
   hipStream_t s = c->own_stream;
   void* yln = nullptr;
-  const int mode = getenv("LDC_GN_LN") ? atoi(getenv("LDC_GN_LN")) : 0;   // 1: fused LayerNorm output, 2: separate ln_rows launch
+  const int mode = 0;   // (1: fused LayerNorm output, 2: separate ln_rows launch -- round-2 experiments)
   if (mode) LDCCHK(keep.alloc(&yln, n * es));
   auto go = [&]() {
     hipError_t e = launch_gn_apply(dt, x, y, with_residual ? r : nullptr, B, L, C, 8, (float*)st, g, g + C, g + 2 * C, 0, nullptr, ACT_SILU, s,
@@ -770,29 +770,6 @@ extern "C" int ldc_gn_microbench(ldc_ctx* c, int dtype, int B, int L, int C, int
 }
 
 
-// Tuning aid (LDC_CHAIN_STAMPS=1): the per-tile s_memtime stamps of chain `chain` of the last UNet call's (XCD-team) plan.
-// out: [8 teams][stride][12] u64 as the kernel wrote them (stride returned in meta[0]); meta[1] = convs of the chain,
-// meta[2 ...] = int[8][17] first tickets per team.  Returns the number of chains of the plan through *n_chains.
-extern "C" int ldc_chain_stamps(ldc_ctx* c, int chain, unsigned long long* out, long long cap_u64, int* meta, int* n_chains, char* info, int info_cap) {
-  if (!c || !n_chains) return fail(LDC_E_INVALID, "null argument");
-  const Halves& h = c->last_halves;
-  if (h.n == 0 || !h.p[0]) return fail(LDC_E_STATE, "no UNet call has been made yet");
-  Plan* pl = h.p[0];
-  *n_chains = (int)pl->chain_dbg.size();
-  if (chain < 0 || chain >= *n_chains || !out) return LDC_OK;
-  const Plan::ChainDbg& d = pl->chain_dbg[chain];
-  if (!d.stamps) return fail(LDC_E_STATE, "stamps are off (LDC_CHAIN_STAMPS=1 before the plan is built)");
-  const long long n = (long long)8 * kChainStampStride * 12;
-  if (cap_u64 < n) return fail(LDC_E_INVALID, "need %lld u64", n);
-  HIPCHK(counted_device_sync());
-  HIPCHK(hipMemcpy(out, d.stamps, (size_t)n * 8, hipMemcpyDeviceToHost));
-  if (meta) {
-    meta[0] = kChainStampStride; meta[1] = d.nconv;
-    for (int i = 0; i < 8 * (kConvChainMax + 1); ++i) meta[2 + i] = d.first[i];
-  }
-  if (info && info_cap > 0) snprintf(info, (size_t)info_cap, "%s", d.info.c_str());
-  return LDC_OK;
-}
 
 // Self-check of the folded PreNorm LayerNorm (ConvLayer::ln_s, unet.py:82-101 in front of to_qkv) on rows with a DC offset:
 // y_ref = conv1x1(LayerNorm(x) * g) through launch_ln_rows + a plain conv, against the LayerNorm-folded conv reading x itself

@@ -201,31 +201,8 @@ struct Plan {   // one UNet step for a fixed (sub-batch B, L, F); `slot` tells t
   struct Tap { void* p; int C; int L; };
   std::map<std::string, Tap> taps;
   double flops = 0, act_bytes = 0, conv_bytes = 0;   // conv_bytes: inputs + outputs + packed weights of every conv-GEMM
-  // XCD-team chains (ldc_ctx::xcd_teams): what every conv op of the step list needs to become a member of a chain, recorded by
-  // PlanBuilder::conv in every planning pass (sizes are shape-only); build_chains wires the runs up in the final pass
-  struct ChainSlot {
-    bool is_conv = false, chainable = false, marker = false;
-    const ConvLayer* ly = nullptr;
-    ConvCall cc;                 // with its own split-K workspace and m_decide
-    ChainInfo info;
-    unsigned* flags = nullptr;
-    unsigned team_words = 0;
-    int sk_team_tiles = 0;
-  };
-  std::vector<ChainSlot> step_chain;          // parallel to step_ops
-  std::vector<std::pair<void*, size_t>> zero_once;   // regions cleared when the plan is created (tile flags, the epoch word)
-  unsigned* chain_heads = nullptr;            // [kChainHeads][8][16] ticket heads inside the per-step zero region
-  char* chain_tables = nullptr;               // device tables of the chains
-  size_t chain_table_bytes = 0;
-  unsigned* chain_flags_base = nullptr;
-  int n_chains = 0, n_chained_convs = 0;
-  struct ChainDbg { unsigned long long* stamps = nullptr; int nconv = 0; int first[8 * (kConvChainMax + 1)] = {}; std::string info; };
-  std::vector<ChainDbg> chain_dbg;            // LDC_CHAIN_STAMPS
-  unsigned long long* chain_stamps = nullptr;
-  bool team_mode = false;
+  std::vector<std::pair<void*, size_t>> zero_once;   // regions cleared when the plan is created (the step state's epoch word)
 };
-static constexpr int kChainHeads = 32;        // chains per step
-static constexpr int kChainStampStride = 4096; // tickets per team and chain the stamp buffer holds
 
 // A batch is decoded as (up to) two independent halves on two streams: utterances do not interact inside
 // the UNet, so the halves' kernels overlap and fill each other's tails and launch gaps.
@@ -334,21 +311,14 @@ struct ldc_ctx {
                                 // item alone is 150 tiles of a 2400-tile launch (the L = 4800 layout: 501 instead of 450 ms per decode)
   int gn_epi_min_l = 0;         // LDC_GN_EPI_MINL: shortest level (positions per item) whose ResnetBlocks fuse the GroupNorm apply
   int fold_ln = 1;              // PreNorm LayerNorm of the attention blocks folded into to_qkv (LDC_NO_LN_FOLD / option "fold_ln")
-  int chain_convs = 0;          // block1's and block2's convs of a ResnetBlock as ONE launch (conv_fast_pair_kernel; LDC_CHAIN=1 / option "chain_convs").
                                 // Off: measured 3 % slower than two launches (157.3 vs 152.2 ms per decode, profiles/r04_fusion_experiments.md)
   int fold_res = 1;             // res_conv as a second accumulator set of block1's conv (LDC_NO_RES_FOLD / option "fold_res")
-  // XCD-team chains (round 5): the whole batch as ONE chain of launches, runs of consecutive convs as one persistent launch each, batch
-  // items pinned to XCDs (conv_fast.inc: conv_chain_kernel).  bf16 engine, fused GroupNorm apply, batches of >= teams_min_b items.
-  int xcd_teams = 0;            // LDC_TEAMS / option "xcd_teams".  OFF by default: built, parity-clean and measured 8-14 % SLOWER than the two-part launch structure (profiles/r05_team_chain_experiments.md)
-  int teams_parts = 1;          // LDC_TEAMS_PARTS: batch parts of an XCD-team decode (experiment: > 1 = one persistent kernel per part, sharing the CUs)
-  int teams_min_b = 16;         // LDC_TEAMS_MINB
-  int teams_max_chain = 16;     // LDC_TEAMS_MAXCHAIN: convs per chain (<= kConvChainMax; 1 = no chaining, team-mode plans only)
   int fuse_gn_epi = 1;          // GroupNorm APPLY in the producing conv's epilogue behind an in-launch per-item wait (LDC_NO_GN_EPI / option "fuse_gn_epi")
   // knobs read from the environment once, at ldc_create (per context, not process-global)
   ConvTune tune;
   int lstm_stream_only = 0;     // LDC_LSTM_STREAM: never use the cooperative LSTM
   int serial_parts = 0;         // LDC_SERIAL: batch parts back to back, eager (diagnostics)
-  int graph_steps = 5;          // LDC_GRAPH_STEPS: denoise steps per replayed graph
+  int graph_steps = 0;          // option "graph_steps": denoise steps per replayed graph (0: by chain count, denoise_loop)
   // plan / graph cache (LRU): a corpus with many distinct lengths must not grow device memory without bound
   uint64_t use_tick = 0, call_tick = 0;
   size_t plan_bytes = 0, plan_bytes_cap = (size_t)48 << 30;   // LDC_PLAN_CACHE_GB

@@ -58,15 +58,14 @@ struct ConvLayer {
 // tuning knobs of the conv launchers; owned by the context (read from the environment once at ldc_create)
 struct ConvTune {
   int force_generic = 0;        // LDC_CONV_V1: every conv on the generic kernel
-  int small_max = 60;           // LDC_CONV_SMALL_TILES: 64x64 tiles up to this many 128x128-equivalents
+  int small_max = 100;          // LDC_CONV_SMALL_TILES: 64x64 tiles up to this many 128x128-equivalents (60 through round 5; with the lean kernel 80-150 measure 0.8-1.2 % faster per decode, 200+ slower: tools/sweep_knobs_r06b.sh)
   int medium_max = 1 << 30;     // LDC_CONV_MEDIUM_TILES: 128x64 tiles up to this many
   int splitk = 1;               // LDC_CONV_SPLITK: 0 off | 1 by layer | 2 | 3
   int sk_tiles = 200, sk_u2 = 24, sk_u3 = 60;   // LDC_SK_TILES / LDC_SK_U2 / LDC_SK_U3
   int m_fastest = 1;            // LDC_CONV_MFAST: 0 N-tile fastest | 1 by operand size | 2 M-tile fastest
   int debug = 0;                // LDC_CONV_DEBUG (bits, see conv_fast.inc)
   int gn_nap = 16, gn_nap0 = 0;  // LDC_GN_NAP / LDC_GN_NAP0: 64-clock naps between the polls of the fused GroupNorm exchange / before the first
-  int force_tile = -1;          // self-check / tuning: 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 256x64 (bf16, k = 3, stride 1) tiles wherever the layer's N allows
-  int tall_min = 0;             // 256 x 64 tiles for k = 3 layers of at least this many 128 x 128 tiles (0: never; LDC_CONV_TALL_TILES)
+  int force_tile = -1;          // self-check / tuning: 0 = 64x64, 1 = 128x64, 2 = 128x128 tiles wherever the layer's N allows
   int lean = 1;                 // round 6: the instruction-diet kernel (conv_lean.inc) where its shapes allow; 0 = conv_fast_kernel everywhere (LDC_CONV_LEAN)
 };
 
@@ -99,14 +98,12 @@ struct ConvCall {
   const float* gn_beta = nullptr;
   const float* gn_ss = nullptr;     // [2 n] scale | shift of the current timestep, or null
   int gn_out = 0;                   // bit 2: tanh after the residual add
-  int io_sc1 = 0;                   // in-launch producer / consumer hints (ConvKArgs::io_sc1)
   unsigned* fail_flag = nullptr;    // host-mapped word raised when the bounded in-launch wait gives up
   float* rowstat_out = nullptr;        // fused apply with residual: per-row (sum, sumsq) partials of the output per 32-column block, [rows][n / 32][2]
   const float* ln_rowstat = nullptr;   // LayerNorm-folded conv (ConvLayer::ln_s): those partials of its input, or null (it reads its rows once more)
   unsigned long long* kst = nullptr;   // timed-mode stamps of this launch (ConvKArgs::kst), pipelined kernel only
   const int* kst_step = nullptr;
   int kst_stride = 0;
-  int m_decide = 0;                 // GEMM rows the tile-shape / split-K decisions are made for (0: B * L_rows); see ConvKArgs::m_decide
   const ConvTune* tune = nullptr;   // null: defaults
   long long* sk_need = nullptr;     // dry run: no launch, *sk_need = split-K workspace floats this call would use
   int* bm_out = nullptr;            // dry run (with sk_need): int[4] = rows per tile of the pipelined kernel (0 when the generic kernel would run), wave rows WM, split-K factor, columns per tile
@@ -114,37 +111,6 @@ struct ConvCall {
 
 hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s);
 long long conv_generic_splitk_floats(const ConvLayer& ly, const ConvCall& c);   // workspace floats a generic_split call of this shape uses (0: it would not split)
-// Two dependent convs (c1 reads c0.y as its input, optionally c0.y2 as its residual; both with the fused GroupNorm apply) as one
-// launch where the pipelined kernel allows it, else back to back.  pair_done: [pair_done_cap] counters on 64-byte lines (16 words each; one per 64 rows of c0's
-// output at least), zeroed before every launch (the step's first kernel does it).
-hipError_t launch_conv_pair(const ConvLayer& ly0, const ConvCall& c0, const ConvLayer& ly1, const ConvCall& c1, unsigned* pair_done,
-                            int pair_done_cap, hipStream_t s);
-// ---- XCD-team chains (round 5; conv_device.h: ChainHead / ChainConv, conv_fast.inc: conv_chain_kernel) ----
-// A run of consecutive convs of the denoise step as one persistent launch: batch items pinned to XCDs, tiles pulled from per-XCD ticket
-// heads, producer -> consumer hand-offs through flags in the XCD's L2.  bf16 engine only.
-struct ChainInfo {        // what the pipelined kernel would do with this conv (shape-only: no pointer is read)
-  bool ok = false;        // runs on the pipelined kernel in a shape the chain kernel contains
-  int variant = -1, bm = 0, bn = 0, ks = 1, ntn = 0;
-  size_t lds = 0;         // dynamic LDS of a tile
-};
-hipError_t conv_chain_info(const ConvLayer& ly, const ConvCall& cc, ChainInfo* out);
-struct ChainConvDesc {
-  const ConvLayer* ly = nullptr;
-  ConvCall cc;                      // sk_part / sk_count: this conv's OWN team-major workspace; m_decide as planned
-  int dep[3] = {-1, -1, -1};        // producers of x1 (and its row statistics), x2, residual inside the chain, or -1
-  unsigned* flags = nullptr;        // [8 teams][team_words] epoch-tagged tile flags (zeroed once at plan creation)
-  unsigned team_words = 0;
-  int sk_team_tiles = 0;
-};
-size_t conv_chain_table_bytes(int nconv);
-static constexpr int kConvChainMax = 16;
-// fills the device table (synchronous upload) for convs[0..n); flags_base: the address every ChainConvDesc::flags is an offset of
-// stamps (tuning aid, may be null): [8][stamp_team_stride][12] u64; first_out (may be null): int[8][kConvChainMax + 1] per-team first tickets
-hipError_t conv_chain_build(const ChainConvDesc* convs, int n, int B, unsigned* heads, unsigned* flags_base, const int* step_state, unsigned* fail_flag,
-                            void* table_dev, size_t* lds_out, unsigned long long* stamps = nullptr, int stamp_team_stride = 0, int* first_out = nullptr);
-hipError_t launch_conv_chain(const void* table_dev, size_t lds, int grid, hipStream_t s);
-int conv_chain_blocks_per_cu(size_t lds);
-
 size_t conv_packed_weight_bytes(const ConvLayer& ly);
 // host-side packers (fp32 [Cout][Cin][k] or, transposed, [Cin][Cout][k]) -> packed image in ly.dt
 void pack_conv_weights(const ConvLayer& ly, const float* w_oik, void* dst_host);

@@ -404,7 +404,7 @@ static bool convmm_ok(int Lin, int Lout) { return !g_train_valu && Lin >= 16 && 
 // chip.  Measured on the full-width step (32 x 2.4 s): 125.1 ms against 122.5 ms with 64 x 64 tiles everywhere -- the kernel is not
 // bound by its loads per MFMA (the fp32 MFMA is 64 cycles; eight resident workgroups per CU cover the rest), so the default stays.
 static bool convmm_big(int M, int N, long tiles_other) {
-  static const bool on = getenv("LDC_TRAIN_BIG_TILES") != nullptr;
+  const bool on = false;   // (measured slower, see above; the variant stays compiled for the exact-fp32 path's probes)
   if (!on) return false;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * tiles_other;
   const double fill = (double)M * N / ((double)((M + 127) / 128 * 128) * ((N + 127) / 128 * 128));

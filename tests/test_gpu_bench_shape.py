@@ -272,13 +272,9 @@ def test_device_noise_advances_per_call_and_reseeds():
 def test_plan_cache_is_bounded():
     """Many distinct (B, L) shapes (a corpus of different lengths): the LRU plan cache evicts instead of growing; a
     re-used shape still decodes identically after its plan was evicted and rebuilt."""
-    import os
     mc, u, _ = CASES["r84"]
-    os.environ["LDC_PLAN_CACHE_N"] = "8"
-    try:
-        e = Engine(mc, u, COND_CFG, dtype="f32")
-    finally:
-        del os.environ["LDC_PLAN_CACHE_N"]
+    e = Engine(mc, u, COND_CFG, dtype="f32")
+    e.set_option("plan_cache_n", 8)
     e.load_state_dict(L.MODEL_MAIN, main_sd_np("r84"))
     e.load_state_dict(L.MODEL_COND, cond_sd_np())
     e.finalize(strict=True)
@@ -402,50 +398,16 @@ def test_fused_gn_epilogue_equals_the_separate_gn_apply(dtype):
             got = e.unet_forward(x, 211, cond).cpu().numpy()
             err = rel(got, ref)
             assert err < (2e-5 if dtype == "f32" else TOL[dtype]["eps_bench"]), (dtype, rep, err)
-        # the chained form (block1's and block2's convs in one launch, per-M-tile hand-off inside the launch; off by default) and
         # the unfolded res_conv / PreNorm LayerNorm give the same tensor again
-        for opt, val in (("chain_convs", 1), ("fold_res", 0), ("fold_ln", 0)):
+        for opt, val in (("fold_res", 0), ("fold_ln", 0)):
             e.set_option(opt, val)
             got = e.unet_forward(x, 211, cond).cpu().numpy()
             e.set_option(opt, 1 - val)
             assert rel(got, ref) < (2e-5 if dtype == "f32" else TOL[dtype]["eps_bench"]), (dtype, opt, rel(got, ref))
     finally:
         e.set_option("fuse_gn_epi", 1)
-        e.set_option("chain_convs", 0)
         e.set_option("fold_res", 1)
         e.set_option("fold_ln", 1)
-
-
-# ------------------------------------------------------------------------------------------- XCD-team chains (round 5, opt-in)
-def test_xcd_team_chains_equal_the_separate_launches():
-    """Round 5: runs of consecutive convs of the step as ONE persistent launch each, batch items pinned to XCDs, producer ->
-    consumer hand-offs through flags in the XCD's L2 (conv_fast.inc: conv_chain_kernel; unet.py:422-469 is what a step computes).
-    Off by default (measured slower, profiles/r05_team_chain_experiments.md) but kept correct: the same eps as the separate
-    launches at the bench grid -- every product is accumulated in the same order, only the partition of the GroupNorm statistics
-    into tiles differs -- over several passes (the tile flags carry the epoch of the pass and are never cleared), against the
-    reference fixture as well, and the bounded waits must not have given up (unet_forward raises on the device-side flag)."""
-    e, mc, u, cc, sd, _ = full_engine("c2", "bf16")
-    B, Lz, F = 32, 1200, 120
-    g = torch.Generator().manual_seed(47)
-    x = (torch.randn(B, 128, Lz, generator=g) * 0.7).cuda()
-    cond = torch.randn(B, 128, F, generator=g).cuda()
-    try:
-        ref = e.unet_forward(x, 211, cond).cpu().numpy()
-        e.set_option("xcd_teams", 1)
-        for rep in range(3):
-            got = e.unet_forward(x, 211, cond).cpu().numpy()
-            assert np.isfinite(got).all()
-            assert rel(got, ref) < TOL["bf16"]["eps_bench"], (rep, rel(got, ref))
-        # a ragged batch: teams with different item counts (20 items: 2 3 2 3 2 3 2 3), and one below the team threshold (13: the separate launches)
-        for Bs in (13, 20):
-            e.set_option("xcd_teams", 0)
-            r2 = e.unet_forward(x[:Bs], 37, cond[:Bs]).cpu().numpy()
-            e.set_option("xcd_teams", 1)
-            g2 = e.unet_forward(x[:Bs], 37, cond[:Bs]).cpu().numpy()
-            assert rel(g2, r2) < TOL["bf16"]["eps_bench"], (Bs, rel(g2, r2))
-    finally:
-        e.set_option("xcd_teams", 0)
-    e.close()
 
 
 # ------------------------------------------------------------------------------------------- part streams chosen by measured overlap (round 5)

@@ -470,7 +470,7 @@ def test_bench_workload_items_against_oracle(dtype):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_conv_fast_every_tile_shape_against_generic_kernel(dtype):
     """ldc_conv_compare: the same layer and pseudo-random operands through conv_fast.inc with every tile shape forced
-    (64x64, 128x64, 128x128, 256x64, and the launcher's own choice incl. split-K) and through the generic kernel (conv_gemm.hip, which
+    (64x64, 128x64, 128x128, and the launcher's own choice incl. split-K) and through the generic kernel (conv_gemm.hip, which
     the SConv1d vectors of the reference pin): outputs, fused GroupNorm statistics (unet.py:142-147), fused k column maxima
     (unet.py:214) and the residual epilogue.  Shapes: the UNet's layer classes incl. two-input (concatenated) convs, k = 1/3/4/7,
     stride 2, folded nearest upsampling, ragged row counts (B * L not a multiple of any tile)."""
@@ -485,7 +485,7 @@ def test_conv_fast_every_tile_shape_against_generic_kernel(dtype):
         (600, 256, 0, 512, 4, 2, 0), (75, 1024, 0, 1024, 3, 1, 1), (77, 256, 0, 128, 1, 1, 0), (53, 512, 0, 512, 3, 1, 0),
     ]
     for Lx, c1, c2, co, k, st, ups in shapes:
-        for cfg in (-1, 0, 1, 2, 3):       # (3: the 256 x 64 tiles where LDC_FAST_TALL is compiled in -- elsewhere the launcher's own choice)
+        for cfg in (-1, 0, 1, 2):
             for B in (3, 16):
                 if B == 16 and (cfg != -1 or Lx > 300):
                     continue

@@ -329,7 +329,7 @@ def test_split_bf16_step_is_bit_reproducible(gemm):
 
 
 def test_plain_bf16_option_is_bf16_class_and_off_by_default(gemm):
-    """option train_bf16 (LDC_TRAIN_BF16): the GEMM shapes with one bf16 MFMA per product (no lo terms) -- an opt-in for runs that accept
+    """option train_bf16: the GEMM shapes with one bf16 MFMA per product (no lo terms) -- an opt-in for runs that accept
     autocast-class numerics; errors must be bf16-class (2^-9 products: 1e-4 .. 2e-2 of the maximum), and fp32-class again once it is off."""
     if gemm != "split_bf16":
         pytest.skip("an option of the split-bf16 kernels")
@@ -512,7 +512,7 @@ def test_full_width_training_step_reference_vectors(gemm):
 
 
 def test_graphed_optimisation_step_equals_the_eager_one():
-    """Round 5: the optimisation step replayed from one hipGraph (DiffusionTrainer.use_graph / LDC_TRAIN_GRAPH=1: the first step of a shape
+    """Round 5: the optimisation step replayed from one hipGraph (DiffusionTrainer.use_graph: the first step of a shape
     eager, the second captured over static input buffers, the rest replayed; Adam's step count on the device) against the same
     steps issued layer by layer: different inputs every step (the static buffers are refreshed), same losses and parameters
     (srcs/train.py:110-177 is the loop both stand for)."""

@@ -25,12 +25,12 @@ leanab)   # the lean kernel against conv_fast_kernel: hot microbenchmark with pe
   for LEAN in 0 1; do
     for SH in "${SHAPES[@]}" "600 512 0 512 3 1 0" "75 1024 1024 1024 1 1 0" "150 512 0 512 3 1 0"; do
       echo "== lean=$LEAN $SH" >> $O/leanab.txt
-      LDC_CONV_LEAN=$LEAN LDC_B=16 LDC_CONV_STAMPS=1 timeout 120 python tools/conv_one.py $SH 50 >> $O/leanab.txt 2>&1
+      LDC_OPTIONS=conv_lean=$LEAN LDC_B=16 LDC_CONV_STAMPS=1 timeout 120 python tools/conv_one.py $SH 50 >> $O/leanab.txt 2>&1
     done
   done
   grep -v "XCC\|workgroup %" $O/leanab.txt
   for LEAN in 0 1 0 1; do
-    LDC_CONV_LEAN=$LEAN timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pipelined --no-roofline > $O/benchq_lean$LEAN.json 2> $O/benchq_lean$LEAN.err
+    LDC_OPTIONS=conv_lean=$LEAN timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pipelined --no-roofline > $O/benchq_lean$LEAN.json 2> $O/benchq_lean$LEAN.err
     python -c "import json; d=json.load(open('$O/benchq_lean$LEAN.json')); print('lean=$LEAN', round(d['value'],1), round(d['ms_per_step'],2))"
   done ;;
 micro)   # hot microbenchmark of the five shape classes at B = 16 (one batch part), with the per-workgroup stamps
