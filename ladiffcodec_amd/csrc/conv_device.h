@@ -53,6 +53,8 @@ struct ConvKArgs {
   int gn_groups, gn_cpg;
   unsigned* colmax;    // fused column max over positions (LinearAttention k softmax): ordered-uint keys, pre-zeroed
   int colmax_lo, colmax_hi, colmax_stride;   // columns [lo, hi) -> colmax[b * stride + col - lo]
+  float* qkv_ctx_ws;       // LinearAttention context accumulated by the to_qkv launch itself (ConvCall::qkv_ctx_ws; lean kernel only) or null
+  int qkv_ctx_stride;
   // split-K (fast kernel, few-tile long-K layers): ksplit workgroups per tile each take a slice of the units, park
   // their fp32 partial tile in sk_part and the last one to arrive (sk_count) sums them and runs the epilogue
   int ksplit;

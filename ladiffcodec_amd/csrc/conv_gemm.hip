@@ -452,6 +452,7 @@ static hipError_t conv_kargs(const ConvLayer& ly, const ConvCall& c, ConvKArgs& 
   a.gn_sum = nullptr; a.gn_groups = 0; a.gn_cpg = 1;
   a.colmax = c.colmax; a.colmax_lo = c.colmax_lo; a.colmax_hi = c.colmax_hi; a.colmax_stride = c.colmax_stride;
   if (ly.tr_stride) a.colmax = nullptr;
+  a.qkv_ctx_ws = c.qkv_ctx_ws; a.qkv_ctx_stride = c.qkv_ctx_stride;
   a.ksplit = 1; a.sk_part = c.sk_part; a.sk_count = c.sk_count; a.sk_part_cap = c.sk_part_cap; a.sk_count_cap = c.sk_count_cap;
   a.tune = c.tune; a.sk_need = c.sk_need; a.bm_out = c.bm_out;
   if (c.bm_out) { c.bm_out[0] = 0; c.bm_out[1] = 0; c.bm_out[2] = 1; c.bm_out[3] = 0; }
@@ -531,6 +532,7 @@ hipError_t launch_conv(const ConvLayer& ly, const ConvCall& c, hipStream_t s) {
     if (e != hipSuccess || launched) return e;
   }
   if (c.sk_need) return hipSuccess;   // dry run: the generic kernel never splits K
+  if (c.qkv_ctx_ws) return hipErrorInvalidValue;   // (the context fold exists only on the lean kernel; the planner asks for it only there)
   if (c.gn_part || c.y2 || ly.ln_s) return hipErrorInvalidValue;   // (the planner asks bm_out first)   // the fused GroupNorm apply exists only on the pipelined kernel (the planner checks bm_out)
   if (ly.dt == DT_FP8) return hipErrorInvalidValue;   // fp8 inputs exist only on the pipelined kernel (the planner checks eligibility)
   a.win_rows = std::min(span, c.B * c.L_in) + 1;

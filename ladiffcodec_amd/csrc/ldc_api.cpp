@@ -443,6 +443,21 @@ static int build_attn(ldc_ctx* c, WeightReader& wr, const std::string& p, int di
     }
     LDCCHK(make_conv(c, sq, w2.data(), nullptr, &a->qkv_ln));
     LDCCHK(c->wmem.upload(&a->qkv_ln.ln_s, sn));
+    if (linear && c->dt == DT_BF16 && hidden == 128 && c->unet.dim_head == 32) {
+      // the same layer with its output channels ordered q | (k_h v_h) x heads: a 64-column tile then holds k and v of ONE head (context fold)
+      std::vector<float> wp((size_t)N3 * dim), sp((size_t)N3);
+      for (int n = 0; n < N3; ++n) {
+        int src = n;
+        if (n >= hidden) {
+          const int t = n - hidden, h = t / 64, w = t % 64;
+          src = (w < 32 ? hidden : 2 * hidden) + h * 32 + (w & 31);
+        }
+        memcpy(&wp[(size_t)n * dim], &w2[(size_t)src * dim], (size_t)dim * sizeof(float));
+        sp[n] = sn[src];
+      }
+      LDCCHK(make_conv(c, sq, wp.data(), nullptr, &a->qkv_ctx));
+      LDCCHK(c->wmem.upload(&a->qkv_ctx.ln_s, sp));
+    }
   }
   ConvSpec so;
   so.dt = c->dt; so.cin1 = hidden; so.cout = dim; so.k = 1;
@@ -836,6 +851,7 @@ static bool find_option(ldc_ctx* c, const std::string& n, OptRef* r) {
   LDC_OPT("fuse_kmax", c->fuse_kmax, true, 0, 1)
   LDC_OPT("fuse_ln", c->fuse_ln, true, 0, 1)
   LDC_OPT("fuse_attn_tail", c->fuse_attn_tail, true, 0, 1)
+  LDC_OPT("fold_ctx", c->fold_ctx, true, 0, 1)                     // LinearAttention context inside to_qkv's epilogue (lean kernel, bf16)
   // conv launchers (ConvTune)
   LDC_OPT("conv_lean", c->tune.lean, true, 0, 1)                  // conv_lean_kernel where its shapes allow; 0 = conv_fast_kernel (A/B)
   LDC_OPT("conv_generic", c->tune.force_generic, true, 0, 1)      // every conv on the generic kernel
@@ -1361,6 +1377,8 @@ struct PlanBuilder {
   }
   std::string info;   // description of the next op added
   void* y2_next = nullptr;   // second output of the next conv added (a layer with a folded 1x1 conv)
+  float* qkv_ctx_next = nullptr;   // context workspace of the next conv added (to_qkv with the context fold)
+  int qkv_ctx_stride_next = 0;
   const float* ln_rowstat_next = nullptr;   // row-statistics partials of the next (LayerNorm-folded) conv's input
   bool want_rowstat = false;                // the next resnet()'s fused block2 conv leaves those partials of its output ...
   float* last_rowstat = nullptr;            // ... here (null when it could not)
@@ -1405,6 +1423,7 @@ struct PlanBuilder {
     cc.B = B; cc.L_in = L_in; cc.L_rows = L_out; cc.x1 = x1; cc.x2 = x2; cc.y = y; cc.residual = residual; cc.y_ld = ly.n;
     cc.gn_sum = gn_sum; cc.gn_groups = gn_sum ? c->unet.groups : 0;
     cc.y2 = y2_next; y2_next = nullptr;
+    cc.qkv_ctx_ws = qkv_ctx_next; cc.qkv_ctx_stride = qkv_ctx_stride_next; qkv_ctx_next = nullptr; qkv_ctx_stride_next = 0;
     cc.ln_rowstat = ly.ln_s ? ln_rowstat_next : nullptr; ln_rowstat_next = nullptr;
     if (pl->kst && pl->step_ops.size() < (size_t)kKstOps) {
       cc.kst = pl->kst + pl->step_ops.size() * 2; cc.kst_stride = kKstOps * 2; cc.kst_step = pl->step_state;
@@ -1429,7 +1448,7 @@ struct PlanBuilder {
     {
       char buf[96];
       snprintf(buf, sizeof(buf), "k%d%s_s%d_u%d_c%d+%d->%d_L%d%s%s", ly.taps, ly.wtaps ? "+res" : "", ly.stride, ly.ups, ly.cin1, ly.cin2, ly.n, L_out,
-               (ge && ge->part) ? (residual ? "_gnapply+res" : "_gnapply") : (gn_sum ? "_gn" : ""), colmax ? "_kmax" : "");
+               (ge && ge->part) ? (residual ? "_gnapply+res" : "_gnapply") : (gn_sum ? "_gn" : ""), colmax ? "_kmax" : (cc.qkv_ctx_ws ? "_ctx" : ""));
       info = buf;
     }
     const double cbytes = ((double)B * L_in * (ly.cin1 + ly.cin2) + (double)B * L_out * ly.n * (((ge && ge->part && residual) ? 2 : 1) + (ly.wtaps ? 1 : 0))) * es + (double)conv_packed_weight_bytes(ly);
@@ -1592,10 +1611,16 @@ struct PlanBuilder {
     if (linear) {
       const size_t wss = linattn_ws_floats_per_item(H, Dh);
       if (c->fuse_kmax && c->fuse_attn_tail && !a.out.w8 && linattn_tail_supported(dt, H, Dh, a.dim)) {
-        // three launches: qkv conv (+ k column max) -> context -> tail (out, to_out conv, LayerNorm, + x)
+        // three launches: qkv conv (+ k column max) -> context -> tail (out, to_out conv, LayerNorm, + x); round 6: TWO where to_qkv
+        // accumulates the context itself (lean kernel, bf16, folded PreNorm: ConvCall::qkv_ctx_ws)
         ln_rowstat_next = rowstat;
-        conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
-        add([=](hipStream_t s) { return launch_linattn_ctx(dt, qkv, ws, Bn, L, H, Dh, s); }, false, 0, LDC_CLASS_LINATTN, 2.0 * rows * hid * es);
+        if (lnf && c->fold_ctx && c->tune.lean && !c->tune.force_generic && dt == DT_BF16 && a.qkv_ctx.w && hid == 128 && a.dim % 64 == 0) {
+          qkv_ctx_next = ws; qkv_ctx_stride_next = (int)wss;
+          conv(a.qkv_ctx, xn, nullptr, qkv, nullptr, L, L);
+        } else {
+          conv(qkv_ly, xn, nullptr, qkv, nullptr, L, L, nullptr, reinterpret_cast<unsigned*>(ws), hid, 2 * hid, (int)wss);
+          add([=](hipStream_t s) { return launch_linattn_ctx(dt, qkv, ws, Bn, L, H, Dh, s); }, false, 0, LDC_CLASS_LINATTN, 2.0 * rows * hid * es);
+        }
         const int dim = a.dim;
         info = "tail_c" + std::to_string(dim) + "_L" + std::to_string(L) + "_B" + std::to_string(B);
         add([=](hipStream_t s) {

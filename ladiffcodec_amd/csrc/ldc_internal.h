@@ -142,6 +142,7 @@ struct LinAttnW {
   ConvLayer qkv, out;
   ConvLayer qkv_f8;             // to_qkv with fp8 inputs (see ResnetW::c2_f8)
   ConvLayer qkv_ln;             // to_qkv with the PreNorm LayerNorm folded in (ConvLayer::ln_s; bf16 / f32 weights only)
+  ConvLayer qkv_ctx;            // ... with its output columns ordered q | (k_h v_h) x heads for the context fold (ConvCall::qkv_ctx_ws; bf16 engine)
   float* out_g = nullptr;       // null for the bottleneck Attention
   int dim = 0;
 };
@@ -298,6 +299,7 @@ struct ldc_ctx {
   int xcd_resident[2] = {0, 0};
   int coop_resident[2] = {0, 0};   // [H == 512]: the cooperative LSTM's H/4 workgroups fit the device together (asked at ldc_create)
   int fuse_attn_tail = 1;       // LinearAttention out + to_out conv + LayerNorm + residual in one launch (bf16 engine)
+  int fold_ctx = 1;             // round 6, option "fold_ctx": the LinearAttention context accumulated by to_qkv's own epilogue (lean kernel, bf16, folded PreNorm): no context launch, no k column max, k and v never written
   // Flow control of the step-graph replays: with more than ~10-20 multi-thousand-node graph launches outstanding the ROCm 7.2
   // runtime's enqueue path degrades (a decode queued behind a running one took 247 instead of 157 ms), so a replay waits on
   // the host until the replay `flow_depth` launches before it has finished (an event of this context, never a device sync)

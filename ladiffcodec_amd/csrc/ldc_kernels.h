@@ -84,6 +84,11 @@ struct ConvCall {
   int gn_groups = 0;
   unsigned* colmax = nullptr; // optional fused per-item column max, columns [colmax_lo, colmax_hi), pre-zeroed keys
   int colmax_lo = 0, colmax_hi = 0, colmax_stride = 0;
+  // LinearAttention context inside to_qkv (round 6, lean kernel, bf16): the layer's output columns are ordered q | (k_h v_h) x heads, the
+  // q tiles are stored, a (k_h | v_h) tile accumulates exp(k)^T v and the column sums of exp(k) into the item's workspace
+  // (qkv_ctx_ws + item * qkv_ctx_stride floats: kmax keys [HD] (unused) | ksum [HD] | ctx [H][D][D], zeroed every step) and stores nothing
+  float* qkv_ctx_ws = nullptr;
+  int qkv_ctx_stride = 0;
   float* sk_part = nullptr;   // optional split-K workspace (fp32 partial tiles) and arrival counters (pre-zeroed)
   unsigned* sk_count = nullptr;
   long long sk_part_cap = 0;  // floats

@@ -566,3 +566,31 @@ def test_lean_conv_kernel_gives_the_same_unet_as_conv_fast_kernel(dtype):
                 assert rel(e.debug_tap(n, shp).cpu().numpy(), rt) < tol_tap, (dtype, n)
     finally:
         e.set_option("conv_lean", 1)
+
+
+# ------------------------------------------------------------------------------------------- LinearAttention context inside to_qkv (round 6)
+@pytest.mark.gpu
+def test_context_fold_gives_the_same_unet_as_the_context_launch():
+    """Round 6: to_qkv's own epilogue accumulates the LinearAttention context (srcs/modules/unet.py:208-216: k.softmax over positions, then
+    einsum('b h d n, b h e n -> b h d e')) -- the layer's output columns are ordered q | (k_h v_h) per head, a (k_h | v_h) tile multiplies
+    exp(k)^T v on the MFMA and adds context and column sums to the item's workspace; the softmax shift is 0 instead of the column maximum
+    (shift-invariant; exp is clamped at 60).  No context launch, no column-max pass, k and v are never written.  Option fold_ctx 0
+    restores the three-launch form: eps and the interior taps at the bench grid (every level's attention block, tiles straddling items
+    at L = 75 / 150) must agree within the bf16 drift; a ragged batch as well.  The reference-pinned tests above run with the fold on."""
+    dtype = "bf16"
+    e, mc, u, cc, sd, _ = full_engine("c2", dtype)
+    B, Lz, F = 32, 1200, 120
+    g = torch.Generator().manual_seed(59)
+    x = (torch.randn(B, 128, Lz, generator=g) * 0.7).cuda()
+    cond = torch.randn(B, 128, F, generator=g).cuda()
+    try:
+        for Bs, t in ((32, 211), (13, 37)):
+            e.set_option("fold_ctx", 0)
+            ref = e.unet_forward(x[:Bs], t, cond[:Bs]).cpu().numpy()
+            e.set_option("fold_ctx", 1)
+            for rep in range(2):      # (the workspace is re-zeroed by every step's first kernel)
+                got = e.unet_forward(x[:Bs], t, cond[:Bs]).cpu().numpy()
+                assert np.isfinite(got).all()
+                assert rel(got, ref) < 0.5 * TOL[dtype]["eps_bench"], (Bs, rep, rel(got, ref))
+    finally:
+        e.set_option("fold_ctx", 1)
