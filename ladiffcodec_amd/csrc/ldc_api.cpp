@@ -716,8 +716,8 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   }
   // Every knob of the library is an OPTION (one table: find_option below; tools/README.md lists them): ldc_set_option at run time, or
   // LDC_OPTIONS="name=value,name=value" in the environment at ldc_create (round 6: ~50 separate LDC_* variables before).
-  c->xcd_resident[0] = lstm_xcd_resident(256) ? 1 : 0;
-  c->xcd_resident[1] = lstm_xcd_resident(512) ? 1 : 0;
+  c->xcd_resident[0] = lstm_xcd_resident(256);
+  c->xcd_resident[1] = lstm_xcd_resident(512);
   c->coop_resident[0] = lstm_coop_resident(256) ? 1 : 0;
   c->coop_resident[1] = lstm_coop_resident(512) ? 1 : 0;
   c->plan_bytes_cap = (size_t)48 << 30;
@@ -1115,7 +1115,7 @@ int run_seanet(SeaRun& R, const std::vector<SeaOp>& ops, const void* x_in, int L
             HIPCHK(launch_conv(op.lstm[n].in_proj, cc, R.s));
             const bool lastl = n + 1 == op.lstm.size();
             hipError_t le = hipErrorCooperativeLaunchTooLarge;
-            if (coop) le = launch_lstm_coop(DT_F32, pre, op.lstm[n].w_rm, o, lastl ? x : nullptr, R.B, L, H, lws, R.c->dev_flag_dev, (R.c->lstm_xcd && R.c->xcd_resident[H == 512 ? 1 : 0]) ? 2 : R.c->coop_launch, R.s);
+            if (coop) le = launch_lstm_coop(DT_F32, pre, op.lstm[n].w_rm, o, lastl ? x : nullptr, R.B, L, H, lws, R.c->dev_flag_dev, (R.c->lstm_xcd && R.c->xcd_resident[H == 512 ? 1 : 0] >= 2 * R.teams) ? 2 : R.c->coop_launch, R.s);
             if (le == hipErrorCooperativeLaunchTooLarge) {   // (or not eligible): one workgroup per item, W_hh streamed from L2
               (void)hipGetLastError();
               le = launch_lstm_layer(DT_F32, pre, op.lstm[n].w_hh, o, lastl ? x : nullptr, R.B, L, H, R.s);
@@ -1247,9 +1247,10 @@ extern "C" int ldc_rvq_decode(ldc_ctx* c, const int64_t* codes, int B, int F, in
 
 // encoder -> RVQ, rows stay channels-last in between; returns the quantized rows pointer (scratch)
 static int get_cond_rows(ldc_ctx* c, const float* wav, int B, int T, float bandwidth, Arena& ar, bool dry, hipStream_t s,
-                         float** q_rows, int* F_out, int64_t* codes_out) {
+                         float** q_rows, int* F_out, int64_t* codes_out, int teams = 1) {
   const Codec& cd = c->codec[LDC_MODEL_COND];
   SeaRun R{c, &ar, s, dry, B};
+  R.teams = teams;
   void* z = nullptr;
   int F = 0, C = 0;
   LDCCHK(run_seanet(R, cd.enc, wav, T, &z, &F, &C));
@@ -2510,7 +2511,7 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
       const int b0 = split_ends ? h.b0[k] : 0, Bk = split_ends ? h.p[k]->B : B;
       float* qr = nullptr;
       int Fq = 0;
-      LDCCHK(get_cond_rows(c, wav + (size_t)b0 * T, Bk, T, 0.f, ar, dry, sk, &qr, &Fq, codes_out));
+      LDCCHK(get_cond_rows(c, wav + (size_t)b0 * T, Bk, T, 0.f, ar, dry, sk, &qr, &Fq, codes_out, n_front));
       if (!dry && Fq != F) return fail(LDC_E_INVALID, "internal: encoder produced %d frames, expected %d", Fq, F);
       // start image: upsample, /= max|.|+1e-8 (sample.py:125-129)
       void* up = nullptr;
@@ -2554,6 +2555,7 @@ extern "C" int ldc_decode(ldc_ctx* c, const float* wav, int B, int T, int n_step
       const int b0 = split_ends ? h.b0[k] : 0, Bk = split_ends ? h.p[k]->B : B;
       SeaRun R{c, &ar, sk, dry, Bk};
       R.side = h.n <= 2 ? k : -1;   // (aux_stream[2], [3] are free when the batch has at most two parts)
+      R.teams = h.n;
       void* zc = ar.alloc((size_t)Bk * L * D * 4);
       if (!dry) HIPCHK(launch_to_cl(DT_F32, x + (size_t)b0 * D * L, zc, Bk, D, L, nullptr, 0, 0.f, sk));
       void* y = nullptr;

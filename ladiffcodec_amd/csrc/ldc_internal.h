@@ -296,7 +296,7 @@ struct ldc_ctx {
   int lstm_xcd = 1;             // LDC_LSTM_XCD / option "lstm_xcd": the cooperative LSTM of ONE or TWO items on sixteen 1024-thread workgroups of one XCD, the
                                 // hidden-state exchange through that XCD's L2 (seanet.hip: lstm_xcd_kernel; configs[0]: 2.6 instead of 3.3 ms per clip); a
                                 // device-side failure of it switches the context back to the placement-independent kernel
-  int xcd_resident[2] = {0, 0};
+  int xcd_resident[2] = {0, 0};   // teams of the XCD-local LSTM one XCD holds (H = 256, 512)
   int coop_resident[2] = {0, 0};   // [H == 512]: the cooperative LSTM's H/4 workgroups fit the device together (asked at ldc_create)
   int fuse_attn_tail = 1;       // LinearAttention out + to_out conv + LayerNorm + residual in one launch (bf16 engine)
   int fold_ctx = 1;             // round 6, option "fold_ctx": the LinearAttention context accumulated by to_qkv's own epilogue (lean kernel, bf16, folded PreNorm): no context launch, no k column max, k and v never written
@@ -425,6 +425,7 @@ struct SeaRun {   // measures or runs a SEANet stack
   bool dry;
   int B;
   int side = -1;   // 0 / 1: aux_stream[2 + side] and lstm_ev[side] may carry the second stage of the two-layer LSTM pipeline (run_seanet)
+  int teams = 1;   // batch parts whose codec ends may be in flight together: the XCD-local LSTM wants room for twice that many teams on its XCD
 };
 
 // ldc_api.cpp

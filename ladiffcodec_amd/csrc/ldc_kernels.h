@@ -246,7 +246,7 @@ size_t lstm_coop_ws_bytes(int H);
 // (the caller falls back to launch_lstm_layer).
 bool lstm_coop_resident(int H);
 // the XCD-local form (launch_lstm_coop with coop_launch == 2) fits one XCD
-bool lstm_xcd_resident(int H);
+int lstm_xcd_resident(int H);   // teams of sixteen workgroups one XCD holds
 // occupancy query x CU count (with a margin) >= the H/4 workgroups that must be co-resident
 hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* out, const void* skip, int B, int T, int H,
                             void* ws, unsigned* host_flag, int coop_launch, hipStream_t s);

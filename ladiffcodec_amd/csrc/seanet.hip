@@ -620,17 +620,19 @@ static hipError_t lstm_coop_launch(const void* pre, const float* w_rm, void* out
 }
 
 bool lstm_coop_eligible(int H) { return H == 256 || H == 512; }
-// the XCD-local form needs its sixteen 1024-thread workgroups resident on one XCD (32 CUs)
-bool lstm_xcd_resident(int H) {
-  if (!lstm_coop_eligible(H)) return false;
+// the XCD-local form needs its sixteen 1024-thread workgroups resident on one XCD (32 CUs): how many such teams fit on one XCD (0 = none).
+// The caller asks for room for twice the teams it may have in flight (batch parts run their codec ends concurrently).
+int lstm_xcd_resident(int H) {
+  if (!lstm_coop_eligible(H)) return 0;
   const void* fn = H == 512 ? reinterpret_cast<const void*>(lstm_xcd_kernel<float, 512>) : reinterpret_cast<const void*>(lstm_xcd_kernel<float, 256>);
   int per_cu = 0, cus = 0, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 1024, 0) != hipSuccess) {
     (void)hipGetLastError();
-    return false;
+    return 0;
   }
-  return cus % 8 == 0 && per_cu >= 1 && cus / 8 >= 16;
+  if (cus % 8 != 0 || per_cu < 1) return 0;
+  return per_cu * (cus / 8) / 16;
 }
 
 // Can the H/4 workgroups of the cooperative kernel be resident together on the current device?  Asked once per context

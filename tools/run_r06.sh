@@ -61,14 +61,15 @@ prof)
   python tools/prof_summary.py $(find $O/prof -name "*.db" | head -1) > $O/kernel_stats.md
   find $O/prof -name "*.db" -size +30M -delete
   head -30 $O/kernel_stats.md ;;
-pmc)
-  rm -rf $O/pmc_FETCH $O/pmc_WRITE
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_FETCH -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipelined > $O/pmc_FETCH.log 2>&1)
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_WRITE -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipelined > $O/pmc_WRITE.log 2>&1)
-  python tools/pmc_traffic.py $O/pmc_FETCH $O/pmc_WRITE $O/conv_traffic.json
-  python tools/pmc_classes.py $O/pmc_FETCH $O/pmc_WRITE $O/conv_pmc_classes.md > /dev/null
-  find $O/pmc_FETCH $O/pmc_WRITE -name "*.csv" -size +20M -delete
-  cat $O/conv_traffic.json ;;
+pmc)   # PMC_TAG=_nosk LDC_OPTIONS=conv_splitk=0 bash tools/run_r06.sh pmc : the same passes under other options, files with the tag
+  G=${PMC_TAG:-}
+  rm -rf $O/pmc_FETCH$G $O/pmc_WRITE$G
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_FETCH$G -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipelined > $O/pmc_FETCH$G.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_WRITE$G -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipelined > $O/pmc_WRITE$G.log 2>&1)
+  python tools/pmc_traffic.py $O/pmc_FETCH$G $O/pmc_WRITE$G $O/conv_traffic$G.json
+  python tools/pmc_classes.py $O/pmc_FETCH$G $O/pmc_WRITE$G $O/conv_pmc_classes$G.md > /dev/null
+  find $O/pmc_FETCH$G $O/pmc_WRITE$G -name "*.csv" -size +20M -delete
+  cat $O/conv_traffic$G.json ;;
 timed)
   timeout 600 python tools/timed_mode_stats.py > $O/timed_mode_kernel_stats.md 2> $O/timed_mode.err; head -12 $O/timed_mode_kernel_stats.md ;;
 configs)   # the other BASELINE configs (builder-run lines)
