@@ -2,4 +2,5 @@
 #define LDC_FAST_T __bf16
 #define LDC_FAST_NS fast_bf16
 #define LDC_FAST_ENTRY launch_conv_fast_bf16
+#define LDC_FAST_RESIDENCY conv_wgs_per_cu_bf16
 #include "conv_fast.inc"

@@ -3,4 +3,5 @@
 #define LDC_FAST_NS fast_bf16w8
 #define LDC_FAST_ENTRY launch_conv_fast_bf16w8
 #define LDC_FAST_W8 1
+#define LDC_FAST_RESIDENCY conv_wgs_per_cu_bf16w8
 #include "conv_fast.inc"

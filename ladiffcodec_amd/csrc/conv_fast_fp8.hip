@@ -4,4 +4,5 @@
 #define LDC_FAST_T fast_fp8::fp8_tag
 #define LDC_FAST_NS fast_fp8
 #define LDC_FAST_ENTRY launch_conv_fast_fp8
+#define LDC_FAST_RESIDENCY conv_wgs_per_cu_fp8
 #include "conv_fast.inc"

@@ -695,6 +695,7 @@ extern "C" int ldc_create(const ldc_config* cfg, int device, ldc_ctx** out) {
   std::unique_ptr<ldc_ctx> c(new ldc_ctx());
   c->cfg = *cfg;
   c->device = device;
+  c->num_cus = prop.multiProcessorCount;
   c->dt = cfg->compute_dtype == LDC_F32 ? DT_F32 : DT_BF16;
   c->w8 = cfg->compute_dtype == LDC_BF16_W8;
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -856,14 +857,14 @@ static bool find_option(ldc_ctx* c, const std::string& n, OptRef* r) {
   LDC_OPT("conv_lean", c->tune.lean, true, 0, 1)                  // conv_lean_kernel where its shapes allow; 0 = conv_fast_kernel (A/B)
   LDC_OPT("conv_generic", c->tune.force_generic, true, 0, 1)      // every conv on the generic kernel
   LDC_OPT("conv_small_tiles", c->tune.small_max, true, 0, 1 << 30)
-  LDC_OPT("conv_medium_tiles", c->tune.medium_max, true, 0, 1 << 30)
   LDC_OPT("conv_splitk", c->tune.splitk, true, 0, 4)
   LDC_OPT("sk_tiles", c->tune.sk_tiles, true, 0, 1 << 30)
   LDC_OPT("sk_u2", c->tune.sk_u2, true, 0, 1 << 30)
   LDC_OPT("sk_u3", c->tune.sk_u3, true, 0, 1 << 30)
   LDC_OPT("conv_mfast", c->tune.m_fastest, true, 0, 2)
   LDC_OPT("conv_debug", c->tune.debug, true, 0, 255)              // ablation bits (conv_lean.inc / conv_fast.inc)
-  LDC_OPT("conv_tile", c->tune.force_tile, true, -1, 2)
+  LDC_OPT("conv_tile", c->tune.force_tile, true, -1, 1)
+  LDC_OPT("conv_xcd_order", c->tune.xcd_order, true, 0, 8)
   LDC_OPT("gn_nap", c->tune.gn_nap, true, 0, 4096)
   LDC_OPT("gn_nap0", c->tune.gn_nap0, true, 0, 4096)
   // codec ends
@@ -1507,8 +1508,10 @@ struct PlanBuilder {
       // even while the other batch parts' launches hold their share of the chip (three workgroups of these kernels fit a CU: 41-51 KB of
       // ring, <= 168 registers; the parts run concurrently).  A long single file (sample.py's whole-file mode: B = 1, L = samples / hop)
       // fails (ii) and takes the conv + gn_apply pair instead of stalling every fused launch for its time-out.
+      // The slots come from the occupancy query of the kernels these convs land on x the device's CUs (round 6; before: a constant 3 x 256).
       const int concurrent = std::max(2, c->split_batch);
-      const long resident_slots = (long)(3 * 256 / concurrent) * 8 / 10;
+      const long resident_slots = (long)(c->w8 ? std::min(conv_fused_gn_wgs_per_cu(DT_BF16, true), conv_fused_gn_wgs_per_cu(DT_FP8, false)) : conv_fused_gn_wgs_per_cu(dt, false)) *
+                                  c->num_cus / concurrent * 8 / 10;
       auto few_tiles = [&](const int* t) {
         if (t[0] <= 0 || t[3] <= 0) return false;
         const long ntn = (r.cout + t[3] - 1) / t[3];

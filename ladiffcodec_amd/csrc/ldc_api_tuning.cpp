@@ -417,6 +417,7 @@ extern "C" int ldc_conv_microbench(ldc_ctx* c, int dtype, int B, int L, int cin1
     void* gs = nullptr;
     LDCCHK(keep.alloc(&gs, (size_t)B * 8 * kGnPad * 4));
     HIPCHK(hipMemset(gs, 0, (size_t)B * 8 * kGnPad * 4));
+  HIPCHK(hipDeviceSynchronize());
     cc.gn_sum = (float*)gs; cc.gn_groups = 8;
   }
   hipStream_t s = c->own_stream;
@@ -566,6 +567,7 @@ extern "C" int ldc_conv_compare(ldc_ctx* c, int dtype, int B, int L, int cin1, i
     HIPCHK(hipMemset(y[v], 0, n_out * es));
     HIPCHK(hipMemset(st[v], 0, stat_n * 4));
     HIPCHK(hipMemset(cm[v], 0, cm_n * 4));
+    HIPCHK(hipDeviceSynchronize());   // (the memsets went to the null stream, which a non-blocking stream does not wait for)
     // tile_cfg >= 100 (round 6): BOTH passes on the pipelined path with tile shape tile_cfg - 100, pass 0 on conv_fast_kernel (lean off), pass 1
     // on conv_lean_kernel -- same tiles, same accumulation order: the caller expects max_abs_diff == 0
     // (+200 / +300: conv_fast_kernel twice / conv_lean_kernel twice -- run-to-run determinism of either)
@@ -688,6 +690,7 @@ extern "C" int ldc_conv_compare_fp8(ldc_ctx* c, int B, int L, int cin1, int cin2
     HIPCHK(hipMemset(y[v], 0, n_out * 2));
     HIPCHK(hipMemset(st[v], 0, stat_n * 4));
     HIPCHK(hipMemset(cm[v], 0, cm_n * 4));
+    HIPCHK(hipDeviceSynchronize());   // (the memsets went to the null stream, which a non-blocking stream does not wait for)
     ConvCall cc;
     cc.B = B; cc.L_in = L; cc.L_rows = L_out; cc.x1 = x1[v]; cc.x2 = x2[v]; cc.y = y[v]; cc.y_ld = cout;
     if (with_gn) { cc.gn_sum = (float*)st[v]; cc.gn_groups = groups; }
@@ -840,6 +843,7 @@ extern "C" int ldc_ln_fold_compare(ldc_ctx* c, int dtype, int rows, int C, int n
   for (int v = 0; v < 3; ++v) {
     LDCCHK(keep.alloc(&y[v], (size_t)rows * n_out * es));
     HIPCHK(hipMemset(y[v], 0, (size_t)rows * n_out * es));
+    HIPCHK(hipDeviceSynchronize());
     ConvCall cc;
     cc.B = 1; cc.L_in = rows; cc.L_rows = rows; cc.y = y[v]; cc.y_ld = n_out; cc.tune = &c->tune;
     if (v == 0) {

@@ -296,6 +296,7 @@ struct ldc_ctx {
   int lstm_xcd = 1;             // LDC_LSTM_XCD / option "lstm_xcd": the cooperative LSTM of ONE or TWO items on sixteen 1024-thread workgroups of one XCD, the
                                 // hidden-state exchange through that XCD's L2 (seanet.hip: lstm_xcd_kernel; configs[0]: 2.6 instead of 3.3 ms per clip); a
                                 // device-side failure of it switches the context back to the placement-independent kernel
+  int num_cus = 256;
   int xcd_resident[2] = {0, 0};   // teams of the XCD-local LSTM one XCD holds (H = 256, 512)
   int coop_resident[2] = {0, 0};   // [H == 512]: the cooperative LSTM's H/4 workgroups fit the device together (asked at ldc_create)
   int fuse_attn_tail = 1;       // LinearAttention out + to_out conv + LayerNorm + residual in one launch (bf16 engine)

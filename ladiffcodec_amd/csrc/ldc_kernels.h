@@ -59,13 +59,13 @@ struct ConvLayer {
 struct ConvTune {
   int force_generic = 0;        // LDC_CONV_V1: every conv on the generic kernel
   int small_max = 100;          // LDC_CONV_SMALL_TILES: 64x64 tiles up to this many 128x128-equivalents (60 through round 5; with the lean kernel 80-150 measure 0.8-1.2 % faster per decode, 200+ slower: tools/sweep_knobs_r06b.sh)
-  int medium_max = 1 << 30;     // LDC_CONV_MEDIUM_TILES: 128x64 tiles up to this many
   int splitk = 1;               // LDC_CONV_SPLITK: 0 off | 1 by layer | 2 | 3
   int sk_tiles = 200, sk_u2 = 24, sk_u3 = 60;   // LDC_SK_TILES / LDC_SK_U2 / LDC_SK_U3
   int m_fastest = 1;            // LDC_CONV_MFAST: 0 N-tile fastest | 1 by operand size | 2 M-tile fastest
   int debug = 0;                // LDC_CONV_DEBUG (bits, see conv_fast.inc)
   int gn_nap = 16, gn_nap0 = 0;  // LDC_GN_NAP / LDC_GN_NAP0: 64-clock naps between the polls of the fused GroupNorm exchange / before the first
-  int force_tile = -1;          // self-check / tuning: 0 = 64x64, 1 = 128x64, 2 = 128x128 tiles wherever the layer's N allows
+  int force_tile = -1;          // self-check / tuning: 0 = 64x64, 1 = 128x64 tiles wherever the layer's N allows
+  int xcd_order = 1;            // round 6: lean kernel's dispatch order as an xm x xn arrangement of the XCDs chosen by operand bytes (conv_lean.inc: lean_xcd_order); 0 = conv_fast_body's order; 2 / 4 / 8 = xn forced
   int lean = 1;                 // round 6: the instruction-diet kernel (conv_lean.inc) where its shapes allow; 0 = conv_fast_kernel everywhere (LDC_CONV_LEAN)
 };
 
@@ -246,6 +246,7 @@ size_t lstm_coop_ws_bytes(int H);
 // (the caller falls back to launch_lstm_layer).
 bool lstm_coop_resident(int H);
 // the XCD-local form (launch_lstm_coop with coop_launch == 2) fits one XCD
+int conv_fused_gn_wgs_per_cu(int dt, bool w8);   // occupancy query: workgroups per CU of the kernels a fused-GroupNorm conv lands on
 int lstm_xcd_resident(int H);   // teams of sixteen workgroups one XCD holds
 // occupancy query x CU count (with a margin) >= the H/4 workgroups that must be co-resident
 hipError_t launch_lstm_coop(int dt, const void* pre, const float* w_rm, void* out, const void* skip, int B, int T, int H,

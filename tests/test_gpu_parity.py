@@ -470,7 +470,7 @@ def test_bench_workload_items_against_oracle(dtype):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_conv_fast_every_tile_shape_against_generic_kernel(dtype):
     """ldc_conv_compare: the same layer and pseudo-random operands through conv_fast.inc with every tile shape forced
-    (64x64, 128x64, 128x128, and the launcher's own choice incl. split-K) and through the generic kernel (conv_gemm.hip, which
+    (64x64, 128x64, and the launcher's own choice incl. split-K; the 128x128 tiles were removed in round 6) and through the generic kernel (conv_gemm.hip, which
     the SConv1d vectors of the reference pin): outputs, fused GroupNorm statistics (unet.py:142-147), fused k column maxima
     (unet.py:214) and the residual epilogue.  Shapes: the UNet's layer classes incl. two-input (concatenated) convs, k = 1/3/4/7,
     stride 2, folded nearest upsampling, ragged row counts (B * L not a multiple of any tile)."""
@@ -485,13 +485,13 @@ def test_conv_fast_every_tile_shape_against_generic_kernel(dtype):
         (600, 256, 0, 512, 4, 2, 0), (75, 1024, 0, 1024, 3, 1, 1), (77, 256, 0, 128, 1, 1, 0), (53, 512, 0, 512, 3, 1, 0),
     ]
     for Lx, c1, c2, co, k, st, ups in shapes:
-        for cfg in (-1, 0, 1, 2):
+        for cfg in (-1, 0, 1):
             for B in (3, 16):
                 if B == 16 and (cfg != -1 or Lx > 300):
                     continue
                 d, m, r = C.c_double(), C.c_double(), C.c_double()
                 L.check(lib.ldc_conv_compare(ctx, dt, B, Lx, c1, c2, co, k, st, ups, cfg, 1 if k == 3 and st == 1 else 0, 1 if k == 1 else 0,
-                                             1 if cfg in (-1, 2) and st == 1 and not ups else 0, C.byref(d), C.byref(m), C.byref(r)))
+                                             1 if cfg in (-1, 1) and st == 1 and not ups else 0, C.byref(d), C.byref(m), C.byref(r)))
                 assert m.value > 0.1 and d.value <= tol_out * m.value, (dtype, Lx, c1, c2, co, k, st, ups, cfg, B, d.value, m.value)
                 assert r.value < 1e-4, ("fused statistics", dtype, Lx, c1, c2, co, k, cfg, B, r.value)
 
