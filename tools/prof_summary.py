@@ -1,8 +1,23 @@
 """Summarise a rocprofv3 rocpd database (the default output of `rocprofv3 --kernel-trace --stats`) as a
 per-kernel table: calls, total / average / min / max duration.  Usage: python tools/prof_summary.py DB [> profiles/x.md]"""
 import re
+import shutil
 import sqlite3
+import subprocess
 import sys
+
+
+def demangle(mangled):
+    """rocprofv3's display names give up on __bf16 (`DF16b`): half of the conv kernels come out mangled, the other half with their template
+    arguments out of step.  binutils' c++filt does not know DF16b either, but it knows `Dh` (half): substitute, demangle, rename."""
+    names = [re.sub(r"\.kd$", "", m).replace("DF16b", "Dh") for m in mangled]
+    exe = shutil.which("c++filt")
+    if not exe:
+        return None
+    out = subprocess.run([exe], input="\n".join(names) + "\n", capture_output=True, text=True).stdout.splitlines()
+    if len(out) != len(names):
+        return None
+    return [o.replace("half", "bf16") for o in out]
 
 
 def short(name: str) -> str:
@@ -17,7 +32,18 @@ def short(name: str) -> str:
 
 def main(path):
     con = sqlite3.connect(path)
-    rows = con.execute("select name, grid_x*1.0/workgroup_x, duration, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size from kernels").fetchall()
+    try:
+        rows = con.execute("select S.kernel_name, K.grid_size_x*1.0/K.workgroup_size_x, K.end - K.start, K.group_segment_size, S.arch_vgpr_count, "
+                           "S.accum_vgpr_count, S.sgpr_count, K.private_segment_size from rocpd_kernel_dispatch K join rocpd_info_kernel_symbol S "
+                           "on S.id = K.kernel_id and S.guid = K.guid").fetchall()
+        uniq = sorted({r[0] for r in rows})
+        dem = demangle(uniq)
+        if dem is None:
+            raise RuntimeError("no c++filt")
+        table = dict(zip(uniq, dem))
+        rows = [(table[r[0]],) + tuple(r[1:]) for r in rows]
+    except Exception:
+        rows = con.execute("select name, grid_x*1.0/workgroup_x, duration, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size from kernels").fetchall()
     agg = {}
     for name, blocks, dur, lds, v, a, s, scr in rows:
         k = short(name)
