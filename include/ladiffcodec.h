@@ -125,7 +125,10 @@ int ldc_destroy(ldc_ctx* ctx);
  * 0 = one fork / join graph, 2 = per-part graphs for three / four parts as well.  (Removed in round 6, measured slower in rounds 4-5:
  * "chain_convs" -- block1's and block2's convs as one launch -- and "xcd_teams" -- runs of convs as persistent XCD-team launches;
  * profiles/r04_fusion_experiments.md, profiles/r05_team_chain_experiments.md keep the numbers.)
- * Cached plans and graphs are dropped when a value changes. */
+ * "conv_xcd_order" (1) = the lean kernel's dispatch order as an xm x xn arrangement of the eight XCDs chosen per launch by operand
+ * bytes (0 = conv_fast_kernel's order; 2 / 4 / 8 = xn forced); "fold_ctx" (1) = the LinearAttention context inside to_qkv's epilogue.
+ * The whole table (name, default, effect) is in tools/README.md; LDC_OPTIONS="name=value,..." in the environment sets the same
+ * names at ldc_create.  Cached plans and graphs are dropped when a value changes. */
 int ldc_set_option(ldc_ctx* ctx, const char* name, int value);
 
 /* Device-drawn noise (noise == NULL): Philox4x32-10 keyed by (noise_seed, call counter); every sampler call that
