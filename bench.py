@@ -113,6 +113,8 @@ def bench_training(args, eng, mc, u, cc, sd_main, sd_cond, wav, T, rank, world, 
         front.finalize(strict=True)
     tr = TR.DiffusionTrainer(eng, sd, dim=u.dim, dim_mults=u.dim_mults, lr=1e-4, upsampling_ratios=u.upsampling_ratios,
                              unet_scale_cond=u.unet_scale_cond, frontend=front)
+    if args.no_dw_side:
+        tr.dw_side = False      # A/B: the Blocks' weight-gradient GEMMs in line instead of on the side stream
     for i in range(args.warmup):
         tr.step_from_wav(wav, next_wav=wav)
         torch.cuda.synchronize(dev)
@@ -294,6 +296,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the CPU-oracle sample (SURVEY 8d: B = 4)")
+    ap.add_argument("--no-dw-side", action="store_true", help="c4: weight-gradient GEMMs in line (A/B of DiffusionTrainer.dw_side)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the supplementary two-batches-in-flight measurement")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="batches decoded concurrently (default 1 = the metric's reading: one batch of the config's size at a time). "

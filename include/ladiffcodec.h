@@ -290,6 +290,13 @@ int ldc_train_conv_forward(ldc_ctx* ctx, const float* x, const float* w, const f
                            int pad, float* y, void* stream);
 int ldc_train_conv_backward(ldc_ctx* ctx, const float* dy, const float* x, const float* w, int B, int Cin, int Cout, int Lin, int K, int stride,
                             int pad, float* dx, float* dw, float* db, void* stream);
+/* Option "train_dw_side" (process-wide, 0 / 1, default 0; DiffusionTrainer sets it around its backward pass): ldc_train_block_backward puts
+ * the weight-gradient GEMM of the Block (and what hangs on it: the ordered reduction of its parts, the bias gradient, the
+ * weight-standardisation backward) on an internal side stream behind an event, the caller's stream goes on with dX.  ldc_train_join makes
+ * `stream` wait for everything the side stream holds: call it between the backward pass and the first use of a parameter gradient.  The
+ * caller keeps the Block's workspace and saved input alive until then.  (The reference's autograd engine does the same thing with its
+ * own streams; srcs/train.py:150-158 is `loss.backward()`.) */
+int ldc_train_join(ldc_ctx* ctx, void* stream);
 int ldc_train_upsample2(ldc_ctx* ctx, const float* in, int64_t rows, int L, int backward, float* out, void* stream);
 int ldc_train_activation(ldc_ctx* ctx, const float* x, const float* dy, int64_t n, int kind, float* out, void* stream);
 int64_t ldc_train_attn_ws_floats(int B, int heads, int N);

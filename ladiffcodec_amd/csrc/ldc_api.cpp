@@ -878,6 +878,7 @@ static bool find_option(ldc_ctx* c, const std::string& n, OptRef* r) {
   LDC_OPT("train_bf16", g_train_bf16, false, 0, 1)
   LDC_OPT("train_fp32_mfma", g_train_fp32_mfma, false, 0, 1)
   LDC_OPT("train_valu", g_train_valu, false, 0, 1)
+  LDC_OPT("train_dw_side", g_train_dw_side, false, 0, 1)
 #undef LDC_OPT
   return false;
 }

@@ -257,6 +257,15 @@ extern "C" int ldc_train_conv_backward(ldc_ctx* c, const float* dy, const float*
   return finish_stream(c, stream);
 }
 
+/* The caller's stream waits for the weight-gradient launches the backward pass put on the training side stream (option
+ * "train_dw_side"); a no-op when there are none.  Call it between the backward pass and the first use of a parameter gradient. */
+extern "C" int ldc_train_join(ldc_ctx* c, void* stream) {
+  LDCCHK(check_dev(c));
+  hipStream_t s = pick_stream(c, stream);
+  HIPCHK(launch_train_join(s));
+  return finish_stream(c, stream);
+}
+
 extern "C" int ldc_train_upsample2(ldc_ctx* c, const float* in, int64_t rows, int L, int backward, float* out, void* stream) {
   LDCCHK(check_dev(c));
   if (!in || !out || rows < 1 || L < 1) return fail(LDC_E_INVALID, "bad arguments");

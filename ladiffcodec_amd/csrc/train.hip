@@ -400,6 +400,43 @@ __global__ __launch_bounds__(256) void convmm_kernel(const float* w, const float
     }
 }
 static bool convmm_ok(int Lin, int Lout) { return !g_train_valu && Lin >= 16 && Lout >= 16; }
+
+// The weight-gradient GEMMs of a backward pass on a side stream (round 6).  dW of a layer is needed by nothing before the optimiser,
+// while dX is the critical path and the kernels between two dX GEMMs (GroupNorm / LayerNorm / attention backward: streaming kernels)
+// leave the matrix pipes idle.  A Block's backward records an event behind its GroupNorm backward, the side stream waits for it and
+// runs dW (+ its ordered reduction, the bias gradient, the weight-standardisation backward) from its own workspace lane, the main
+// stream goes on with dX.  launch_train_join makes the main stream wait for the side stream before the gradients are used.
+// Everything a side launch reads lives in the Block's saved workspace / saved input (kept by the Python layer until the next forward)
+// and everything it writes in that workspace or the flat gradient buffer.  Off by default: DiffusionTrainer switches it on around
+// net.backward only (a per-layer caller reads dw right after the call).  Not inside a stream capture.
+int g_train_dw_side = 0;
+static hipStream_t g_side_stream = nullptr;
+static hipEvent_t g_side_fork_ev = nullptr, g_side_join_ev = nullptr;
+static bool g_side_dirty = false;
+static hipStream_t dw_side_fork(hipStream_t s) {
+  if (!g_train_dw_side || g_train_fp32_mfma || g_train_valu) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  if (!g_side_stream) {
+    if (hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g_side_fork_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_side_join_ev, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      g_side_stream = nullptr;
+      return nullptr;
+    }
+  }
+  if (hipEventRecord(g_side_fork_ev, s) != hipSuccess || hipStreamWaitEvent(g_side_stream, g_side_fork_ev, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  g_side_dirty = true;
+  return g_side_stream;
+}
+hipError_t launch_train_join(hipStream_t s) {
+  if (!g_side_dirty || !g_side_stream) return hipSuccess;
+  hipError_t e = hipEventRecord(g_side_join_ev, g_side_stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, g_side_join_ev, 0);
+  if (e == hipSuccess) g_side_dirty = false;
+  return e;
+}
 // 128 x 128 tiles (opt-in, LDC_TRAIN_BIG_TILES=1) when both output dimensions fill them reasonably and the grid still covers the
 // chip.  Measured on the full-width step (32 x 2.4 s): 125.1 ms against 122.5 ms with 64 x 64 tiles everywhere -- the kernel is not
 // bound by its loads per MFMA (the fp32 MFMA is 64 cycles; eight resident workgroups per CU cover the rest), so the default stays.
@@ -427,8 +464,8 @@ static void convmm_dx(const float* dy, const float* w, int B, int Cin, int Cout,
 }
 // -> true when the bias gradient was produced too (split-bf16 path: fused into the dW kernel)
 static bool convmm_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
-                      float* db = nullptr) {
-  if (!g_train_fp32_mfma) { (void)launch_mm3_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s, db); return db != nullptr; }
+                      float* db = nullptr, int lane = 0) {
+  if (!g_train_fp32_mfma) { (void)launch_mm3_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s, db, lane); return db != nullptr; }
   // few output tiles, a long reduction over the items: split the items over workgroups (fp32 atomics into the zeroed gradient:
   // the sum order varies from run to run at the 1e-7 level) until the grid fills the chip
   const bool big = convmm_big(Cout, Cin, (long)K * B);
@@ -671,11 +708,14 @@ hipError_t launch_train_block_backward(const float* dy, const float* x, const fl
   hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pgam, B, Cout, dgamma);
   hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pbet, B, Cout, dbeta);
   hipLaunchKernelGGL(gn_silu_backward2_kernel, dim3(groups, B), dim3(1024), 0, s, k.h, k.stats, Cout, L, groups, k.tmp);   // tmp := dh
+  // the weight gradient (reads tmp and x, writes dwn, dw, db): on the side stream when the trainer has switched that on
+  hipStream_t sd = convmm_ok(L, L) ? dw_side_fork(s) : nullptr;
+  hipStream_t sw = sd ? sd : s;
   bool db_done = false;
-  if (convmm_ok(L, L)) db_done = convmm_dw(k.tmp, x, B, Cin, Cout, L, L, 3, 1, 1, k.dwn, s, db);
-  else hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, k.tmp, x, B, Cin, Cout, L, k.dwn);
-  if (!db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, k.tmp, B, Cout, L, db);
-  hipLaunchKernelGGL(ws_backward_kernel, dim3(Cout), dim3(256), 0, s, k.dwn, k.wn, k.rstd_w, Cin * 3, dw);
+  if (convmm_ok(L, L)) db_done = convmm_dw(k.tmp, x, B, Cin, Cout, L, L, 3, 1, 1, k.dwn, sw, db, sd ? 1 : 0);
+  else hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, sw, k.tmp, x, B, Cin, Cout, L, k.dwn);
+  if (!db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, sw, k.tmp, B, Cout, L, db);
+  hipLaunchKernelGGL(ws_backward_kernel, dim3(Cout), dim3(256), 0, sw, k.dwn, k.wn, k.rstd_w, Cin * 3, dw);
   if (dx) {
     if (convmm_ok(L, L)) convmm_dx(k.tmp, k.wn, B, Cin, Cout, L, L, 3, 1, 1, dx, s);
     else hipLaunchKernelGGL(conv3_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, k.tmp, k.wn, Cin, Cout, L, dx);

@@ -550,22 +550,24 @@ u32x4* pack_workspace(size_t bytes, hipStream_t s) {
   }
   return (u32x4*)g_pw;
 }
-void* g_dw_ws = nullptr;      // partial dW tiles of a split reduction (same ownership rules as g_pw)
-size_t g_dw_ws_bytes = 0;
-float* dw_workspace(size_t bytes, hipStream_t s) {
+// partial dW tiles / split forward-dX reductions (same ownership rules as g_pw).  Two lanes: lane 1 serves the dW GEMMs the training
+// step moves to its side stream (train.hip: dw_side_fork), so that they never share a buffer with the main stream's launches.
+void* g_dw_ws[2] = {nullptr, nullptr};
+size_t g_dw_ws_bytes[2] = {0, 0};
+float* dw_workspace(size_t bytes, hipStream_t s, int lane = 0) {
   if (!ws_device_ok()) return nullptr;
-  if (bytes > g_dw_ws_bytes) {
+  if (bytes > g_dw_ws_bytes[lane]) {
     if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
     ++g_device_syncs;
     if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-    if (g_dw_ws) (void)hipFree(g_dw_ws);
-    g_dw_ws = nullptr;
-    g_dw_ws_bytes = 0;
+    if (g_dw_ws[lane]) (void)hipFree(g_dw_ws[lane]);
+    g_dw_ws[lane] = nullptr;
+    g_dw_ws_bytes[lane] = 0;
     const size_t want = std::max(bytes + bytes / 4, (size_t)64 << 20);
-    if (hipMalloc(&g_dw_ws, want) != hipSuccess) return nullptr;
-    g_dw_ws_bytes = want;
+    if (hipMalloc(&g_dw_ws[lane], want) != hipSuccess) return nullptr;
+    g_dw_ws_bytes[lane] = want;
   }
-  return (float*)g_dw_ws;
+  return (float*)g_dw_ws[lane];
 }
 inline int up(int v, int q) { return (v + q - 1) / q * q; }
 // waves per workgroup of the GEMM kernels (LDC_MM3_NW = 4 | 8; see mm3_kernel)
@@ -647,7 +649,7 @@ hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Co
   return hipGetLastError();
 }
 hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
-                         float* db) {
+                         float* db, int lane) {
   // few output tiles, a long reduction over the items: split the items over workgroups until the grid fills the chip (two workgroups
   // per CU); the parts write their tiles to a workspace and a second kernel sums them in order (deterministic)
   const int tiles = ((Cin + 127) / 128) * ((Cout + 127) / 128) * K;
@@ -657,7 +659,7 @@ hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Co
   float* db_target = db;          // the first column tile of tap 0 writes the row sums of its dy tiles (per part)
   if (nsplit > 1) {
     const size_t n_dw = (size_t)nsplit * K * Cout * Cin;
-    target = dw_workspace((n_dw + (size_t)nsplit * Cout) * sizeof(float), s);
+    target = dw_workspace((n_dw + (size_t)nsplit * Cout) * sizeof(float), s, lane ? 1 : 0);
     if (!target) return hipErrorOutOfMemory;
     if (db) db_target = target + n_dw;
   }

@@ -710,6 +710,7 @@ class DiffusionTrainer:
         self._grad_views = {p.data_ptr(): g for p, g in zip(self.state_dict().values(), self._views(self.flat_g).values())}
         self.num_timesteps = int(eng.lib.ldc_train_num_timesteps(eng._ctx))
         self.opt = Adam(eng, self.flat, lr=lr)
+        self.dw_side = True        # the Blocks' weight-gradient GEMMs on the library's side stream, under the dX chain (round 6: 49.9 -> 48.1 ms per full-width step, same box; bit-identical gradients)
         self.use_graph = False     # the step as one replayed hipGraph (see _step_graphed): opt-in attribute, measured equal (49.96 vs 49.75 ms)
         self._graph, self._graph_key, self._graph_seen, self._graph_in, self._graph_out = None, None, 0, None, None
 
@@ -816,7 +817,19 @@ class DiffusionTrainer:
             x_t = q_sample(eng, x_start, t, noise)
             out = self.net.forward(x_t, t, cond)
             loss, grad = p_losses_objective(eng, out, noise, t)
-            grads, _, _ = self.net.backward(grad)
+            # the weight-gradient GEMMs of the Blocks on the library's side stream, under the dX chain (csrc/train.hip: dw_side_fork);
+            # joined before anything reads a parameter gradient.  The layers keep what those launches read until their next forward.
+            side = bool(self.dw_side)
+            if side:
+                eng.set_option("train_dw_side", 1)
+            try:
+                grads, _, _ = self.net.backward(grad)
+            finally:
+                if side:
+                    eng.set_option("train_dw_side", 0)
+                    s = eng._enter()
+                    LL.check(eng.lib.ldc_train_join(eng._ctx, s))
+                    eng._exit()
             missing = set(self._grad_views) - eng._grad_written
             if missing or set(grads) != set(self.names):
                 raise RuntimeError(f"backward left {len(missing)} parameter gradient(s) unwritten; key mismatch: "

@@ -535,3 +535,32 @@ def test_graphed_optimisation_step_equals_the_eager_one():
     assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-5, (l0, l1)
     dev = (p0 - p1).abs()
     assert float(dev.mean()) < 2e-6 and float((dev > 2e-4).float().mean()) < 2e-3, (float(dev.mean()), float(dev.max()))
+
+
+def test_weight_gradients_on_the_side_stream_equal_the_in_line_ones():
+    """Round 6: DiffusionTrainer.dw_side (default on) puts the Blocks' weight-gradient GEMMs, their ordered reductions, bias
+    gradients and weight-standardisation backward on the library's side stream under the dX chain (csrc/train.hip:
+    dw_side_fork; ldc_train_join before the gradients are used; `loss.backward()` of srcs/train.py:150-158 is what both orders
+    stand for).  Same kernels on the same operands: losses, the flat gradient of every step and the parameters after six Adam
+    steps are bit-identical with the in-line order -- at a width where the GEMM path is taken (L >= 16) -- and switching the
+    setting between steps continues the same trajectory (nothing is left on the side stream after a step)."""
+    g = load_golden("train_unet")
+    sd = {k[2:]: T(g[k]) for k in list(g.keys()) if k.startswith("p.")}
+    gen = torch.Generator().manual_seed(78)
+    steps = [(torch.randn(2, 8, 32, generator=gen).clamp(-1, 1), torch.randn(2, 8, 32, generator=gen), torch.randint(0, 1000, (2,), generator=gen),
+              torch.randn(2, 8, 32, generator=gen)) for _ in range(6)]
+    out = []
+    for pattern in ((False,) * 6, (True,) * 6, (True, False, True, True, False, True)):
+        e = engine("r84", "f32")
+        tr = TR.DiffusionTrainer(e, {k: v.clone() for k, v in sd.items()}, dim=16, dim_mults=(1, 2), lr=2e-3)
+        losses, grads = [], []
+        for side, st in zip(pattern, steps):
+            tr.dw_side = side
+            losses.append(float(tr.step(*st).cpu()[0]))
+            grads.append(tr.flat_g.detach().cpu().clone())
+        out.append((losses, grads, torch.cat([v.reshape(-1).cpu() for v in tr.state_dict().values()])))
+    for losses, grads, params in out[1:]:
+        assert losses == out[0][0], (losses, out[0][0])
+        for a, b in zip(grads, out[0][1]):
+            assert float(a.abs().max()) > 0 and torch.equal(a, b)
+        assert torch.equal(params, out[0][2])
