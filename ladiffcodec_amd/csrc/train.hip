@@ -705,12 +705,13 @@ hipError_t launch_train_block_backward(const float* dy, const float* x, const fl
   const BlockWs k = carve(ws, B, Cin, Cout, L, groups);
   hipLaunchKernelGGL(gn_silu_backward1_kernel, dim3(Cout, B), dim3(256), 0, s, dy, k.h, gamma, beta, ss, k.stats, Cout, L, groups, k.tmp,
                      dss, k.pgam, k.pbet);
-  hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pgam, B, Cout, dgamma);
-  hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, k.pbet, B, Cout, dbeta);
   hipLaunchKernelGGL(gn_silu_backward2_kernel, dim3(groups, B), dim3(1024), 0, s, k.h, k.stats, Cout, L, groups, k.tmp);   // tmp := dh
-  // the weight gradient (reads tmp and x, writes dwn, dw, db): on the side stream when the trainer has switched that on
+  // the parameter gradients (the GroupNorm's: sums of pgam / pbet over the items; the weight's: reads tmp and x, writes dwn, dw, db): on
+  // the side stream when the trainer has switched that on
   hipStream_t sd = convmm_ok(L, L) ? dw_side_fork(s) : nullptr;
   hipStream_t sw = sd ? sd : s;
+  hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, sw, k.pgam, B, Cout, dgamma);
+  hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, sw, k.pbet, B, Cout, dbeta);
   bool db_done = false;
   if (convmm_ok(L, L)) db_done = convmm_dw(k.tmp, x, B, Cin, Cout, L, L, 3, 1, 1, k.dwn, sw, db, sd ? 1 : 0);
   else hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, sw, k.tmp, x, B, Cin, Cout, L, k.dwn);

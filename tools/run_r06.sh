@@ -54,6 +54,7 @@ issue)   # instruction-issue / instruction-cache counters of the pipelined conv 
     done
   done
   python tools/pmc_counters.py $O/iss $O/conv_issue_counters.md $O/conv_counters.json > /dev/null; head -70 $O/conv_issue_counters.md
+  cp $O/conv_counters.json profiles/r06_conv_counters.json   # (bench.py attaches mfma_busy_frac from it while the kernel-source hash matches)
   find $O/iss -name "*.csv" -size +5M -delete ;;
 prof)
   rm -rf $O/prof
