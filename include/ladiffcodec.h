@@ -297,6 +297,10 @@ int ldc_train_conv_backward(ldc_ctx* ctx, const float* dy, const float* x, const
  * caller keeps the Block's workspace and saved input alive until then.  (The reference's autograd engine does the same thing with its
  * own streams; srcs/train.py:150-158 is `loss.backward()`.) */
 int ldc_train_join(ldc_ctx* ctx, void* stream);
+/* Round 6 (second half): ldc_train_conv_backward, ldc_train_pointwise_backward (L > 1) and ldc_train_layernorm_backward put their parameter
+ * gradients on the side stream as well; those read `dy`, which the caller therefore keeps alive until ldc_train_join -- a torch caller marks
+ * it with dy.record_stream(torch.cuda.ExternalStream(handle)), handle from ldc_train_side_stream. */
+int ldc_train_side_stream(ldc_ctx* ctx, void** stream_out);
 int ldc_train_upsample2(ldc_ctx* ctx, const float* in, int64_t rows, int L, int backward, float* out, void* stream);
 int ldc_train_activation(ldc_ctx* ctx, const float* x, const float* dy, int64_t n, int kind, float* out, void* stream);
 int64_t ldc_train_attn_ws_floats(int B, int heads, int N);

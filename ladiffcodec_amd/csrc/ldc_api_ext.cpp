@@ -259,6 +259,15 @@ extern "C" int ldc_train_conv_backward(ldc_ctx* c, const float* dy, const float*
 
 /* The caller's stream waits for the weight-gradient launches the backward pass put on the training side stream (option
  * "train_dw_side"); a no-op when there are none.  Call it between the backward pass and the first use of a parameter gradient. */
+/* The side stream's handle (hipStream_t), for callers whose allocator must know that a tensor handed to a backward call is still read
+ * there (torch: tensor.record_stream(torch.cuda.ExternalStream(handle))). */
+extern "C" int ldc_train_side_stream(ldc_ctx* c, void** out) {
+  LDCCHK(check_dev(c));
+  if (!out) return fail(LDC_E_INVALID, "bad arguments");
+  *out = (void*)train_side_stream();
+  if (!*out) return fail(LDC_E_HIP, "could not create the training side stream");
+  return LDC_OK;
+}
 extern "C" int ldc_train_join(ldc_ctx* c, void* stream) {
   LDCCHK(check_dev(c));
   hipStream_t s = pick_stream(c, stream);

@@ -308,8 +308,10 @@ hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Co
                          const float* bias = nullptr);
 // (db: optional bias gradient [Cout] = sum over items and positions of dy, accumulated by the workgroups that stage dy anyway)
 hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
-                         float* db = nullptr, int lane = 0);   // lane 1: the side stream's workspace (train.hip: dw_side_fork)
+                         float* db = nullptr);
+extern hipStream_t g_train_side_stream;   // the training side stream (train.hip; nullptr until first used): launches on it take their own workspaces
 extern int g_train_dw_side;    // option train_dw_side: the weight-gradient GEMMs of the Blocks on a side stream (set by DiffusionTrainer around its backward pass)
+hipStream_t train_side_stream();              // the side stream (created on first use; nullptr on failure)
 hipError_t launch_train_join(hipStream_t s);   // `s` waits for everything the side stream holds (no-op when it was not used)
 extern int g_train_valu;   // LDC_TRAIN_VALU: the training path's GEMM shapes on the VALU reference kernels instead of the fp32 MFMA ones
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, hipStream_t s);

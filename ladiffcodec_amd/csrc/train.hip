@@ -410,31 +410,34 @@ static bool convmm_ok(int Lin, int Lout) { return !g_train_valu && Lin >= 16 && 
 // and everything it writes in that workspace or the flat gradient buffer.  Off by default: DiffusionTrainer switches it on around
 // net.backward only (a per-layer caller reads dw right after the call).  Not inside a stream capture.
 int g_train_dw_side = 0;
-static hipStream_t g_side_stream = nullptr;
+hipStream_t g_train_side_stream = nullptr;
 static hipEvent_t g_side_fork_ev = nullptr, g_side_join_ev = nullptr;
-static bool g_side_dirty = false;
+hipStream_t train_side_stream();
 static hipStream_t dw_side_fork(hipStream_t s) {
   if (!g_train_dw_side || g_train_fp32_mfma || g_train_valu) return nullptr;
+  if (g_train_side_stream && s == g_train_side_stream) return nullptr;   // (the caller runs this whole branch on the side stream already)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-  if (!g_side_stream) {
-    if (hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking) != hipSuccess ||
+  if (!train_side_stream()) return nullptr;
+  if (hipEventRecord(g_side_fork_ev, s) != hipSuccess || hipStreamWaitEvent(g_train_side_stream, g_side_fork_ev, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return g_train_side_stream;
+}
+// the side stream itself (created on first use), for callers that must tell their allocator about it
+hipStream_t train_side_stream() {
+  if (!g_train_side_stream) {
+    if (hipStreamCreateWithFlags(&g_train_side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&g_side_fork_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g_side_join_ev, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
-      g_side_stream = nullptr;
-      return nullptr;
+      g_train_side_stream = nullptr;
     }
   }
-  if (hipEventRecord(g_side_fork_ev, s) != hipSuccess || hipStreamWaitEvent(g_side_stream, g_side_fork_ev, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  g_side_dirty = true;
-  return g_side_stream;
+  return g_train_side_stream;
 }
 hipError_t launch_train_join(hipStream_t s) {
-  if (!g_side_dirty || !g_side_stream) return hipSuccess;
-  hipError_t e = hipEventRecord(g_side_join_ev, g_side_stream);
+  if (!g_train_side_stream || s == g_train_side_stream) return hipSuccess;
+  hipError_t e = hipEventRecord(g_side_join_ev, g_train_side_stream);   // (unconditional: callers may have launched on the side stream themselves)
   if (e == hipSuccess) e = hipStreamWaitEvent(s, g_side_join_ev, 0);
-  if (e == hipSuccess) g_side_dirty = false;
   return e;
 }
 // 128 x 128 tiles (opt-in, LDC_TRAIN_BIG_TILES=1) when both output dimensions fill them reasonably and the grid still covers the
@@ -464,8 +467,8 @@ static void convmm_dx(const float* dy, const float* w, int B, int Cin, int Cout,
 }
 // -> true when the bias gradient was produced too (split-bf16 path: fused into the dW kernel)
 static bool convmm_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
-                      float* db = nullptr, int lane = 0) {
-  if (!g_train_fp32_mfma) { (void)launch_mm3_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s, db, lane); return db != nullptr; }
+                      float* db = nullptr) {
+  if (!g_train_fp32_mfma) { (void)launch_mm3_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s, db); return db != nullptr; }
   // few output tiles, a long reduction over the items: split the items over workgroups (fp32 atomics into the zeroed gradient:
   // the sum order varies from run to run at the 1e-7 level) until the grid fills the chip
   const bool big = convmm_big(Cout, Cin, (long)K * B);
@@ -713,7 +716,7 @@ hipError_t launch_train_block_backward(const float* dy, const float* x, const fl
   hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, sw, k.pgam, B, Cout, dgamma);
   hipLaunchKernelGGL(reduce_items_kernel, dim3((Cout + 255) / 256), dim3(256), 0, sw, k.pbet, B, Cout, dbeta);
   bool db_done = false;
-  if (convmm_ok(L, L)) db_done = convmm_dw(k.tmp, x, B, Cin, Cout, L, L, 3, 1, 1, k.dwn, sw, db, sd ? 1 : 0);
+  if (convmm_ok(L, L)) db_done = convmm_dw(k.tmp, x, B, Cin, Cout, L, L, 3, 1, 1, k.dwn, sw, db);
   else hipLaunchKernelGGL(conv3_dw_kernel, dim3(Cin, Cout), dim3(256), 0, sw, k.tmp, x, B, Cin, Cout, L, k.dwn);
   if (!db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, sw, k.tmp, B, Cout, L, db);
   hipLaunchKernelGGL(ws_backward_kernel, dim3(Cout), dim3(256), 0, sw, k.dwn, k.wn, k.rstd_w, Cin * 3, dw);
@@ -914,7 +917,8 @@ hipError_t launch_train_ln_backward(const float* dy, const float* x, const float
                                     float* dg, hipStream_t s) {
   const dim3 grid((L + 63) / 64, B);
   hipLaunchKernelGGL(ln_backward_dx_kernel, grid, dim3(256), 0, s, dy, x, g, stats, C, L, dx);
-  hipLaunchKernelGGL(ln_backward_dg_kernel, dim3(C), dim3(256), 0, s, dy, x, stats, B, C, L, dg);
+  hipStream_t sd = dw_side_fork(s);   // the gain's gradient feeds the optimiser only (as launch_train_conv_backward)
+  hipLaunchKernelGGL(ln_backward_dg_kernel, dim3(C), dim3(256), 0, sd ? sd : s, dy, x, stats, B, C, L, dg);
   return hipGetLastError();
 }
 
@@ -1003,19 +1007,20 @@ __global__ __launch_bounds__(256) void silu_map_kernel(const float* x, int64_t n
 __global__ __launch_bounds__(256) void silu_grad_mul_kernel(const float* x, int64_t n, float* dx) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dx[i] *= silu_grad_f(x[i]);
 }
-static float* g_lin_ws = nullptr;     // SiLU(x) of the Linear being processed (one training context per process, one stream)
-static size_t g_lin_ws_floats = 0;
+static float* g_lin_ws[2] = {nullptr, nullptr};     // SiLU(x) of the Linear being processed (one training context per process; a lane per stream: 1 = the side stream)
+static size_t g_lin_ws_floats[2] = {0, 0};
 static float* lin_workspace(size_t n, hipStream_t s) {
-  if (n > g_lin_ws_floats) {
+  const int lane = (g_train_side_stream && s == g_train_side_stream) ? 1 : 0;
+  if (n > g_lin_ws_floats[lane]) {
     (void)hipStreamSynchronize(s);
-    if (g_lin_ws) (void)hipFree(g_lin_ws);
-    g_lin_ws = nullptr;
-    g_lin_ws_floats = 0;
+    if (g_lin_ws[lane]) (void)hipFree(g_lin_ws[lane]);
+    g_lin_ws[lane] = nullptr;
+    g_lin_ws_floats[lane] = 0;
     const size_t want = std::max(n, (size_t)1 << 18);
-    if (hipMalloc((void**)&g_lin_ws, want * sizeof(float)) != hipSuccess) return nullptr;
-    g_lin_ws_floats = want;
+    if (hipMalloc((void**)&g_lin_ws[lane], want * sizeof(float)) != hipSuccess) return nullptr;
+    g_lin_ws_floats[lane] = want;
   }
-  return g_lin_ws;
+  return g_lin_ws[lane];
 }
 // nn.Linear on [B, Cin] (the time-embedding MLPs; 24 of them per step at B x 1024 x <= 2048): the round-2 kernels read the weight once
 // per item (forward), column-wise (dX: 179 us a call) or the activations once per output (dW); here they are the same three GEMM
@@ -1066,10 +1071,12 @@ hipError_t launch_train_pw_backward(const float* dy, const float* x, const float
     if (mm) convmm_dx(dy, w, B, Cin, Cout, L, L, 1, 1, 0, dx, s);
     else hipLaunchKernelGGL(pw_dx_kernel, dim3((L + 255) / 256, Cin, B), dim3(256), 0, s, dy, x, w, Cin, Cout, L, pre_silu, dx);
   }
+  hipStream_t sd = dw_side_fork(s);   // (as launch_train_conv_backward)
+  hipStream_t sw = sd ? sd : s;
   bool db_done = false;
-  if (mm) db_done = convmm_dw(dy, x, B, Cin, Cout, L, L, 1, 1, 0, dw, s, db);
-  else hipLaunchKernelGGL(pw_dw_kernel, dim3(Cin, Cout), dim3(256), 0, s, dy, x, B, Cin, Cout, L, pre_silu, dw);
-  if (db && !db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, L, db);
+  if (mm) db_done = convmm_dw(dy, x, B, Cin, Cout, L, L, 1, 1, 0, dw, sw, db);
+  else hipLaunchKernelGGL(pw_dw_kernel, dim3(Cin, Cout), dim3(256), 0, sw, dy, x, B, Cin, Cout, L, pre_silu, dw);
+  if (db && !db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, sw, dy, B, Cout, L, db);
   return hipGetLastError();
 }
 
@@ -1315,10 +1322,14 @@ hipError_t launch_train_conv_backward(const float* dy, const float* x, const flo
     if (mm) convmm_dx(dy, w, B, Cin, Cout, Lin, Lout, K, S, P, dx, s);
     else hipLaunchKernelGGL(convg_dx_kernel, dim3((Lin + 255) / 256, Cin, B), dim3(256), 0, s, dy, w, Cin, Cout, Lin, Lout, K, S, P, dx);
   }
+  // parameter gradients: on the side stream when the trainer has switched that on (the caller then keeps dy alive -- record_stream -- and x
+  // is the layer's saved input)
+  hipStream_t sd = dw_side_fork(s);
+  hipStream_t sw = sd ? sd : s;
   bool db_done = false;
-  if (mm) db_done = convmm_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, s, db);
-  else hipLaunchKernelGGL(convg_dw_kernel, dim3(Cin, Cout, K), dim3(256), 0, s, dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw);
-  if (db && !db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, dy, B, Cout, Lout, db);
+  if (mm) db_done = convmm_dw(dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw, sw, db);
+  else hipLaunchKernelGGL(convg_dw_kernel, dim3(Cin, Cout, K), dim3(256), 0, sw, dy, x, B, Cin, Cout, Lin, Lout, K, S, P, dw);
+  if (db && !db_done) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, sw, dy, B, Cout, Lout, db);
   return hipGetLastError();
 }
 

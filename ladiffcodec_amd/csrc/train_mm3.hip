@@ -532,30 +532,35 @@ bool ws_device_ok() {
   if (g_ws_device < 0) g_ws_device = dev;
   return dev == g_ws_device;
 }
-void* g_pw = nullptr;
-size_t g_pw_bytes = 0;
+// Two lanes of every workspace: lane 1 serves the launches on the training side stream (train.hip: g_train_side_stream -- parameter
+// gradients and the time-embedding branch's backward run there concurrently with the main stream's dX chain), so that the two streams
+// never share a buffer.
+inline int lane_of(hipStream_t s) { return (g_train_side_stream && s == g_train_side_stream) ? 1 : 0; }
+void* g_pw[2] = {nullptr, nullptr};
+size_t g_pw_bytes[2] = {0, 0};
 u32x4* pack_workspace(size_t bytes, hipStream_t s) {
   if (!ws_device_ok()) return nullptr;
-  if (bytes > g_pw_bytes) {
+  const int lane = lane_of(s);
+  if (bytes > g_pw_bytes[lane]) {
     // (counted like every device-wide sync of the library: ldc_debug_sync_count; a failed sync means work may still read the buffer)
     if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
     ++g_device_syncs;
     if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-    if (g_pw) (void)hipFree(g_pw);
-    g_pw = nullptr;
-    g_pw_bytes = 0;
+    if (g_pw[lane]) (void)hipFree(g_pw[lane]);
+    g_pw[lane] = nullptr;
+    g_pw_bytes[lane] = 0;
     const size_t want = std::max(bytes + bytes / 2, (size_t)32 << 20);
-    if (hipMalloc(&g_pw, want) != hipSuccess) return nullptr;
-    g_pw_bytes = want;
+    if (hipMalloc(&g_pw[lane], want) != hipSuccess) return nullptr;
+    g_pw_bytes[lane] = want;
   }
-  return (u32x4*)g_pw;
+  return (u32x4*)g_pw[lane];
 }
-// partial dW tiles / split forward-dX reductions (same ownership rules as g_pw).  Two lanes: lane 1 serves the dW GEMMs the training
-// step moves to its side stream (train.hip: dw_side_fork), so that they never share a buffer with the main stream's launches.
+// partial dW tiles / split forward-dX reductions (same ownership rules as g_pw; a lane per stream, see above)
 void* g_dw_ws[2] = {nullptr, nullptr};
 size_t g_dw_ws_bytes[2] = {0, 0};
-float* dw_workspace(size_t bytes, hipStream_t s, int lane = 0) {
+float* dw_workspace(size_t bytes, hipStream_t s) {
   if (!ws_device_ok()) return nullptr;
+  const int lane = lane_of(s);
   if (bytes > g_dw_ws_bytes[lane]) {
     if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
     ++g_device_syncs;
@@ -649,7 +654,7 @@ hipError_t launch_mm3_dx(const float* dy, const float* w, int B, int Cin, int Co
   return hipGetLastError();
 }
 hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Cout, int Lin, int Lout, int K, int S, int P, float* dw, hipStream_t s,
-                         float* db, int lane) {
+                         float* db) {
   // few output tiles, a long reduction over the items: split the items over workgroups until the grid fills the chip (two workgroups
   // per CU); the parts write their tiles to a workspace and a second kernel sums them in order (deterministic)
   const int tiles = ((Cin + 127) / 128) * ((Cout + 127) / 128) * K;
@@ -659,7 +664,7 @@ hipError_t launch_mm3_dw(const float* dy, const float* x, int B, int Cin, int Co
   float* db_target = db;          // the first column tile of tap 0 writes the row sums of its dy tiles (per part)
   if (nsplit > 1) {
     const size_t n_dw = (size_t)nsplit * K * Cout * Cin;
-    target = dw_workspace((n_dw + (size_t)nsplit * Cout) * sizeof(float), s, lane ? 1 : 0);
+    target = dw_workspace((n_dw + (size_t)nsplit * Cout) * sizeof(float), s);
     if (!target) return hipErrorOutOfMemory;
     if (db) db_target = target + n_dw;
   }

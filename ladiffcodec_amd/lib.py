@@ -25,7 +25,7 @@ EXPORTS = [
     "ldc_sconv1d", "ldc_sconvtr1d", "ldc_slstm", "ldc_unet_debug_tap", "ldc_unet_step_cost", "ldc_profile_enable",
     "ldc_profile_read", "ldc_profile_read_classes", "ldc_conv_microbench", "ldc_conv_compare", "ldc_conv_compare_fp8", "ldc_ln_fold_compare", "ldc_gn_microbench", "ldc_host_stats", "ldc_stream_info", "ldc_clock_sample", "ldc_debug_raise_failure", "ldc_debug_sync_count", "ldc_xcc_census", "ldc_timeline_enable", "ldc_timeline_read", "ldc_kstamps_enable", "ldc_kstamps_reset", "ldc_kstamps_read", "ldc_packed_bytes", "ldc_pack_codes", "ldc_unpack_codes",
     "ldc_ac_build_cdf", "ldc_ac_encode", "ldc_ac_decode", "ldc_train_q_sample", "ldc_train_num_timesteps", "ldc_train_predict_x_start", "ldc_train_neg_sdsdr", "ldc_train_l1_loss", "ldc_train_block_ws_floats",
-    "ldc_train_block_forward", "ldc_train_block_backward", "ldc_train_layernorm_forward", "ldc_train_layernorm_backward", "ldc_train_adam_step", "ldc_train_adam_step_dev", "ldc_train_pointwise_forward", "ldc_train_pointwise_backward", "ldc_train_linattn_ws_floats", "ldc_train_linattn_forward", "ldc_train_linattn_backward", "ldc_train_conv_forward", "ldc_train_conv_backward", "ldc_train_join", "ldc_train_upsample2", "ldc_train_activation", "ldc_train_attn_ws_floats", "ldc_train_attn_forward", "ldc_train_attn_backward", "ldc_train_convtr_forward", "ldc_train_convtr_backward", "ldc_train_maxscale", "ldc_resample_out_len", "ldc_resample",
+    "ldc_train_block_forward", "ldc_train_block_backward", "ldc_train_layernorm_forward", "ldc_train_layernorm_backward", "ldc_train_adam_step", "ldc_train_adam_step_dev", "ldc_train_pointwise_forward", "ldc_train_pointwise_backward", "ldc_train_linattn_ws_floats", "ldc_train_linattn_forward", "ldc_train_linattn_backward", "ldc_train_conv_forward", "ldc_train_conv_backward", "ldc_train_join", "ldc_train_side_stream", "ldc_train_upsample2", "ldc_train_activation", "ldc_train_attn_ws_floats", "ldc_train_attn_forward", "ldc_train_attn_backward", "ldc_train_convtr_forward", "ldc_train_convtr_backward", "ldc_train_maxscale", "ldc_resample_out_len", "ldc_resample",
 ]
 
 
@@ -147,6 +147,7 @@ def load() -> C.CDLL:
     lib.ldc_train_conv_forward.argtypes = [vp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, fp, vp]
     lib.ldc_train_conv_backward.argtypes = [vp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, fp, fp, fp, vp]
     lib.ldc_train_join.argtypes = [vp, vp]
+    lib.ldc_train_side_stream.argtypes = [vp, C.POINTER(C.c_void_p)]
     lib.ldc_train_upsample2.argtypes = [vp, fp, C.c_int64, i32, i32, fp, vp]
     lib.ldc_train_activation.argtypes = [vp, fp, fp, C.c_int64, i32, fp, vp]
     lib.ldc_train_attn_ws_floats.argtypes = [i32, i32, i32]

@@ -77,6 +77,42 @@ class Block:
         return out
 
 
+def _keep_for_side(eng, *tensors):
+    """A backward call that put a parameter gradient on the library's side stream (option train_dw_side, set by DiffusionTrainer around its
+    backward pass) still reads these tensors there: tell torch's caching allocator, so that their memory is not handed out again before
+    the side stream is through (the layers' saved inputs live until their next forward and need no mark)."""
+    ext = getattr(eng, "_dw_side_ext", None)
+    if ext is not None:
+        for v in tensors:
+            if v is not None:
+                v.record_stream(ext)
+
+
+class _SideRegion:
+    """`with _SideRegion(eng):` -- the layer calls and the ATen glue inside run on the library's training side stream (when the trainer has
+    switched it on; otherwise in line): the backward of the time-embedding branch feeds nothing but parameter gradients, so it need not sit
+    on the dX chain.  The side stream first waits for what the main stream has produced so far; DiffusionTrainer joins the two after the
+    backward pass (ldc_train_join).  Launches on the side stream take their own workspaces in the library (csrc/train_mm3.hip: lane_of)."""
+
+    def __init__(self, eng):
+        self.eng, self.ext = eng, getattr(eng, "_dw_side_ext", None)
+
+    def __enter__(self):
+        if self.ext is not None:
+            self.main = self.eng.stream
+            self.ext.wait_stream(self.main)
+            self.eng.stream = self.ext
+            self.ctx = self.eng.torch.cuda.stream(self.ext)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ext is not None:
+            self.ctx.__exit__(*exc)
+            self.eng.stream = self.main
+        return False
+
+
 def q_sample(eng, x_start, t, noise):
     """diffusion.q_sample (ddpm_loss.py:386-392)."""
     tt = eng.torch
@@ -135,6 +171,7 @@ class LayerNorm:
         L.check(self.lib.ldc_train_layernorm_backward(self.eng._ctx, dy.data_ptr(), x.data_ptr(), self.g.data_ptr(), stats.data_ptr(), B, Cc, Lx,
                                                       dx.data_ptr(), dg.data_ptr(), s))
         self.eng._exit()
+        _keep_for_side(self.eng, dy)
         return dx, dg
 
 
@@ -216,6 +253,7 @@ class Pointwise:
                                                       int(self.pre_silu), dx.data_ptr() if dx is not None else None, dw.data_ptr(),
                                                       db.data_ptr() if db is not None else None, s))
         self.eng._exit()
+        _keep_for_side(self.eng, dy)
         out = {"dw": dw}
         if db is not None:
             out["db"] = db
@@ -237,10 +275,25 @@ class ResnetBlock:
         self.block2 = Block(eng, p["block2.proj.weight"], p["block2.proj.bias"], p["block2.norm.weight"], p["block2.norm.bias"], groups)
         self.res = Pointwise(eng, p["res_conv.weight"], p["res_conv.bias"]) if "res_conv.weight" in p else None
 
+    def precompute_scale_shift(self, time_emb):
+        """The block's (scale, shift) = mlp(time_emb) ahead of its forward (Unet1D.forward runs the whole time-embedding branch on the side
+        stream at the start of a training step); an event marks it ready for the stream the block itself runs on."""
+        ss = self.mlp.forward(time_emb)
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.eng.device))
+        self._ss_pre = (ss, ev)
+
     def forward(self, x, time_emb):
         t = self.torch
         x = x.to(self.eng.device, t.float32).contiguous()
-        ss = self.mlp.forward(time_emb)                                     # [B, 2 * Cout]
+        pre, self._ss_pre = getattr(self, "_ss_pre", None), None
+        if pre is not None:
+            ss, ev = pre
+            cur = t.cuda.current_stream(self.eng.device)
+            cur.wait_event(ev)
+            ss.record_stream(cur)
+        else:
+            ss = self.mlp.forward(time_emb)                                 # [B, 2 * Cout]
         cout = ss.shape[1] // 2
         scale, shift = ss[:, :cout].reshape(-1, cout, 1), ss[:, cout:].reshape(-1, cout, 1)
         h = self.block1.forward(x, (scale, shift))
@@ -253,8 +306,10 @@ class ResnetBlock:
         dy = dy.to(self.eng.device, t.float32).contiguous()
         g2 = self.block2.backward(dy)
         g1 = self.block1.backward(g2["dx"])
-        dss = t.cat([g1["dscale"].reshape(dy.shape[0], -1), g1["dshift"].reshape(dy.shape[0], -1)], dim=1)
-        gm = self.mlp.backward(dss)
+        _keep_for_side(self.eng, g1["dscale"], g1["dshift"])
+        with _SideRegion(self.eng):      # (the time-embedding branch: parameter gradients only)
+            dss = t.cat([g1["dscale"].reshape(dy.shape[0], -1), g1["dshift"].reshape(dy.shape[0], -1)], dim=1)
+            gm = self.mlp.backward(dss)
         out = {"mlp.1.weight": gm["dw"], "mlp.1.bias": gm["db"], "dtime_emb": gm["dx"],
                "block1.proj.weight": g1["dw"], "block1.proj.bias": g1["db"], "block1.norm.weight": g1["dgamma"], "block1.norm.bias": g1["dbeta"],
                "block2.proj.weight": g2["dw"], "block2.proj.bias": g2["db"], "block2.norm.weight": g2["dgamma"], "block2.norm.bias": g2["dbeta"]}
@@ -353,6 +408,7 @@ class Conv1d:
                                                  self.padding, dx.data_ptr() if dx is not None else None, dw.data_ptr(),
                                                  db.data_ptr() if db is not None else None, s))
         self.eng._exit()
+        _keep_for_side(self.eng, dy)
         return {"dx": dx, "dw": dw, "db": db}
 
 
@@ -544,10 +600,23 @@ class Unet1D:
             self._cond_pre_scale = x_cond.to(self.eng.device, t.float32).contiguous()
             x_cond = maxscale(self.eng, self._cond_pre_scale)
         x = t.cat((x_cond.to(self.eng.device, t.float32), x.to(self.eng.device, t.float32)), dim=1).contiguous()
-        x = self.init_conv.forward(x)
-        r = x
-        self._t_pre = self.t1.forward(self._sinusoidal(time))
-        temb = self.t2.forward(activation(self.eng, self._t_pre, ACT_GELU))
+        if getattr(self.eng, "_dw_side_ext", None) is not None:
+            # training step: the time-embedding branch (time_mlp and the 23 per-block SiLU -> Linear maps) does not depend on x: all of it on
+            # the side stream now, under init_conv and the first blocks; every ResnetBlock waits for its own (scale, shift)
+            with _SideRegion(self.eng):
+                self._t_pre = self.t1.forward(self._sinusoidal(time))
+                temb = self.t2.forward(activation(self.eng, self._t_pre, ACT_GELU))
+                blocks = [b for rb1, rb2, _, _ in self.downs for b in (rb1, rb2)] + [self.mid1, self.mid2]
+                blocks += [b for rb1, rb2, _, _, _ in self.ups for b in (rb1, rb2)] + [self.final_res]
+                for rb in blocks:
+                    rb.precompute_scale_shift(temb)
+            x = self.init_conv.forward(x)
+            r = x
+        else:
+            x = self.init_conv.forward(x)
+            r = x
+            self._t_pre = self.t1.forward(self._sinusoidal(time))
+            temb = self.t2.forward(activation(self.eng, self._t_pre, ACT_GELU))
         h = []
         for rb1, rb2, attn, down in self.downs:
             x = rb1.forward(x, temb); h.append(x)
@@ -577,7 +646,8 @@ class Unet1D:
         def rb_back(rb, prefix, d):
             nonlocal dtemb
             g = rb.backward(d)
-            dtemb = g["dtime_emb"] if dtemb is None else dtemb + g["dtime_emb"]
+            with _SideRegion(self.eng):
+                dtemb = g["dtime_emb"] if dtemb is None else dtemb + g["dtime_emb"]
             for k, v in g.items():
                 if k not in ("dx", "dtime_emb"):
                     grads[prefix + k] = v
@@ -634,10 +704,11 @@ class Unet1D:
         d = d + dr
         g = self.init_conv.backward(d)
         grads["init_conv.weight"], grads["init_conv.bias"] = g["dw"], g["db"]
-        g2 = self.t2.backward(dtemb)
-        grads["time_mlp.3.weight"], grads["time_mlp.3.bias"] = g2["dw"], g2["db"]
-        g1 = self.t1.backward(activation(self.eng, self._t_pre, ACT_GELU, dy=g2["dx"]), want_dx=False)
-        grads["time_mlp.1.weight"], grads["time_mlp.1.bias"] = g1["dw"], g1["db"]
+        with _SideRegion(self.eng):
+            g2 = self.t2.backward(dtemb)
+            grads["time_mlp.3.weight"], grads["time_mlp.3.bias"] = g2["dw"], g2["db"]
+            g1 = self.t1.backward(activation(self.eng, self._t_pre, ACT_GELU, dy=g2["dx"]), want_dx=False)
+            grads["time_mlp.1.weight"], grads["time_mlp.1.bias"] = g1["dw"], g1["db"]
         cc = self._ccond
         dx, dcond = g["dx"][:, cc:].contiguous(), g["dx"][:, :cc].contiguous()
         if self.scale_cond:
@@ -710,7 +781,8 @@ class DiffusionTrainer:
         self._grad_views = {p.data_ptr(): g for p, g in zip(self.state_dict().values(), self._views(self.flat_g).values())}
         self.num_timesteps = int(eng.lib.ldc_train_num_timesteps(eng._ctx))
         self.opt = Adam(eng, self.flat, lr=lr)
-        self.dw_side = True        # the Blocks' weight-gradient GEMMs on the library's side stream, under the dX chain (round 6: 49.9 -> 48.1 ms per full-width step, same box; bit-identical gradients)
+        self.dw_side = True        # parameter gradients (weight-gradient GEMMs, their reductions, norm gains) on the library's side stream, under the dX chain (round 6: 49.3 -> 42.5 ms per full-width step, same box; bit-identical gradients)
+        self._side_ext = None
         self.use_graph = False     # the step as one replayed hipGraph (see _step_graphed): opt-in attribute, measured equal (49.96 vs 49.75 ms)
         self._graph, self._graph_key, self._graph_seen, self._graph_in, self._graph_out = None, None, 0, None, None
 
@@ -813,29 +885,36 @@ class DiffusionTrainer:
             loss = p_losses_objective(eng, out, noise, t, want_grad=False)
             return self._report(loss, x_t, out, t, wav, latent_scale) if monitor else loss
         eng._grad_views, eng._grad_written = self._grad_views, set()
+        # What feeds nothing but parameter gradients -- the weight-gradient GEMMs with their reductions, norm gains, the whole time-embedding
+        # branch -- runs on the library's side stream, under the dX chain (csrc/train.hip: dw_side_fork; _SideRegion); so does the
+        # time-embedding branch of the forward pass.  Joined before anything reads a parameter gradient.  The layers keep what those
+        # launches read until their next forward; temporaries are marked for the allocator (_keep_for_side).
+        side = bool(self.dw_side) and not self.torch.cuda.is_current_stream_capturing()
+        if side:
+            if self._side_ext is None:
+                import ctypes
+                h = ctypes.c_void_p()
+                LL.check(eng.lib.ldc_train_side_stream(eng._ctx, ctypes.byref(h)))
+                self._side_ext = self.torch.cuda.ExternalStream(h.value, device=eng.device)
+            eng.set_option("train_dw_side", 1)
+            eng._dw_side_ext = self._side_ext
         try:
             x_t = q_sample(eng, x_start, t, noise)
             out = self.net.forward(x_t, t, cond)
             loss, grad = p_losses_objective(eng, out, noise, t)
-            # the weight-gradient GEMMs of the Blocks on the library's side stream, under the dX chain (csrc/train.hip: dw_side_fork);
-            # joined before anything reads a parameter gradient.  The layers keep what those launches read until their next forward.
-            side = bool(self.dw_side)
-            if side:
-                eng.set_option("train_dw_side", 1)
-            try:
-                grads, _, _ = self.net.backward(grad)
-            finally:
-                if side:
-                    eng.set_option("train_dw_side", 0)
-                    s = eng._enter()
-                    LL.check(eng.lib.ldc_train_join(eng._ctx, s))
-                    eng._exit()
+            grads, _, _ = self.net.backward(grad)
             missing = set(self._grad_views) - eng._grad_written
             if missing or set(grads) != set(self.names):
                 raise RuntimeError(f"backward left {len(missing)} parameter gradient(s) unwritten; key mismatch: "
                                    f"{sorted(set(self.names) ^ set(grads))[:5]}")
         finally:
             eng._grad_views = None
+            if side:
+                eng.set_option("train_dw_side", 0)
+                eng._dw_side_ext = None
+                s = eng._enter()
+                LL.check(eng.lib.ldc_train_join(eng._ctx, s))
+                eng._exit()
         parallel.allreduce_gradients(self.flat_g)      # no-op without a process group
         self.opt.step(self.flat_g)
         return self._report(loss, x_t, out, t, wav, latent_scale) if monitor else loss
