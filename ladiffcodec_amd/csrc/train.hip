@@ -578,7 +578,17 @@ __global__ __launch_bounds__(1024) void gn_silu_forward_lds_kernel(const float* 
   const int b = blockIdx.y, g = blockIdx.x, cpg = C / groups, n = cpg * L;
   const float* p = h + ((size_t)b * C + (size_t)g * cpg) * L;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) { const float v = p[i]; slab[i] = v; s += v; }
+  int i0 = threadIdx.x;
+  // (round 6: eight loads in flight per thread -- one workgroup per CU streams its 150 KB with 16 waves; same elements per thread in the
+  // same order: bit-identical sums)
+  for (; i0 + 7 * 1024 < n; i0 += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[i0 + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { slab[i0 + u * 1024] = v[u]; s += v[u]; }
+  }
+  for (; i0 < n; i0 += 1024) { const float v = p[i0]; slab[i0] = v; s += v; }
   const float mean = block_sum16(s, red) / (float)n;       // (the barriers inside make the slab visible to every thread)
   float q = 0.f;
   for (int i = threadIdx.x; i < n; i += 1024) { const float d = slab[i] - mean; q += d * d; }
@@ -818,7 +828,15 @@ __global__ __launch_bounds__(256) void ln_forward_kernel(const float* x, const f
   const float rstd = rsqrtf(ln_quad_sum(ss, red, w, lx) / (float)C + 1e-5f);
   if (!ok) return;
   float* yb = y + (size_t)b * C * L + l;
-  for (c = w; c < C; c += 4) yb[(size_t)c * L] = (xb[(size_t)c * L] - mean) * rstd * g[c];
+  c = w;
+  for (; c + 28 < C; c += 32) {   // (eight loads in flight, as ln_backward_dx_kernel)
+    float xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = xb[(size_t)(c + 4 * u) * L];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) yb[(size_t)(c + 4 * u) * L] = (xv[u] - mean) * rstd * g[c + 4 * u];
+  }
+  for (; c < C; c += 4) yb[(size_t)c * L] = (xb[(size_t)c * L] - mean) * rstd * g[c];
   if (w == 0) {
     stats[((size_t)b * L + l) * 2] = mean;
     stats[((size_t)b * L + l) * 2 + 1] = rstd;
@@ -835,6 +853,19 @@ __global__ __launch_bounds__(256) void ln_backward_dx_kernel(const float* dy, co
   const float mean = stats[sidx], rstd = stats[sidx + 1];
   float s1 = 0.f, s2 = 0.f;
   int c = w;
+  // (round 6: eight channels' loads in flight per thread instead of two -- the kernel is a latency chain of 256-byte row segments; the
+  // order in which a thread adds its channels is unchanged: bit-identical sums)
+  for (; c + 28 < C; c += 32) {
+    float xv[8], dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { xv[u] = x[base + (size_t)(c + 4 * u) * L]; dv[u] = dy[base + (size_t)(c + 4 * u) * L]; }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      const float da = dv[u] * g[c + 4 * u], db2 = dv[u + 1] * g[c + 4 * u + 4];
+      s1 += da + db2;
+      s2 += da * ((xv[u] - mean) * rstd) + db2 * ((xv[u + 1] - mean) * rstd);
+    }
+  }
   for (; c + 4 < C; c += 8) {
     const float xa = x[base + (size_t)c * L], xb2 = x[base + (size_t)(c + 4) * L];
     const float da = dy[base + (size_t)c * L] * g[c], db2 = dy[base + (size_t)(c + 4) * L] * g[c + 4];
@@ -849,7 +880,18 @@ __global__ __launch_bounds__(256) void ln_backward_dx_kernel(const float* dy, co
   s1 = ln_quad_sum(s1, red, w, lx) / (float)C;
   s2 = ln_quad_sum(s2, red, w, lx) / (float)C;
   if (!ok) return;
-  for (c = w; c < C; c += 4) {
+  c = w;
+  for (; c + 28 < C; c += 32) {
+    float xv[8], dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { xv[u] = x[base + (size_t)(c + 4 * u) * L]; dv[u] = dy[base + (size_t)(c + 4 * u) * L]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float xh = (xv[u] - mean) * rstd, dxh = dv[u] * g[c + 4 * u];
+      dx[base + (size_t)(c + 4 * u) * L] = rstd * (dxh - s1 - xh * s2);
+    }
+  }
+  for (; c < C; c += 4) {
     const float xh = (x[base + (size_t)c * L] - mean) * rstd, dxh = dy[base + (size_t)c * L] * g[c];
     dx[base + (size_t)c * L] = rstd * (dxh - s1 - xh * s2);
   }

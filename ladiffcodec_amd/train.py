@@ -781,7 +781,7 @@ class DiffusionTrainer:
         self._grad_views = {p.data_ptr(): g for p, g in zip(self.state_dict().values(), self._views(self.flat_g).values())}
         self.num_timesteps = int(eng.lib.ldc_train_num_timesteps(eng._ctx))
         self.opt = Adam(eng, self.flat, lr=lr)
-        self.dw_side = True        # parameter gradients (weight-gradient GEMMs, their reductions, norm gains) on the library's side stream, under the dX chain (round 6: 49.3 -> 42.5 ms per full-width step, same box; bit-identical gradients)
+        self.dw_side = True        # parameter gradients (weight-gradient GEMMs, their reductions, norm gains) on the library's side stream, under the dX chain (round 6: 48.5 -> 41.9 ms per full-width step, same box; bit-identical gradients)
         self._side_ext = None
         self.use_graph = False     # the step as one replayed hipGraph (see _step_graphed): opt-in attribute, measured equal (49.96 vs 49.75 ms)
         self._graph, self._graph_key, self._graph_seen, self._graph_in, self._graph_out = None, None, 0, None, None
