@@ -76,7 +76,7 @@ timed)
 configs)   # the other BASELINE configs (builder-run lines)
   timeout 300 python bench.py --config c1 --steps 20 --warmup 3 > $O/bench_c1.json 2> $O/bench_c1.err; tail -1 $O/bench_c1.err
   for c in c3 c8 c5 c4; do
-    timeout 900 python bench.py --config $c --steps 3 --warmup 1 > $O/bench_$c.json 2> $O/bench_$c.err; tail -1 $O/bench_$c.err
+    timeout 900 python bench.py --config $c --steps $([ $c = c4 ] && echo 6 || echo 3) --warmup $([ $c = c4 ] && echo 2 || echo 1) > $O/bench_$c.json 2> $O/bench_$c.err; tail -1 $O/bench_$c.err
   done
   timeout 600 python bench.py --dtype fp8 --steps 4 --warmup 1 --no-cpu-baseline --no-pipelined > $O/bench_c2_fp8.json 2> /dev/null
   python - <<PY
